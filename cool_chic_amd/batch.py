@@ -1,0 +1,119 @@
+"""DecodeBatch: many cool-chics in flight on one MI355X (wraps the ccd_batch_* C ABI)."""
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import CCHeader, check, lib
+
+FRAME_DATA_TYPES = ["rgb", "yuv420", "yuv444", "flow"]
+
+
+class _DevArray:
+    """Zero-copy view of library-owned device memory for torch.as_tensor(..., device='cuda')."""
+
+    def __init__(self, ptr: int, shape: Tuple[int, ...], typestr: str, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner  # keeps the batch (and its arena) alive
+
+
+class DecodeBatch:
+    """One slot per cool-chic; all slots decode concurrently in run().
+
+    Inputs (latent payload words, network parameters) are uploaded to HBM by add(); run() only
+    enqueues kernels on `stream` (a hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream).
+    """
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        check(lib().ccd_batch_create(int(device), C.byref(self._h)), "ccd_batch_create")
+        self.device = int(device)
+        self._meta: List[Tuple[int, int]] = []
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().ccd_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self):
+        return len(self._meta)
+
+    def add(self, cc_header: bytes, bytes_nn: bytes, bytes_latent: bytes, bitdepth: int = 0,
+            frame_data_type: int = 0) -> int:
+        slot = check(lib().ccd_batch_add(self._h, cc_header, len(cc_header), bytes_nn, len(bytes_nn), bytes_latent,
+                                         len(bytes_latent), int(bitdepth), int(frame_data_type)), "ccd_batch_add")
+        self._meta.append((int(bitdepth), int(frame_data_type)))
+        return slot
+
+    def header(self, slot: int) -> CCHeader:
+        h = CCHeader()
+        check(lib().ccd_batch_header(self._h, slot, C.byref(h)), "ccd_batch_header")
+        return h
+
+    def run(self, stream: int = 0, stage: Optional[int] = None):
+        st = C.c_void_p(stream or None)
+        if stage is None:
+            check(lib().ccd_batch_run(self._h, st), "ccd_batch_run")
+        else:
+            check(lib().ccd_batch_run_stage(self._h, st, int(stage)), "ccd_batch_run_stage")
+
+    def wait(self, stream: int = 0):
+        check(lib().ccd_batch_wait(self._h, C.c_void_p(stream or None)), "ccd_batch_wait")
+
+    def slot_status(self, slot: int) -> int:
+        return lib().ccd_batch_slot_status(self._h, slot)
+
+    # ---- results -------------------------------------------------------------------------------
+    def latent(self, slot: int, grid: int) -> np.ndarray:
+        h = self.header(slot)
+        out = np.empty((h.grid_h[grid], h.grid_w[grid]), dtype=np.int8)
+        check(lib().ccd_batch_copy_latent(self._h, slot, grid, out.ctypes.data, None), "copy_latent")
+        return out
+
+    def output(self, slot: int) -> np.ndarray:
+        h = self.header(slot)
+        out = np.empty((h.out_channels, h.img_size[0], h.img_size[1]), dtype=np.float32)
+        check(lib().ccd_batch_copy_output(self._h, slot, out.ctypes.data, None), "copy_output")
+        return out
+
+    def dense(self, slot: int) -> np.ndarray:
+        h = self.header(slot)
+        g0 = next(g for g in range(h.n_grids) if not h.is_hyperlatent[g])
+        out = np.empty((h.input_feature_synthesis, h.grid_h[g0], h.grid_w[g0]), dtype=np.float32)
+        check(lib().ccd_batch_copy_dense(self._h, slot, out.ctypes.data, None), "copy_dense")
+        return out
+
+    def plane_shape(self, slot: int, plane: int) -> Tuple[int, int]:
+        ph, pw = C.c_int(), C.c_int()
+        if not lib().ccd_batch_plane(self._h, slot, plane, C.byref(ph), C.byref(pw)):
+            raise ValueError("slot has no integer planes (added with bitdepth=0)")
+        return ph.value, pw.value
+
+    def planes(self, slot: int) -> List[np.ndarray]:
+        bd, _ = self._meta[slot]
+        res = []
+        for p in range(3):
+            shape = self.plane_shape(slot, p)
+            out = np.empty(shape, dtype=np.uint8 if bd == 8 else np.uint16)
+            check(lib().ccd_batch_copy_plane(self._h, slot, p, out.ctypes.data, None), "copy_plane")
+            res.append(out)
+        return res
+
+    def output_device(self, slot: int) -> _DevArray:
+        h = self.header(slot)
+        ptr = lib().ccd_batch_output(self._h, slot)
+        return _DevArray(ptr, (1, h.out_channels, h.img_size[0], h.img_size[1]), "<f4", self)
+
+    def plane_device(self, slot: int, plane: int) -> _DevArray:
+        bd, _ = self._meta[slot]
+        ph, pw = C.c_int(), C.c_int()
+        ptr = lib().ccd_batch_plane(self._h, slot, plane, C.byref(ph), C.byref(pw))
+        return _DevArray(ptr, (ph.value, pw.value), "|u1" if bd == 8 else "<u2", self)

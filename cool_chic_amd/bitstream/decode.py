@@ -1,0 +1,124 @@
+"""decode_video / decode_frame on the MI355X - mirror of coolchic/bitstream/decode.py:26-212.
+
+All-intra streams (images, image sets) take the batched path: every frame's cool-chic is added to
+one DecodeBatch, all of them decode concurrently, and the reference's rounding / clamping / 4:2:0
+chain (decode.py:191-206) runs in the HIP epilogue that produces the integer planes."""
+import time
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ..batch import DecodeBatch
+from ..io import FrameData, save_frame_data_to_file
+from .component.coolchic import encode_decode_coolchic
+from .header import CoolChicHeader, FrameHeader, VideoHeader
+
+_FDT_INDEX = {"rgb": 0, "yuv420": 1, "yuv444": 2, "flow": 3}
+
+
+def _planes_to_frame_data(planes: List[torch.Tensor], bitdepth: int, frame_data_type: str) -> FrameData:
+    maxv = float(2 ** bitdepth - 1)
+    f = [p.to(torch.float32).div(maxv)[None, None] for p in planes]
+    if frame_data_type == "yuv420":
+        return FrameData(bitdepth, frame_data_type, {"y": f[0], "u": f[1], "v": f[2]})
+    return FrameData(bitdepth, frame_data_type, torch.cat(f, dim=1))
+
+
+def _split_frame(bitstream_bytes: bytes):
+    """decode.py:115-143: frame header, then per cool-chic header + NN bytes + latent bytes."""
+    fh = FrameHeader()
+    rest = fh.read_header(bitstream_bytes)
+    ccs = []
+    for _name in (["residue"] + (["motion"] if fh.get_value("frame_type") in ("P", "B") else [])):
+        ch = CoolChicHeader()
+        rest = ch.read_header(rest)
+        n_nn, n_lat = ch.get_value("nn_n_bytes"), ch.get_value("n_bytes_latent")
+        if len(rest) < n_nn + n_lat:
+            raise ValueError("bitstream truncated")
+        ccs.append((ch, rest[:n_nn], rest[n_nn:n_nn + n_lat]))
+        rest = rest[n_nn + n_lat:]
+    return fh, ccs, rest
+
+
+@torch.no_grad()
+def decode_frame(bitstream_bytes: bytes, reference_frames: List[FrameData], verbosity: int = 0,
+                 device: int = 0) -> Tuple[FrameData, bytes]:
+    """decode.py:96-212. Returns the decoded FrameData and the remaining bytes."""
+    fh, ccs, rest = _split_frame(bitstream_bytes)
+    if verbosity:
+        print(fh.pretty_string())
+    frame_type, bitdepth, fdt = fh.get_value("frame_type"), fh.get_value("bitdepth"), fh.get_value("frame_data_type")
+    if frame_type != "I":
+        from .intercoding import reconstruct_inter_frame  # P / B frames
+
+        outs = [encode_decode_coolchic(ch, nn, "decode", dec_bytes_latent=lat, verbosity=verbosity,
+                                       device=f"cuda:{device}")[0] for ch, nn, lat in ccs]
+        return reconstruct_inter_frame(fh, outs[0], outs[1], reference_frames), rest
+    ch, nn, lat = ccs[0]
+    batch = DecodeBatch(device)
+    try:
+        batch.add(ch.raw, nn, lat, bitdepth, _FDT_INDEX[fdt])
+        stream = torch.cuda.current_stream(device).cuda_stream
+        batch.run(stream)
+        batch.wait(stream)
+        planes = [torch.as_tensor(batch.plane_device(0, p), device=f"cuda:{device}").clone() for p in range(3)]
+    finally:
+        batch.close()
+    return _planes_to_frame_data(planes, bitdepth, fdt), rest
+
+
+@torch.no_grad()
+def decode_video(bitstream_path: str, decoded_path: Optional[str] = None, max_decoding_order: int = -1,
+                 verbosity: int = 0, device: int = 0) -> Dict[str, FrameData]:
+    """decode.py:26-91: decode a .cool file; returns {display index as str: FrameData}."""
+    with open(bitstream_path, "rb") as f:
+        bitstream_bytes = f.read()
+    vh = VideoHeader()
+    bitstream_bytes = vh.read_header(bitstream_bytes)
+    if verbosity:
+        print(vh.pretty_string())
+    n_frames = vh.get_value("n_frames")
+    all_intra = vh.get_value("n_intras") == n_frames
+    if max_decoding_order == -1:
+        max_decoding_order = n_frames - 1
+    frames: Dict[int, FrameData] = {}
+    if all_intra:
+        # every frame is independent: one batch, all cool-chics in flight together
+        start = time.time()
+        batch = DecodeBatch(device)
+        try:
+            meta = []
+            for _ in range(max_decoding_order + 1):
+                fh, ccs, bitstream_bytes = _split_frame(bitstream_bytes)
+                ch, nn, lat = ccs[0]
+                bd, fdt = fh.get_value("bitdepth"), fh.get_value("frame_data_type")
+                batch.add(ch.raw, nn, lat, bd, _FDT_INDEX[fdt])
+                meta.append((fh.get_value("display_index"), bd, fdt))
+            stream = torch.cuda.current_stream(device).cuda_stream
+            batch.run(stream)
+            batch.wait(stream)
+            for slot, (di, bd, fdt) in enumerate(meta):
+                planes = [torch.as_tensor(batch.plane_device(slot, p), device=f"cuda:{device}").clone()
+                          for p in range(3)]
+                frames[di] = _planes_to_frame_data(planes, bd, fdt)
+        finally:
+            batch.close()
+        print(f"Decoding {len(frames)} intra frame(s) time = {time.time() - start:6.2f} seconds.")
+    else:
+        from .codingstructure import coding_structure
+
+        order = coding_structure(n_frames, vh.get_value("intra_pos"), vh.get_value("p_pos"))
+        for coding_idx in range(max_decoding_order + 1):
+            start = time.time()
+            fr = order[coding_idx]
+            refs = [frames[r] for r in fr["index_references"]]
+            frame_data, bitstream_bytes = decode_frame(bitstream_bytes, refs, verbosity, device)
+            frames[fr["display_order"]] = frame_data
+            print(f"Decoding frame {fr['display_order']:<4} time = {time.time() - start:6.2f} seconds.")
+    all_frames = {}
+    for display_idx in sorted(frames):
+        all_frames[str(display_idx)] = frames[display_idx]
+        if decoded_path is not None:
+            save_frame_data_to_file(frames[display_idx], decoded_path, append=display_idx != 0)
+    return all_frames

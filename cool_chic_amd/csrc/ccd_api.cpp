@@ -1,0 +1,593 @@
+// ccd_api.cpp - C ABI of libccd.so (include/ccd.h): batch bookkeeping, device memory, stage launches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "ccd_device.hpp"
+#include "ccd_format.hpp"
+
+namespace ccd {
+// kernels (ccd_entropy.hip, ccd_float.hip)
+size_t entropy_lds_bytes(int dim, int arm_len);
+hipError_t launch_entropy(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_laplace_bounds(const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* sym,
+                                 const float* scale_table, int64_t n, uint32_t* left, uint32_t* right, hipStream_t stream);
+hipError_t launch_upsample_level(const UpsampleLevel& L, hipStream_t stream);
+hipError_t launch_i8_to_f32(const int8_t* in, float* out, size_t n, hipStream_t stream);
+hipError_t launch_syn_layer(const float* in, const float* in2, const float* wt, const float* bias, float* out, int c_in,
+                            int c_out, int k, int residual, int relu, int h, int w, hipStream_t stream);
+hipError_t launch_resize_nearest(const float* in, float* out, int c, int h_in, int w_in, int h_out, int w_out,
+                                 hipStream_t stream);
+hipError_t launch_planes(const float* src, void* p0, void* p1, void* p2, int h, int w, int bitdepth, int frame_data_type,
+                         hipStream_t stream);
+
+static const uint32_t kScaleBits[kNumScale] = {
+#include "../../include/ccd_scale_table.inc"
+};
+}  // namespace ccd
+
+using namespace ccd;
+
+#define HIP_TRY(expr)                           \
+    do {                                        \
+        hipError_t e__ = (expr);                \
+        if (e__ != hipSuccess) return CCD_ERR_HIP; \
+    } while (0)
+
+namespace {
+
+// Bump allocator over one hipMalloc: every slot's buffers live in a single arena.
+class Arena {
+public:
+    size_t reserve(size_t bytes) { size_t off = total_; total_ += (bytes + 255) & ~size_t{255}; return off; }
+    int commit() {
+        if (total_ == 0) total_ = 256;
+        return hipMalloc(&base_, total_) == hipSuccess ? CCD_OK : CCD_ERR_NOMEM;
+    }
+    template <typename T> T* at(size_t off) const { return reinterpret_cast<T*>(static_cast<char*>(base_) + off); }
+    void release() { if (base_) (void)hipFree(base_); base_ = nullptr; }
+    size_t total() const { return total_; }
+private:
+    void* base_ = nullptr;
+    size_t total_ = 0;
+};
+
+struct Slot {
+    ccd_cc_header hdr;
+    Network net;
+    int bitdepth = 0, frame_data_type = 0;
+    Arena arena;
+    EntropyParams ep;
+    std::vector<UpsampleLevel> levels;
+    int dense_c = 0, dense_h = 0, dense_w = 0;
+    float* d_dense = nullptr;
+    // synthesis
+    float* d_syn_params = nullptr;
+    std::vector<size_t> w_off, b_off;  // per main layer
+    size_t stab_w = 0, stab_b = 0, out_w = 0, out_b = 0;
+    float* d_tmp[2] = {nullptr, nullptr};
+    float* d_stab = nullptr;
+    float* d_syn_out = nullptr;  // [C][dense_h][dense_w]
+    float* d_out = nullptr;      // [C][H][W] (== d_syn_out when no resize)
+    void* d_plane[3] = {nullptr, nullptr, nullptr};
+    int plane_h[3] = {0, 0, 0}, plane_w[3] = {0, 0, 0};
+    int32_t* d_status = nullptr;
+    int status = CCD_OK;
+    int32_t host_status[4] = {0, 0, 0, 0};
+};
+
+}  // namespace
+
+struct ccd_batch {
+    int device = 0;
+    std::vector<std::unique_ptr<Slot>> slots;
+    EntropyParams* d_params = nullptr;
+    int n_params_uploaded = 0;
+    float* d_scale_table = nullptr;
+    size_t lds_bytes = 0;
+};
+
+extern "C" {
+
+const char* ccd_strerror(int code) {
+    switch (code) {
+        case CCD_OK: return "ok";
+        case CCD_ERR_TRUNCATED: return "bitstream truncated";
+        case CCD_ERR_VALUE: return "header value out of range";
+        case CCD_ERR_INVALID_DATA: return "invalid compressed data";
+        case CCD_ERR_UNSUPPORTED: return "feature not supported by this build";
+        case CCD_ERR_NOMEM: return "out of memory";
+        case CCD_ERR_HIP: return "HIP runtime error / no usable gfx950 device";
+        case CCD_ERR_ARG: return "bad argument";
+        default: return "unknown error";
+    }
+}
+
+const char* ccd_version(void) { return "ccd 0.1.0 gfx950"; }
+
+int ccd_read_video_header(const uint8_t* p, size_t n, ccd_video_header* h) { return (p && h) ? read_video_header(p, n, h) : CCD_ERR_ARG; }
+int ccd_read_frame_header(const uint8_t* p, size_t n, ccd_frame_header* h) { return (p && h) ? read_frame_header(p, n, h) : CCD_ERR_ARG; }
+int ccd_read_cc_header(const uint8_t* p, size_t n, ccd_cc_header* h) { return (p && h) ? read_cc_header(p, n, h) : CCD_ERR_ARG; }
+
+void ccd_free(void* p) { std::free(p); }
+
+// -------------------------------------------------------------------------------------------------
+// Batch
+// -------------------------------------------------------------------------------------------------
+int ccd_batch_create(int device, ccd_batch** out) {
+    if (!out) return CCD_ERR_ARG;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return CCD_ERR_HIP;
+    HIP_TRY(hipSetDevice(device));
+    ccd_batch* b = new (std::nothrow) ccd_batch();
+    if (!b) return CCD_ERR_NOMEM;
+    b->device = device;
+    if (hipMalloc(&b->d_scale_table, sizeof(kScaleBits)) != hipSuccess) { delete b; return CCD_ERR_NOMEM; }
+    if (hipMemcpy(b->d_scale_table, kScaleBits, sizeof(kScaleBits), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(b->d_scale_table); delete b; return CCD_ERR_HIP;
+    }
+    *out = b;
+    return CCD_OK;
+}
+
+void ccd_batch_destroy(ccd_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    for (auto& s : b->slots) s->arena.release();
+    if (b->d_params) (void)hipFree(b->d_params);
+    if (b->d_scale_table) (void)hipFree(b->d_scale_table);
+    delete b;
+}
+
+int ccd_batch_size(const ccd_batch* b) { return b ? static_cast<int>(b->slots.size()) : CCD_ERR_ARG; }
+
+int ccd_batch_header(const ccd_batch* b, int slot, ccd_cc_header* h) {
+    if (!b || !h || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
+    *h = b->slots[slot]->hdr;
+    return CCD_OK;
+}
+
+int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const uint8_t* bytes_nn, size_t n_nn,
+                  const uint8_t* bytes_latent, size_t n_lat, int bitdepth, int frame_data_type) {
+    if (!b || !cc_header || !bytes_nn || (!bytes_latent && n_lat)) return CCD_ERR_ARG;
+    if (bitdepth != 0 && (bitdepth < 8 || bitdepth > 16)) return CCD_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->device));
+    std::unique_ptr<Slot> sp(new (std::nothrow) Slot());
+    if (!sp) return CCD_ERR_NOMEM;
+    Slot& s = *sp;
+    int rc = read_cc_header(cc_header, n_hdr, &s.hdr);
+    if (rc < 0) return rc;
+    const ccd_cc_header& h = s.hdr;
+    if (n_lat % 4) return CCD_ERR_VALUE;  // np.frombuffer(dtype=uint32) raises (rangecoder.py:81)
+    if (h.flag_common_randomness) return CCD_ERR_UNSUPPORTED;
+    rc = decode_network(h, bytes_nn, n_nn, s.net);
+    if (rc < 0) return rc;
+    s.bitdepth = bitdepth; s.frame_data_type = frame_data_type;
+    const Network& net = s.net;
+
+    // ---- pack the integer networks ------------------------------------------------------------------
+    std::vector<int64_t> arm_blob;
+    for (const FixedLayer& L : net.arm.layers) {
+        arm_blob.insert(arm_blob.end(), L.w.begin(), L.w.end());
+        arm_blob.insert(arm_blob.end(), L.b.begin(), L.b.end());
+    }
+    arm_blob.insert(arm_blob.end(), net.arm.ws.begin(), net.arm.ws.end());
+    arm_blob.insert(arm_blob.end(), net.arm.bs.begin(), net.arm.bs.end());
+    std::vector<int64_t> ifce_blob;
+    std::vector<int32_t> ifce_off(h.n_grids, 0);
+    for (int g = 0; g < h.n_grids; ++g) {
+        if (net.ifce[g].dim == 0) continue;
+        ifce_off[g] = static_cast<int32_t>(ifce_blob.size());
+        const FixedLayer& L = net.ifce[g].layers[0];
+        ifce_blob.insert(ifce_blob.end(), L.w.begin(), L.w.end());
+        ifce_blob.insert(ifce_blob.end(), L.b.begin(), L.b.end());
+    }
+    const size_t lds = entropy_lds_bytes(h.total_context_arm, static_cast<int>(arm_blob.size()));
+    if (lds > 160 * 1024) return CCD_ERR_UNSUPPORTED;  // ARM too large for the LDS-resident kernel
+
+    // ---- geometry of the float stages ------------------------------------------------------------------
+    std::vector<int> lat_grids;
+    for (int g = 0; g < h.n_grids; ++g) if (!h.is_hyperlatent[g]) lat_grids.push_back(g);
+    const int n_levels = static_cast<int>(lat_grids.size());
+    if (n_levels < 1 || n_levels != h.input_feature_synthesis) return CCD_ERR_VALUE;
+    if (n_levels > 1 && net.n_ups < 1) return CCD_ERR_VALUE;
+    s.dense_c = n_levels; s.dense_h = h.grid_h[lat_grids[0]]; s.dense_w = h.grid_w[lat_grids[0]];
+    const int H = h.img_size[0], W = h.img_size[1];
+    const bool need_resize = (s.dense_h != H || s.dense_w != W);
+    if (need_resize && h.final_upsampling_type != 0) return CCD_ERR_UNSUPPORTED;  // bilinear / bicubic resize
+    if (bitdepth != 0 && h.out_channels < 3) return CCD_ERR_ARG;
+
+    // ---- arena layout --------------------------------------------------------------------------------
+    Arena& A = s.arena;
+    const size_t n_words = n_lat / 4;
+    const size_t o_words = A.reserve((n_words + 2) * 4);
+    const size_t o_arm = A.reserve(arm_blob.size() * 8);
+    const size_t o_ifce = A.reserve(std::max<size_t>(ifce_blob.size(), 1) * 8);
+    std::vector<size_t> o_lat(h.n_grids);
+    size_t feat_px = 1;
+    for (int g = 0; g < h.n_grids; ++g) {
+        o_lat[g] = A.reserve(static_cast<size_t>(h.grid_h[g]) * h.grid_w[g]);
+        if (h.input_features_ifce[g] > 0) {
+            const int fg = (g == h.n_grids - 1) ? g : g + 1;
+            feat_px = std::max(feat_px, static_cast<size_t>(h.grid_h[fg]) * h.grid_w[fg]);
+        }
+    }
+    const size_t o_feat = A.reserve(feat_px * std::max(h.output_feature_ifce, 1) * 4);
+    const size_t o_status = A.reserve(64);
+    const size_t dense_elems = static_cast<size_t>(n_levels) * s.dense_h * s.dense_w;
+    const size_t o_stack_a = A.reserve(dense_elems * 4);
+    size_t stack_b_elems = 1;
+    if (n_levels >= 3) {
+        const int g1 = lat_grids[1];
+        stack_b_elems = static_cast<size_t>(n_levels - 1) * h.grid_h[g1] * h.grid_w[g1];
+    }
+    const size_t o_stack_b = A.reserve(stack_b_elems * 4);
+    // synthesis parameters blob
+    std::vector<float> syn_blob;
+    auto push = [&](const std::vector<float>& v) { size_t off = syn_blob.size(); syn_blob.insert(syn_blob.end(), v.begin(), v.end()); return off; };
+    s.w_off.clear(); s.b_off.clear();
+    int max_c = h.out_channels;
+    for (const SynLayerParams& L : net.syn) { s.w_off.push_back(push(L.w)); s.b_off.push_back(push(L.b)); max_c = std::max(max_c, L.c_out); }
+    if (net.syn_stab.c_out) { s.stab_w = push(net.syn_stab.w); s.stab_b = push(net.syn_stab.b); }
+    s.out_w = push(net.syn_out.w); s.out_b = push(net.syn_out.b);
+    const size_t o_synp = A.reserve(syn_blob.size() * 4);
+    const size_t plane_px = static_cast<size_t>(s.dense_h) * s.dense_w;
+    const size_t o_tmp0 = A.reserve(plane_px * max_c * 4);
+    const size_t o_tmp1 = A.reserve(plane_px * max_c * 4);
+    const size_t o_stab = A.reserve(plane_px * std::max(h.out_channels, 1) * 4);
+    const size_t o_synout = A.reserve(plane_px * std::max(h.out_channels, 1) * 4);
+    const size_t o_out = need_resize ? A.reserve(static_cast<size_t>(H) * W * h.out_channels * 4) : o_synout;
+    size_t o_plane[3] = {0, 0, 0};
+    const size_t sample_bytes = bitdepth == 8 ? 1 : 2;
+    if (bitdepth) {
+        for (int p = 0; p < 3; ++p) {
+            const bool chroma420 = (frame_data_type == 1 && p > 0);
+            s.plane_h[p] = chroma420 ? H / 2 : H;
+            s.plane_w[p] = chroma420 ? W / 2 : W;
+            o_plane[p] = A.reserve(static_cast<size_t>(s.plane_h[p]) * s.plane_w[p] * sample_bytes + 16);
+        }
+    }
+    rc = A.commit();
+    if (rc < 0) return rc;
+
+    // ---- uploads (inputs become resident in HBM here) ----------------------------------------------------
+    auto fail = [&](int code) { A.release(); return code; };
+    if (hipMemset(A.at<char>(0), 0, A.total()) != hipSuccess) return fail(CCD_ERR_HIP);
+    if (n_words && hipMemcpy(A.at<void>(o_words), bytes_latent, n_words * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(CCD_ERR_HIP);
+    if (hipMemcpy(A.at<void>(o_arm), arm_blob.data(), arm_blob.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail(CCD_ERR_HIP);
+    if (!ifce_blob.empty() && hipMemcpy(A.at<void>(o_ifce), ifce_blob.data(), ifce_blob.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail(CCD_ERR_HIP);
+    if (!syn_blob.empty() && hipMemcpy(A.at<void>(o_synp), syn_blob.data(), syn_blob.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(CCD_ERR_HIP);
+
+    // ---- entropy stage description -----------------------------------------------------------------------
+    EntropyParams& E = s.ep;
+    std::memset(&E, 0, sizeof(E));
+    E.words = A.at<uint32_t>(o_words); E.n_words = static_cast<uint32_t>(n_words);
+    E.n_grids = h.n_grids;
+    int level = 0;
+    for (int g = 0; g < h.n_grids; ++g) {
+        E.grid_h[g] = h.grid_h[g]; E.grid_w[g] = h.grid_w[g];
+        E.latent[g] = A.at<int8_t>(o_lat[g]);
+        E.ifce_in[g] = h.input_features_ifce[g];
+        E.ifce_off[g] = ifce_off[g];
+        if (g > 0 && (h.grid_h[g] != h.grid_h[g - 1] || h.grid_w[g] != h.grid_w[g - 1])) ++level;
+        E.level[g] = level;
+    }
+    E.dim = h.total_context_arm; E.n_spatial = h.spatial_context_arm; E.n_ifce_out = h.output_feature_ifce;
+    E.n_layers = h.n_hidden_layers_arm + 1;
+    E.narrow = net.arm.narrow ? 1 : 0;
+    E.has_ifce = h.has_ifce_resolution;
+    context_offsets(h.spatial_context_arm, E.ctx_dy, E.ctx_dx);
+    E.arm = A.at<int64_t>(o_arm); E.arm_len = static_cast<int32_t>(arm_blob.size());
+    E.ifce = A.at<int64_t>(o_ifce);
+    E.ifce_feat = A.at<int32_t>(o_feat);
+    E.scale_table = b->d_scale_table;
+    E.status = A.at<int32_t>(o_status);
+    s.d_status = E.status;
+
+    // ---- upsampling levels (upsampling.py:486-498): coarsest -> finest -------------------------------------
+    s.levels.clear();
+    float* stack_a = A.at<float>(o_stack_a);
+    float* stack_b = A.at<float>(o_stack_b);
+    const int n_steps = n_levels - 1;
+    const float* prev = nullptr;
+    for (int step = 0; step < n_steps; ++step) {
+        const int g_in = lat_grids[n_levels - 1 - step], g_out = lat_grids[n_levels - 2 - step];
+        UpsampleLevel L;
+        std::memset(&L, 0, sizeof(L));
+        L.in_f32 = prev;
+        L.in_i8 = (step == 0) ? E.latent[g_in] : nullptr;
+        L.target = E.latent[g_out];
+        L.out = ((n_steps - 1 - step) % 2 == 0) ? stack_a : stack_b;
+        L.c_in = step + 1;
+        L.h_in = h.grid_h[g_in]; L.w_in = h.grid_w[g_in];
+        L.h_out = h.grid_h[g_out]; L.w_out = h.grid_w[g_out];
+        L.ups_k = net.ups_k; L.pre_k = net.pre_k;
+        const int kidx = step % net.n_ups;
+        std::copy_n(&net.ups_w[static_cast<size_t>(kidx) * net.ups_k], net.ups_k, L.ups_w);
+        std::copy_n(&net.pre_w[static_cast<size_t>(kidx) * net.pre_k], net.pre_k, L.pre_w);
+        s.levels.push_back(L);
+        prev = L.out;
+    }
+    s.d_dense = stack_a;
+    s.d_syn_params = A.at<float>(o_synp);
+    s.d_tmp[0] = A.at<float>(o_tmp0); s.d_tmp[1] = A.at<float>(o_tmp1);
+    s.d_stab = A.at<float>(o_stab);
+    s.d_syn_out = A.at<float>(o_synout);
+    s.d_out = A.at<float>(o_out);
+    for (int p = 0; p < 3; ++p) s.d_plane[p] = bitdepth ? A.at<void>(o_plane[p]) : nullptr;
+
+    b->lds_bytes = std::max(b->lds_bytes, lds);
+    b->slots.push_back(std::move(sp));
+    return static_cast<int>(b->slots.size()) - 1;
+}
+
+static int upload_params(ccd_batch* b) {
+    const int n = static_cast<int>(b->slots.size());
+    if (b->n_params_uploaded == n) return CCD_OK;
+    if (b->d_params) { (void)hipFree(b->d_params); b->d_params = nullptr; }
+    std::vector<EntropyParams> host(n);
+    for (int i = 0; i < n; ++i) host[i] = b->slots[i]->ep;
+    if (hipMalloc(&b->d_params, sizeof(EntropyParams) * std::max(n, 1)) != hipSuccess) return CCD_ERR_NOMEM;
+    if (n && hipMemcpy(b->d_params, host.data(), sizeof(EntropyParams) * n, hipMemcpyHostToDevice) != hipSuccess) return CCD_ERR_HIP;
+    b->n_params_uploaded = n;
+    return CCD_OK;
+}
+
+static int run_upsampling(Slot& s, hipStream_t st) {
+    if (s.levels.empty()) {
+        const int g = [&] { for (int i = 0; i < s.hdr.n_grids; ++i) if (!s.hdr.is_hyperlatent[i]) return i; return 0; }();
+        HIP_TRY(launch_i8_to_f32(s.ep.latent[g], s.d_dense, static_cast<size_t>(s.dense_h) * s.dense_w, st));
+        return CCD_OK;
+    }
+    for (const UpsampleLevel& L : s.levels) HIP_TRY(launch_upsample_level(L, st));
+    return CCD_OK;
+}
+
+static int run_synthesis(Slot& s, hipStream_t st) {
+    const Network& net = s.net;
+    const int h = s.dense_h, w = s.dense_w;
+    const float* x = s.d_dense;
+    int cur = 0;
+    for (size_t l = 0; l < net.syn.size(); ++l) {
+        const SynLayerParams& L = net.syn[l];
+        HIP_TRY(launch_syn_layer(x, nullptr, s.d_syn_params + s.w_off[l], s.d_syn_params + s.b_off[l], s.d_tmp[cur], L.c_in,
+                                 L.c_out, L.k, L.residual, L.relu, h, w, st));
+        x = s.d_tmp[cur];
+        cur ^= 1;
+    }
+    const float* stab = nullptr;
+    if (net.syn_stab.c_out) {
+        HIP_TRY(launch_syn_layer(s.d_dense, nullptr, s.d_syn_params + s.stab_w, s.d_syn_params + s.stab_b, s.d_stab,
+                                 net.syn_stab.c_in, net.syn_stab.c_out, 1, 0, 0, h, w, st));
+        stab = s.d_stab;
+    }
+    HIP_TRY(launch_syn_layer(x, stab, s.d_syn_params + s.out_w, s.d_syn_params + s.out_b, s.d_syn_out, net.syn_out.c_in,
+                             net.syn_out.c_out, 1, 0, 0, h, w, st));
+    const int H = s.hdr.img_size[0], W = s.hdr.img_size[1];
+    if (s.d_out != s.d_syn_out)
+        HIP_TRY(launch_resize_nearest(s.d_syn_out, s.d_out, s.hdr.out_channels, h, w, H, W, st));
+    if (s.bitdepth)
+        HIP_TRY(launch_planes(s.d_out, s.d_plane[0], s.d_plane[1], s.d_plane[2], H, W, s.bitdepth, s.frame_data_type, st));
+    return CCD_OK;
+}
+
+int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
+    if (!b) return CCD_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = upload_params(b);
+    if (rc < 0) return rc;
+    if (stage == 0) {
+        HIP_TRY(launch_entropy(b->d_params, static_cast<int>(b->slots.size()), b->lds_bytes, st));
+        return CCD_OK;
+    }
+    for (auto& sp : b->slots) {
+        rc = (stage == 1) ? run_upsampling(*sp, st) : (stage == 2 ? run_synthesis(*sp, st) : CCD_ERR_ARG);
+        if (rc < 0) return rc;
+    }
+    return CCD_OK;
+}
+
+int ccd_batch_run(ccd_batch* b, void* stream) {
+    for (int stage = 0; stage < 3; ++stage) {
+        const int rc = ccd_batch_run_stage(b, stream, stage);
+        if (rc < 0) return rc;
+    }
+    return CCD_OK;
+}
+
+int ccd_batch_wait(ccd_batch* b, void* stream) {
+    if (!b) return CCD_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    int first = CCD_OK;
+    for (auto& sp : b->slots) {
+        HIP_TRY(hipMemcpy(sp->host_status, sp->d_status, sizeof(sp->host_status), hipMemcpyDeviceToHost));
+        sp->status = sp->host_status[0];
+        if (first == CCD_OK && sp->status != CCD_OK) first = sp->status;
+    }
+    return first;
+}
+
+int ccd_batch_slot_status(const ccd_batch* b, int slot) {
+    if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
+    return b->slots[slot]->status;
+}
+
+const float* ccd_batch_output(const ccd_batch* b, int slot) {
+    return (b && slot >= 0 && slot < static_cast<int>(b->slots.size())) ? b->slots[slot]->d_out : nullptr;
+}
+const float* ccd_batch_dense(const ccd_batch* b, int slot) {
+    return (b && slot >= 0 && slot < static_cast<int>(b->slots.size())) ? b->slots[slot]->d_dense : nullptr;
+}
+const int8_t* ccd_batch_latent(const ccd_batch* b, int slot, int grid) {
+    if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size())) return nullptr;
+    const Slot& s = *b->slots[slot];
+    return (grid >= 0 && grid < s.hdr.n_grids) ? s.ep.latent[grid] : nullptr;
+}
+const void* ccd_batch_plane(const ccd_batch* b, int slot, int plane, int* h, int* w) {
+    if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size()) || plane < 0 || plane > 2) return nullptr;
+    const Slot& s = *b->slots[slot];
+    if (h) *h = s.plane_h[plane];
+    if (w) *w = s.plane_w[plane];
+    return s.d_plane[plane];
+}
+
+static int copy_out(ccd_batch* b, const void* src, void* dst, size_t bytes, void* stream) {
+    if (!src || !dst) return CCD_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CCD_OK;
+}
+
+int ccd_batch_copy_latent(ccd_batch* b, int slot, int grid, int8_t* host, void* stream) {
+    const int8_t* p = ccd_batch_latent(b, slot, grid);
+    if (!p) return CCD_ERR_ARG;
+    const ccd_cc_header& h = b->slots[slot]->hdr;
+    return copy_out(b, p, host, static_cast<size_t>(h.grid_h[grid]) * h.grid_w[grid], stream);
+}
+int ccd_batch_copy_plane(ccd_batch* b, int slot, int plane, void* host, void* stream) {
+    int ph = 0, pw = 0;
+    const void* p = ccd_batch_plane(b, slot, plane, &ph, &pw);
+    if (!p) return CCD_ERR_ARG;
+    return copy_out(b, p, host, static_cast<size_t>(ph) * pw * (b->slots[slot]->bitdepth == 8 ? 1 : 2), stream);
+}
+int ccd_batch_copy_output(ccd_batch* b, int slot, float* host, void* stream) {
+    const float* p = ccd_batch_output(b, slot);
+    if (!p) return CCD_ERR_ARG;
+    const ccd_cc_header& h = b->slots[slot]->hdr;
+    return copy_out(b, p, host, static_cast<size_t>(h.out_channels) * h.img_size[0] * h.img_size[1] * 4, stream);
+}
+int ccd_batch_copy_dense(ccd_batch* b, int slot, float* host, void* stream) {
+    const float* p = ccd_batch_dense(b, slot);
+    if (!p) return CCD_ERR_ARG;
+    const Slot& s = *b->slots[slot];
+    return copy_out(b, p, host, static_cast<size_t>(s.dense_c) * s.dense_h * s.dense_w * 4, stream);
+}
+
+// -------------------------------------------------------------------------------------------------
+// One-shot conveniences
+// -------------------------------------------------------------------------------------------------
+int ccd_decode_coolchic(const uint8_t* cc_header, size_t n_hdr, const uint8_t* bytes_nn, size_t n_nn,
+                        const uint8_t* bytes_latent, size_t n_lat, int device, void* stream, float* out,
+                        int out_on_device) {
+    if (!out) return CCD_ERR_ARG;
+    if (!bytes_latent) return CCD_ERR_ARG;  // coolchic.py:46-51
+    ccd_batch* b = nullptr;
+    int rc = ccd_batch_create(device, &b);
+    if (rc < 0) return rc;
+    rc = ccd_batch_add(b, cc_header, n_hdr, bytes_nn, n_nn, bytes_latent, n_lat, 0, 0);
+    if (rc >= 0) rc = ccd_batch_run(b, stream);
+    if (rc >= 0) rc = ccd_batch_wait(b, stream);
+    if (rc >= 0) {
+        const ccd_cc_header& h = b->slots[0]->hdr;
+        const size_t bytes = static_cast<size_t>(h.out_channels) * h.img_size[0] * h.img_size[1] * 4;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (hipMemcpyAsync(out, b->slots[0]->d_out, bytes, out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            rc = CCD_ERR_HIP;
+    }
+    ccd_batch_destroy(b);
+    return rc;
+}
+
+void ccd_video_free(ccd_video* v) {
+    if (!v || !v->frames) return;
+    for (int i = 0; i < v->n_frames; ++i)
+        for (int p = 0; p < 3; ++p) std::free(v->frames[i].plane[p]);
+    std::free(v->frames);
+    v->frames = nullptr; v->n_frames = 0;
+}
+
+int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
+    if (!bs || !v) return CCD_ERR_ARG;
+    v->n_frames = 0; v->frames = nullptr;
+    std::unique_ptr<ccd_video_header> vh(new (std::nothrow) ccd_video_header());
+    if (!vh) return CCD_ERR_NOMEM;
+    int used = read_video_header(bs, n, vh.get());
+    if (used < 0) return used;
+    size_t pos = static_cast<size_t>(used);
+    const int n_frames = vh->n_frames;
+    ccd_batch* b = nullptr;
+    int rc = ccd_batch_create(device, &b);
+    if (rc < 0) return rc;
+    std::vector<ccd_frame_header> fhs(n_frames);
+    for (int f = 0; f < n_frames && rc >= 0; ++f) {
+        used = read_frame_header(bs + pos, n - pos, &fhs[f]);
+        if (used < 0) { rc = used; break; }
+        pos += static_cast<size_t>(used);
+        if (fhs[f].frame_type != 0) { rc = CCD_ERR_UNSUPPORTED; break; }  // P/B reconstruction: next round
+        ccd_cc_header ch;
+        used = read_cc_header(bs + pos, n - pos, &ch);
+        if (used < 0) { rc = used; break; }
+        const uint8_t* hdr = bs + pos;
+        pos += static_cast<size_t>(used);
+        if (pos + static_cast<size_t>(ch.nn_n_bytes) + static_cast<size_t>(ch.n_bytes_latent) > n) { rc = CCD_ERR_TRUNCATED; break; }
+        rc = ccd_batch_add(b, hdr, static_cast<size_t>(used), bs + pos, ch.nn_n_bytes, bs + pos + ch.nn_n_bytes,
+                           ch.n_bytes_latent, fhs[f].bitdepth, fhs[f].frame_data_type);
+        pos += static_cast<size_t>(ch.nn_n_bytes) + static_cast<size_t>(ch.n_bytes_latent);
+    }
+    if (rc >= 0) rc = ccd_batch_run(b, nullptr);
+    if (rc >= 0) rc = ccd_batch_wait(b, nullptr);
+    if (rc >= 0) {
+        v->frames = static_cast<ccd_frame*>(std::calloc(std::max(n_frames, 1), sizeof(ccd_frame)));
+        v->n_frames = n_frames;
+        for (int f = 0; f < n_frames && rc >= 0; ++f) {
+            const Slot& s = *b->slots[f];
+            const int di = fhs[f].display_index;
+            if (di < 0 || di >= n_frames) { rc = CCD_ERR_VALUE; break; }
+            ccd_frame& fr = v->frames[di];
+            fr.display_index = di; fr.frame_type = fhs[f].frame_type; fr.frame_data_type = fhs[f].frame_data_type;
+            fr.bitdepth = fhs[f].bitdepth;
+            fr.h = s.plane_h[0]; fr.w = s.plane_w[0]; fr.ch = s.plane_h[1]; fr.cw = s.plane_w[1];
+            for (int p = 0; p < 3 && rc >= 0; ++p) {
+                const size_t px = static_cast<size_t>(s.plane_h[p]) * s.plane_w[p];
+                fr.plane[p] = static_cast<uint16_t*>(std::malloc(px * 2 + 2));
+                if (s.bitdepth == 8) {
+                    std::vector<uint8_t> tmp(px);
+                    rc = ccd_batch_copy_plane(b, f, p, tmp.data(), nullptr);
+                    for (size_t i = 0; i < px; ++i) fr.plane[p][i] = tmp[i];
+                } else {
+                    rc = ccd_batch_copy_plane(b, f, p, fr.plane[p], nullptr);
+                }
+            }
+        }
+        if (rc < 0) ccd_video_free(v);
+    }
+    ccd_batch_destroy(b);
+    return rc < 0 ? rc : CCD_OK;
+}
+
+int ccd_debug_laplace_bounds(int device, const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* s, int64_t n,
+                             uint32_t* left, uint32_t* right) {
+    if (n <= 0) return CCD_OK;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return CCD_ERR_HIP;
+    HIP_TRY(hipSetDevice(device));
+    int32_t *d_mu = nullptr, *d_sc = nullptr, *d_s = nullptr;
+    uint32_t *d_l = nullptr, *d_r = nullptr;
+    float* d_tab = nullptr;
+    int rc = CCD_OK;
+    const size_t nb = static_cast<size_t>(n) * 4;
+    if (hipMalloc(&d_mu, nb) != hipSuccess || hipMalloc(&d_sc, nb) != hipSuccess || hipMalloc(&d_s, nb) != hipSuccess ||
+        hipMalloc(&d_l, nb) != hipSuccess || hipMalloc(&d_r, nb) != hipSuccess || hipMalloc(&d_tab, sizeof(kScaleBits)) != hipSuccess)
+        rc = CCD_ERR_NOMEM;
+    if (rc == CCD_OK &&
+        (hipMemcpy(d_mu, mu_idx, nb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_sc, scale_idx, nb, hipMemcpyHostToDevice) != hipSuccess ||
+         hipMemcpy(d_s, s, nb, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_tab, kScaleBits, sizeof(kScaleBits), hipMemcpyHostToDevice) != hipSuccess))
+        rc = CCD_ERR_HIP;
+    if (rc == CCD_OK && launch_laplace_bounds(d_mu, d_sc, d_s, d_tab, n, d_l, d_r, nullptr) != hipSuccess) rc = CCD_ERR_HIP;
+    if (rc == CCD_OK && (hipMemcpy(left, d_l, nb, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(right, d_r, nb, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = CCD_ERR_HIP;
+    (void)hipFree(d_mu); (void)hipFree(d_sc); (void)hipFree(d_s); (void)hipFree(d_l); (void)hipFree(d_r); (void)hipFree(d_tab);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// ccd_device.hpp - structures shared between the host API and the HIP kernels.
+#pragma once
+
+#include <cstdint>
+
+#include "../../include/ccd.h"
+
+namespace ccd {
+
+constexpr int kMaxCtx = 40;          // spatial context template size (arm.py:501-509)
+constexpr int kAcLo = -64;           // symbols live in [-64, 63] (constants.py:11)
+constexpr int kAlphabet = 128;
+constexpr int kRcPrecision = 24;     // constriction default range-coder precision
+constexpr int kMuOffset = 16384;     // -MU_MIN_FIXED_POINT (constants.py:31)
+constexpr int kScaleOffset = 1280;   // -LOG_SCALE_MIN_FIXED_POINT (constants.py:36)
+constexpr int kNumMu = 32768, kNumScale = 2561;
+
+// Per-slot description of the entropy stage (device memory, read-only for the kernel).
+struct EntropyParams {
+    const uint32_t* words;   // latent payload as little-endian u32 words
+    uint32_t n_words;
+    int32_t n_grids;
+    int32_t grid_h[CCD_MAX_GRIDS], grid_w[CCD_MAX_GRIDS];
+    int8_t* latent[CCD_MAX_GRIDS];     // decoded grids [h][w]
+    int32_t ifce_in[CCD_MAX_GRIDS];    // number of IFCE input channels of the grid (0 = none)
+    int32_t ifce_off[CCD_MAX_GRIDS];   // offset (in int64) of the grid's IFCE parameters in `ifce`
+    int32_t level[CCD_MAX_GRIDS];      // number of size changes between grid 0 and grid g
+    int32_t dim, n_spatial, n_ifce_out, n_layers, narrow, has_ifce;
+    int32_t ctx_dy[kMaxCtx], ctx_dx[kMaxCtx];
+    const int64_t* arm;      // per layer: w[in][out], b[out]; then ws[dim][2], bs[2]
+    int32_t arm_len;         // length of `arm` in int64
+    const int64_t* ifce;     // per grid with IFCE: w[in][out], b[out]
+    int32_t* ifce_feat;      // scratch [n_ifce_out][fh][fw] (features at the previous grid's size)
+    const float* scale_table;  // 2561 float32 scales
+    int32_t* status;         // [0] error code, [1] words consumed, [2..3] symbols decoded (lo, hi)
+};
+
+// Upsampling level: stack_in [c_in][h_in][w_in] f32 (or the coarsest int8 grid) ->
+// stack_out [c_in + 1][h_out][w_out]; channel 0 = pre-concat conv of the int8 grid `target`.
+struct UpsampleLevel {
+    const float* in_f32;     // nullptr when the input is the coarsest latent itself
+    const int8_t* in_i8;
+    const int8_t* target;    // [h_out][w_out]
+    float* out;
+    int32_t c_in, h_in, w_in, h_out, w_out;
+    int32_t ups_k, pre_k;
+    float ups_w[16], pre_w[16];
+};
+
+constexpr int kMaxSynWeights = 8192;  // floats of synthesis parameters kept in LDS
+
+struct SynthLayerDesc {
+    int32_t c_in, c_out, k, residual, relu;
+    int32_t w_off, b_off;    // offsets in the parameter blob (floats)
+};
+
+struct SynthParams {
+    const float* dense;      // [c_in][h][w]
+    float* out;              // [c_out][h][w] synthesis output (f32), may be null
+    void* plane[3];          // integer planes (u8 / u16), may be null
+    int32_t h, w, c_in, c_out;
+    int32_t n_layers;
+    SynthLayerDesc layer[CCD_MAX_SYN_LAYERS];
+    SynthLayerDesc stab;     // c_out == 0 when absent
+    SynthLayerDesc out_tf;   // output transform
+    const float* params;     // blob
+    int32_t n_params;
+    int32_t bitdepth;        // 0 = no integer planes
+    int32_t frame_data_type; // 0 rgb 1 yuv420 2 yuv444
+    int32_t halo;            // sum of (k-1)/2 over the main branch
+};
+
+}  // namespace ccd

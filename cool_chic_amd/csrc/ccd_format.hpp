@@ -1,0 +1,88 @@
+// ccd_format.hpp - host-side parsing of the .cool format: bit-packed headers, derived grid
+// geometry, Exp-Golomb network parameters and their fixed-point / float forms.
+//
+// Reference behaviour (paths relative to /root/reference/coolchic):
+//   bitstream/header/header.py:72-88,130-147,172-218,244-325   headers
+//   component/core/coolchic.py:149-225                         grid geometry
+//   bitstream/neuralnet/{neuralnet.py:92-204,expgolomb.py:74-130}   network payload
+//   bitstream/component/armint.py:30-170                       fixed-point ARM / IFCE parameters
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/ccd.h"
+
+namespace ccd {
+
+// MSB-first bit cursor over a byte span; reading past the end latches `bad`.
+class BitReader {
+public:
+    BitReader(const uint8_t* p, size_t n_bytes) : p_(p), n_bits_(n_bytes * 8) {}
+    uint64_t get(int n);
+    int get_sign_magnitude(int n);  // element.py:62-85 (signed=True)
+    int peek_bit() const;           // -1 at end of data
+    void skip(size_t n) { pos_ += n; if (pos_ > n_bits_) bad_ = true; }
+    bool bad() const { return bad_; }
+    size_t pos() const { return pos_; }
+private:
+    const uint8_t* p_;
+    size_t n_bits_, pos_ = 0;
+    bool bad_ = false;
+};
+
+int read_video_header(const uint8_t* p, size_t n, ccd_video_header* h);
+int read_frame_header(const uint8_t* p, size_t n, ccd_frame_header* h);
+int read_cc_header(const uint8_t* p, size_t n, ccd_cc_header* h);  // also fills the derived geometry
+
+// One linear layer in fixed point, weights stored [in][out] (already transposed like armint.py:127).
+struct FixedLayer {
+    int n_in = 0, n_out = 0;
+    std::vector<int64_t> w, b;
+};
+
+struct FixedArm {
+    int dim = 0;
+    std::vector<FixedLayer> layers;  // hidden layers then the output layer
+    std::vector<int64_t> ws, bs;     // stabiliser [dim][n_out], [n_out] (zeros when absent)
+    int n_out = 2;
+    // true when every operand fits int32 and no accumulator can leave int64 without wrapping, for
+    // inputs bounded by |latent| <= 64 and the worst-case IFCE features: the kernel may then use
+    // 32x32->64 multiply-adds; otherwise it runs full 64-bit wrap-around arithmetic like torch.
+    bool narrow = false;
+};
+
+struct SynLayerParams {
+    int c_in = 0, c_out = 0, k = 1;
+    bool residual = false, relu = false;
+    std::vector<float> w, b;  // w: [c_out][c_in][k][k]
+};
+
+struct Network {
+    std::vector<int64_t> ints;           // every transmitted integer, stream order
+    FixedArm arm;
+    std::vector<FixedArm> ifce;          // one per grid (dim == 0 when the grid has no IFCE)
+    std::vector<int64_t> ifce_feat_bound;  // per grid: worst-case |feature| (Q8)
+    int n_ups = 0, ups_k = 0, pre_k = 0;
+    std::vector<float> ups_w;            // [n_ups][ups_k] symmetric 1-D kernels (upsampling.py:42-64)
+    std::vector<float> pre_w;            // [n_ups][pre_k]
+    std::vector<SynLayerParams> syn;     // main branch
+    SynLayerParams syn_stab;             // c_out == 0 when absent; 1x1 on the first c_in channels
+    SynLayerParams syn_out;              // output transform 1x1
+};
+
+int decode_exp_golomb(const uint8_t* p, size_t n, int n_pad_bits, const std::vector<int>& count,
+                      std::vector<int64_t>& out);
+int decode_network(const ccd_cc_header& h, const uint8_t* bytes_nn, size_t n_nn, Network& net);
+
+// Context template: (dy, dx) of the n highest-priority causal neighbours, component/core/arm.py:493-562.
+// The neighbour of (y, x) is (y - dy, x + dx) with dy in 0..4, dx in -4..4.
+void context_offsets(int n_spatial, int* dy, int* dx);
+
+// For the IFCE input stack seen while decoding grid g (channel c = grid g+1+c, all resampled to the
+// size of grid g+1 by repeated nearest x2 + crop, upsampling.py:556-595): right-shift to apply to the
+// coordinates for channel c.
+void ifce_channel_shifts(const ccd_cc_header& h, int g, std::vector<int>& shifts);
+
+}  // namespace ccd

@@ -1,0 +1,187 @@
+/*
+ * ccd.h - C ABI of the MI355X-native Cool-chic decoder (libccd.so).
+ *
+ * Drop-in boundary for the reference's decode path (paths relative to /root/reference):
+ *   cc_decode.py:14-20                                  -> ccd_decode_video()
+ *   coolchic/bitstream/decode.py:26   decode_video()    -> ccd_decode_video()
+ *   coolchic/bitstream/decode.py:96   decode_frame()    -> ccd_batch_* (one frame = 1-2 cool-chics)
+ *   coolchic/bitstream/component/coolchic.py:29
+ *        encode_decode_coolchic(mode="decode")          -> ccd_decode_coolchic(), ccd_batch_*
+ *   coolchic/bitstream/header/header.py:72 read_header  -> ccd_read_*_header()
+ *
+ * Conventions: plain pointers and sizes, no torch types; status-code
+ * returns (0 = ok, <0 = error, see ccd_strerror); caller-owned output buffers; one HIP stream
+ * per call, no hidden global state; inputs are never modified.  Device pointers are ordinary
+ * hipMalloc'ed addresses (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as
+ * void* (e.g. torch.cuda.current_stream().cuda_stream), NULL = the default stream.
+ *
+ * The library has NO CPU fallback: every compute entry point fails with CCD_ERR_HIP when no
+ * gfx950 device is usable.
+ */
+#ifndef CCD_H
+#define CCD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCD_MAX_GRIDS 40
+#define CCD_MAX_SYN_LAYERS 8
+#define CCD_MAX_REFS 2
+
+enum {
+    CCD_OK = 0,
+    CCD_ERR_TRUNCATED = -1,    /* bitstream shorter than its headers claim */
+    CCD_ERR_VALUE = -2,        /* header field out of range (reference: ValueError, element.py:289-292) */
+    CCD_ERR_INVALID_DATA = -3, /* range decoder met an impossible quantile (constriction: InvalidData) */
+    CCD_ERR_UNSUPPORTED = -4,  /* legal stream using a feature this build does not implement yet */
+    CCD_ERR_NOMEM = -5,
+    CCD_ERR_HIP = -6,          /* HIP runtime error / no usable device */
+    CCD_ERR_ARG = -7           /* bad argument (reference: ValueError, coolchic.py:39-51) */
+};
+
+const char* ccd_strerror(int code);
+/* "ccd <version> gfx950" */
+const char* ccd_version(void);
+
+/* ---- headers (host only; reference: bitstream/header/header.py) ------------------------- */
+typedef struct {
+    int32_t n_frames, n_intras, n_p_frames, n_bytes_header;
+    int32_t intra_pos[4096];
+    int32_t p_pos[4096];
+} ccd_video_header; /* header.py:130-147 */
+
+typedef struct {
+    int32_t display_index;
+    int32_t frame_type;      /* 0 I, 1 P, 2 B */
+    int32_t frame_data_type; /* 0 rgb, 1 yuv420, 2 yuv444, 3 flow */
+    int32_t bitdepth;        /* 8..16 */
+    int32_t n_bytes_header;
+    int32_t n_refs;
+    int32_t index_references[CCD_MAX_REFS];
+    int32_t global_flow[2 * CCD_MAX_REFS];
+    int32_t warp_filter_size;
+} ccd_frame_header; /* header.py:172-218 */
+
+typedef struct { int32_t out_ft, k_size, mode /*0 linear 1 residual*/, non_linearity /*0 none 1 relu*/; } ccd_syn_layer;
+
+typedef struct {
+    /* transmitted fields, header.py:244-325 */
+    int32_t linear_stabiliser_synth, n_layer_synthesis, ups_k_size, ups_preconcat_k_size;
+    int32_t output_feature_ifce, spatial_context_arm, linear_stabiliser_arm, n_hidden_layers_arm;
+    int32_t img_size[2];
+    int32_t latent_resolution[2];
+    int32_t n_latent_grids;
+    int32_t flag_hyperlatent, flag_common_randomness;
+    int32_t final_upsampling_type; /* 0 nearest 1 bilinear 2 bicubic */
+    int32_t nn_q_step_log2[8];     /* arm.w arm.b ifce.w ifce.b ups.w ups.b syn.w syn.b */
+    int32_t nn_expgol_cnt[8];
+    int32_t nn_n_bytes, nn_n_bit_pad, n_bytes_latent, n_bytes_header;
+    int32_t has_ifce_resolution;
+    int32_t ifce_resolution[2];
+    int32_t hyperlatent_resolution[2];
+    ccd_syn_layer syn_layer[CCD_MAX_SYN_LAYERS];
+    /* derived geometry, component/core/coolchic.py:149-225 */
+    int32_t n_grids;
+    int32_t grid_h[CCD_MAX_GRIDS], grid_w[CCD_MAX_GRIDS];
+    int32_t is_hyperlatent[CCD_MAX_GRIDS];
+    int32_t input_features_ifce[CCD_MAX_GRIDS];
+    int32_t input_feature_synthesis;
+    int32_t total_context_arm;
+    int32_t out_channels; /* synthesis output channels */
+    int64_t n_symbols;    /* total latent symbols */
+} ccd_cc_header;
+
+/* Each returns the number of header bytes consumed (> 0) or an error (< 0). */
+int ccd_read_video_header(const uint8_t* p, size_t n, ccd_video_header* h);
+int ccd_read_frame_header(const uint8_t* p, size_t n, ccd_frame_header* h);
+int ccd_read_cc_header(const uint8_t* p, size_t n, ccd_cc_header* h);
+
+/* ---- one cool-chic: encode_decode_coolchic(mode="decode"), coolchic.py:29-207 ------------- */
+/* Decodes one cool-chic on `device` and writes the synthesis output [C][H][W] float32 (after the
+ * final resize/crop, coolchic.py:187-192) to `out`, a device pointer if out_on_device else host.
+ * Synchronous with respect to `stream` on return when out is a host pointer. */
+int ccd_decode_coolchic(const uint8_t* cc_header, size_t n_hdr, const uint8_t* bytes_nn, size_t n_nn,
+                        const uint8_t* bytes_latent, size_t n_lat, int device, void* stream,
+                        float* out, int out_on_device);
+
+/* ---- batches of cool-chics: the throughput API (one frame per slot, many frames in flight) --
+ * A batch owns the device-resident inputs (bitstream words, network parameters) and all
+ * intermediate buffers of its slots.  Typical use: create, add every cool-chic of a set of
+ * frames, then repeatedly run() - all slots decode concurrently (one workgroup per slot walks
+ * the serial ARM + range-decoder chain; upsampling/synthesis tiles fill the rest of the chip). */
+typedef struct ccd_batch ccd_batch;
+
+int ccd_batch_create(int device, ccd_batch** out);
+void ccd_batch_destroy(ccd_batch* b);
+/* Adds one cool-chic; parses headers + network on the host and uploads to HBM. Returns the slot
+ * index (>= 0) or an error.  bitdepth/frame_data_type describe the frame it belongs to and drive
+ * the integer output planes (decode.py:191-206); pass bitdepth 0 to skip integer planes. */
+int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const uint8_t* bytes_nn, size_t n_nn,
+                  const uint8_t* bytes_latent, size_t n_lat, int bitdepth, int frame_data_type);
+int ccd_batch_size(const ccd_batch* b);
+int ccd_batch_header(const ccd_batch* b, int slot, ccd_cc_header* h);
+/* Enqueues the whole decode of every slot on `stream` (asynchronous). */
+int ccd_batch_run(ccd_batch* b, void* stream);
+/* Enqueue only one stage (profiling / tests): 0 entropy, 1 upsampling, 2 synthesis(+integer planes). */
+int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage);
+/* Waits for `stream` and returns the first per-slot decode error (CCD_ERR_INVALID_DATA ...). */
+int ccd_batch_wait(ccd_batch* b, void* stream);
+int ccd_batch_slot_status(const ccd_batch* b, int slot);
+
+/* Device pointers of a slot's results (valid until the batch is destroyed / re-run): */
+const float* ccd_batch_output(const ccd_batch* b, int slot);    /* [C][H][W] f32, synthesis output */
+const float* ccd_batch_dense(const ccd_batch* b, int slot);     /* [L][H0][W0] f32, Upsampling.forward */
+const int8_t* ccd_batch_latent(const ccd_batch* b, int slot, int grid); /* [h][w] int8 */
+/* Integer planes (value = round(x * (2^bitdepth-1)) after the reference's clamp/round/420 chain):
+ * plane p of the frame, uint8 if bitdepth == 8 else uint16; chroma planes are half size for yuv420. */
+const void* ccd_batch_plane(const ccd_batch* b, int slot, int plane, int* h, int* w);
+/* Copies (device -> host, synchronous on `stream`) for tests and writers. */
+int ccd_batch_copy_latent(ccd_batch* b, int slot, int grid, int8_t* host, void* stream);
+int ccd_batch_copy_plane(ccd_batch* b, int slot, int plane, void* host, void* stream);
+int ccd_batch_copy_output(ccd_batch* b, int slot, float* host, void* stream);
+int ccd_batch_copy_dense(ccd_batch* b, int slot, float* host, void* stream);
+
+/* ---- whole file: decode_video(), decode.py:26-91 ----------------------------------------- */
+typedef struct {
+    int32_t display_index, frame_type, frame_data_type, bitdepth;
+    int32_t h, w, ch, cw;
+    uint16_t* plane[3]; /* host, malloc'ed by the library, integer samples (u16 for every bitdepth) */
+} ccd_frame;
+
+typedef struct {
+    int32_t n_frames;
+    ccd_frame* frames; /* display order */
+} ccd_video;
+
+int ccd_decode_video(const uint8_t* bitstream, size_t n, int device, ccd_video* v);
+void ccd_video_free(ccd_video* v);
+
+/* ---- bitstream writer + synthetic streams ("next-2" row of SURVEY section 8f) -------------- */
+/* Range-encodes `n` symbols with per-symbol (mu_idx, scale_idx) table indices exactly as
+ * constriction 0.4.2's RangeEncoder + QuantizedLaplace(-64,63) (rangecoder.py:46-76).
+ * Returns the number of bytes written to *out (malloc'ed; free with ccd_free). */
+int64_t ccd_range_encode(const int8_t* symbols, const int32_t* mu_idx, const int32_t* scale_idx, int64_t n,
+                         uint8_t** out);
+/* Bitstream writer for one intra frame (bitstream/encode.py:24-95): frames the video / frame /
+ * cool-chic headers (architecture = the transmitted fields of `tmpl`), the NN payload `bytes_nn`
+ * verbatim and the range-coded `latents` (latents[g] = int8 [grid_h[g]][grid_w[g]], values in
+ * [-64, 63]).  The encoder walks the decoder's integer ARM/IFCE path on the HOST, like the
+ * reference (latent.py:168-173).  Used by bench.py and the round-trip tests to manufacture
+ * Kodak/CLIC/4K-shaped inputs; never used while decoding. */
+int64_t ccd_encode_stream(const ccd_cc_header* tmpl, const uint8_t* bytes_nn, size_t n_nn,
+                          const int8_t* const* latents, int bitdepth, int frame_data_type, uint8_t** out);
+void ccd_free(void* p);
+
+/* Leaky-quantised-Laplace boundaries computed ON THE GPU for a list of (mu_idx, scale_idx, s):
+ * left[i], right[i] as the entropy kernel sees them (exhaustive parity tests of the f64 CDF). */
+int ccd_debug_laplace_bounds(int device, const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* s,
+                             int64_t n, uint32_t* left, uint32_t* right);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

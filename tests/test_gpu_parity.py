@@ -1,0 +1,208 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the reference fixtures.
+
+Bars: integer stages bit-exact; float stages bit-exact to the oracle's
+canonical accumulation order; integer planes identical to the oracle and within 1 LSB /
+<= 2e-5 mismatch fraction of what the reference decoder produced."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import IMAGE_STREAMS, SMALL_STREAMS, load_golden, reference_planes
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from cool_chic_amd import DecodeBatch, _lib
+
+    _lib.lib()
+    return DecodeBatch
+
+
+def _decode(gpu, triples, bitdepth, fdt):
+    b = gpu(0)
+    for hdr, nn, lat in triples:
+        b.add(hdr, nn, lat, bitdepth, fdt)
+    b.run()
+    b.wait()
+    return b
+
+
+@pytest.mark.parametrize("name", IMAGE_STREAMS)
+def test_stream_parity(gpu, oracle, name):
+    bs, z, j = load_golden(name)
+    _, frames = oracle.split_stream(bs)
+    fh, ccs = frames[0]
+    ref = oracle.decode_coolchic(*ccs[0])
+    b = _decode(gpu, ccs[:1], fh.bitdepth, fh.frame_data_type)
+    try:
+        # integer stage: every latent grid bit-exact with the oracle AND the reference fixture
+        for g in range(ref["n_grids"]):
+            got = b.latent(0, g)
+            assert np.array_equal(got, ref["latent"][g]), f"grid {g} vs oracle"
+            assert np.array_equal(got, z[f"cc0.latent{g}"]), f"grid {g} vs reference fixture"
+        # float stages: bit-exact with the oracle
+        dense = b.dense(0)
+        assert np.array_equal(dense.view(np.uint32), ref["dense"].view(np.uint32)), "Upsampling.forward"
+        out = b.output(0)
+        assert np.array_equal(out.view(np.uint32), ref["out"].view(np.uint32)), "synthesis output"
+        # integer planes: identical to the oracle, within the reference's noise floor of the fixture
+        want = oracle.decode_video(bs)[0]["planes"]
+        planes = b.planes(0)
+        n_diff = n_tot = 0
+        for p, w, r in zip(planes, want, reference_planes(z, j)):
+            assert np.array_equal(p.astype(np.uint16), w)
+            d = np.abs(p.astype(np.int64) - r.astype(np.int64))
+            assert d.max() <= 1
+            n_diff += int((d != 0).sum())
+            n_tot += d.size
+        assert n_diff / n_tot <= 2e-5
+    finally:
+        b.close()
+
+
+def test_many_streams_in_one_batch(gpu, oracle):
+    """Several different architectures / sizes in flight together decode like they do alone."""
+    triples, refs, meta = [], [], []
+    for name in SMALL_STREAMS + ["kodim14"] + SMALL_STREAMS:
+        bs, z, j = load_golden(name)
+        fh, ccs = oracle.split_stream(bs)[1][0]
+        triples.append(ccs[0])
+        refs.append(oracle.decode_video(bs)[0]["planes"])
+        meta.append((fh.bitdepth, fh.frame_data_type))
+    b = gpu(0)
+    try:
+        for t, m in zip(triples, meta):
+            b.add(*t, *m)
+        for _ in range(2):  # a batch can be re-run
+            b.run()
+            b.wait()
+            for i, want in enumerate(refs):
+                for p, w in zip(b.planes(i), want):
+                    assert np.array_equal(p.astype(np.uint16), w)
+    finally:
+        b.close()
+
+
+def test_laplace_boundaries_on_device(gpu, oracle):
+    """The f64 CDF boundaries the entropy kernel computes vs libm on the host (hard part H2)."""
+    from cool_chic_amd._lib import check, lib
+
+    rng = np.random.default_rng(1)
+    n = 400_000
+    mu = rng.integers(0, 32768, n).astype(np.int32)
+    sc = rng.integers(0, 2561, n).astype(np.int32)
+    s = rng.integers(-64, 64, n).astype(np.int32)
+    # add structured cases: every scale at a few mus, all symbols
+    mm, cc, ss = np.meshgrid(np.array([0, 1, 255, 16384, 16385, 20000, 32767]), np.arange(0, 2561, 7), np.arange(-64, 64))
+    mu = np.concatenate([mu, mm.ravel().astype(np.int32)])
+    sc = np.concatenate([sc, cc.ravel().astype(np.int32)])
+    s = np.concatenate([s, ss.ravel().astype(np.int32)])
+    left = np.empty(mu.size, np.uint32)
+    right = np.empty(mu.size, np.uint32)
+    check(lib().ccd_debug_laplace_bounds(0, mu.ctypes.data, sc.ctypes.data, s.ctypes.data, mu.size, left.ctypes.data,
+                                         right.ctypes.data))
+    L = oracle.lib()
+    a, b = C.c_uint32(), C.c_uint32()
+    bad = 0
+    for i in range(0, mu.size, 1):
+        L.ora_laplace_bounds(int(mu[i]), int(sc[i]), int(s[i]), C.byref(a), C.byref(b))
+        if a.value != left[i] or b.value != right[i]:
+            bad += 1
+    assert bad == 0, f"{bad} of {mu.size} boundaries differ from the host"
+
+
+def test_synthetic_variants_round_trip(gpu, oracle):
+    """writer -> GPU decoder round trip at the Kodak size, both orientations (config 1 inputs)."""
+    from cool_chic_amd import writer
+
+    bs, z, j = load_golden("kodim14")
+    hdr, nn, lat = oracle.split_stream(bs)[1][0][1][0]
+    latents = [z[f"cc0.latent{g}"] for g in range(10)]
+    _, levels = writer.grid_sizes((512, 768), hdr)
+    streams, variants = [], []
+    for seed, tr in ((11, False), (12, True), (13, False)):
+        v = writer.variant_latents(latents, levels, seed, tr)
+        streams.append(writer.encode_stream(hdr, nn, v, img_size=(768, 512) if tr else (512, 768)))
+        variants.append(v)
+    triples = [oracle.split_stream(s)[1][0][1][0] for s in streams]
+    b = _decode(gpu, triples, 8, 0)
+    try:
+        for i, v in enumerate(variants):
+            for g, a in enumerate(v):
+                assert np.array_equal(b.latent(i, g), a), f"stream {i} grid {g}"
+        # one full check against the oracle for the portrait stream
+        want = oracle.decode_video(streams[1])[0]["planes"]
+        for p, w in zip(b.planes(1), want):
+            assert np.array_equal(p.astype(np.uint16), w)
+    finally:
+        b.close()
+
+
+def test_corrupt_payload_is_reported_or_contained(gpu, oracle):
+    """A damaged payload must not hang or crash: it either decodes to (wrong) symbols or reports
+    CCD_ERR_INVALID_DATA, exactly like the oracle does on the same bytes."""
+    from cool_chic_amd import CcdError
+
+    bs, z, j = load_golden("rgb192")
+    hdr, nn, lat = oracle.split_stream(bs)[1][0][1][0]
+    bad = bytearray(lat)
+    for i in range(40, 80):
+        bad[i] ^= 0xA5
+    bad = bytes(bad)
+    try:
+        ref = oracle.decode_coolchic(hdr, nn, bad, stop_after_entropy=True)
+    except oracle.OracleError:
+        ref = None
+    b = gpu(0)
+    try:
+        b.add(hdr, nn, bad, 8, 0)
+        b.run()
+        if ref is None:
+            with pytest.raises(CcdError):
+                b.wait()
+        else:
+            b.wait()
+            for g in range(ref["n_grids"]):
+                assert np.array_equal(b.latent(0, g), ref["latent"][g])
+    finally:
+        b.close()
+
+
+def test_python_surface(gpu, oracle, tmp_path):
+    """decode_video / encode_decode_coolchic mirrors + the PNG writer."""
+    import torch
+    from PIL import Image
+
+    from cool_chic_amd.bitstream.component.coolchic import encode_decode_coolchic
+    from cool_chic_amd.bitstream.decode import decode_video
+    from cool_chic_amd.bitstream.header import CoolChicHeader, FrameHeader, VideoHeader
+    from conftest import GOLDEN
+    import os
+
+    out_png = str(tmp_path / "k.png")
+    frames = decode_video(os.path.join(GOLDEN, "kodim14.cool"), decoded_path=out_png)
+    assert list(frames) == ["0"]
+    fd = frames["0"]
+    assert fd.bitdepth == 8 and fd.frame_data_type == "rgb" and tuple(fd.data.shape) == (1, 3, 512, 768)
+    bs, z, j = load_golden("kodim14")
+    want = np.stack(oracle.decode_video(bs)[0]["planes"]).astype(np.uint8)
+    png = np.asarray(Image.open(out_png)).transpose(2, 0, 1)
+    assert np.array_equal(png, want)
+    # boundary function
+    rest = VideoHeader().read_header(bs)
+    rest = FrameHeader().read_header(rest)
+    ch = CoolChicHeader()
+    rest = ch.read_header(rest)
+    nn, lat = rest[: ch.get_value("nn_n_bytes")], rest[ch.get_value("nn_n_bytes"):]
+    t, none = encode_decode_coolchic(ch, nn, "decode", dec_bytes_latent=lat)
+    assert none is None and t.dtype == torch.float32 and tuple(t.shape) == (1, 3, 512, 768)
+    ref = oracle.decode_coolchic(ch.raw, nn, lat)["out"]
+    assert np.array_equal(t[0].cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    with pytest.raises(ValueError):
+        encode_decode_coolchic(ch, nn, "decode", dec_bytes_latent=None)

@@ -1,0 +1,99 @@
+"""The CPU oracle against golden vectors captured from the reference decoder (tests/golden/gen).
+
+Integer stages (NN integers, fixed-point ARM, every latent grid, (mu, scale) indices) must be
+bit-exact; float stages are compared with the tolerances of SURVEY.md section 8c: the reference's
+own output moves by +-1 LSB on ~1e-5 of the samples between thread counts."""
+import numpy as np
+import pytest
+
+from conftest import IMAGE_STREAMS, load_golden, reference_planes
+
+
+@pytest.mark.parametrize("name", IMAGE_STREAMS)
+def test_integer_stages_bit_exact(oracle, name):
+    bs, z, j = load_golden(name)
+    _, frames = oracle.split_stream(bs)
+    hdr, nn, lat = frames[0][1][0]
+    r = oracle.decode_coolchic(hdr, nn, lat, stop_after_entropy=True)
+    cc = j["cc"][0]
+    assert r["grid_hw"] == [tuple(s) for s in cc["size_per_latent"]]
+    assert r["is_hyper"] == cc["flag_is_hyperlatent"]
+    assert r["input_features_ifce"] == cc["input_features_ifce"]
+    assert np.array_equal(r["nn_ints"], z["cc0.nn_ints"])
+    n_layers = len(r["arm_w"])
+    for l in range(n_layers):
+        assert np.array_equal(r["arm_w"][l], z[f"cc0.fp.arm.w{l}"])
+        assert np.array_equal(r["arm_b"][l], z[f"cc0.fp.arm.b{l}"])
+    assert np.array_equal(r["arm_ws"], z["cc0.fp.arm.ws"])
+    assert np.array_equal(r["arm_bs"], z["cc0.fp.arm.bs"])
+    for g in range(r["n_grids"]):
+        assert np.array_equal(r["latent"][g], z[f"cc0.latent{g}"]), f"latent grid {g}"
+        head = z[f"cc0.mu_scale_idx{g}.head"]
+        assert np.array_equal(r["mu_scale_idx"][g][: len(head)], head), f"(mu, scale) indices grid {g}"
+        key = f"cc0.ctx_ifce{g}"
+        if key in z.files:
+            assert np.array_equal(r["ctx_ifce"][g], z[key]), f"IFCE features grid {g}"
+        elif key + ".crop" in z.files:
+            assert np.array_equal(r["ctx_ifce"][g][:, :32, :48], z[key + ".crop"])
+    assert r["n_symbols"] == sum(h * w for h, w in r["grid_hw"])
+    # the decoder consumed the payload exactly (one read past the end on the last renormalisation at most)
+    assert len(lat) // 4 <= r["words_consumed"] <= len(lat) // 4 + 1
+
+
+@pytest.mark.parametrize("name", IMAGE_STREAMS)
+def test_float_stages_close_to_reference(oracle, name):
+    bs, z, j = load_golden(name)
+    _, frames = oracle.split_stream(bs)
+    r = oracle.decode_coolchic(*frames[0][1][0])
+    d, s = r["dense"], r["syn_out"]
+    H, W = d.shape[1:]
+    ch, cw = min(H, 40), min(W, 48)
+    for arr, key in ((d, "dense"), (s, "syn")):
+        assert np.abs(arr[:, :ch, :cw] - z[f"cc0.{key}.tl"]).max() < 2e-5
+        assert np.abs(arr[:, H - ch:, W - cw:] - z[f"cc0.{key}.br"]).max() < 2e-5
+        assert np.abs(arr[:, H // 2:H // 2 + ch, W // 2:W // 2 + cw] - z[f"cc0.{key}.mid"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("name", IMAGE_STREAMS)
+def test_integer_planes_vs_reference(oracle, name):
+    bs, z, j = load_golden(name)
+    fr = oracle.decode_video(bs)[0]
+    ref = reference_planes(z, j)
+    assert fr["bitdepth"] == j["frames"]["0"]["bitdepth"]
+    assert fr["frame_data_type"] == j["frames"]["0"]["frame_data_type"]
+    n_diff = n_tot = 0
+    for a, b in zip(fr["planes"], ref):
+        assert a.shape == b.shape
+        diff = np.abs(a.astype(np.int64) - b.astype(np.int64))
+        assert diff.max() <= 1, "more than 1 LSB away from the reference decoder"
+        n_diff += int((diff != 0).sum())
+        n_tot += diff.size
+    # reference noise floor: 8 / 1 179 648 samples between thread counts
+    assert n_diff / n_tot <= 2e-5, f"{n_diff} of {n_tot} samples differ"
+
+
+def test_laplace_known_answers(oracle):
+    # (mu_idx, scale_idx, s) -> (left, right)
+    kat = [((16384, 1280, 0), (5087973, 11689243)), ((16421, 300, -1), (63, 64)), ((16000, 2560, 5), (8720978, 8775079)),
+           ((20000, 0, 14), (78, 16777167)), ((0, 0, -64), (0, 16777089)), ((32767, 2560, 63), (8304534, 16777216))]
+    for args, want in kat:
+        assert oracle.laplace_bounds(*args) == want
+
+
+def test_range_encoder_reproduces_shipped_payload(oracle):
+    """Known-answer test in the encode direction: re-encoding kodim14's symbols gives its payload."""
+    bs, z, j = load_golden("kodim14")
+    _, frames = oracle.split_stream(bs)
+    hdr, nn, lat = frames[0][1][0]
+    r = oracle.decode_coolchic(hdr, nn, lat, stop_after_entropy=True)
+    syms, mus, scs = [], [], []
+    for g in range(r["n_grids"] - 1, -1, -1):
+        h, w = r["grid_hw"][g]
+        ys, xs = np.mgrid[0:h, 0:w]
+        order = (ys * w + xs if w <= 9 else xs + 10 * ys).ravel()
+        idx = np.lexsort((ys.ravel(), order))
+        syms.append(r["latent"][g].ravel()[idx])
+        mus.append(r["mu_scale_idx"][g][:, 0])
+        scs.append(r["mu_scale_idx"][g][:, 1])
+    payload = oracle.rc_encode(np.concatenate(syms), np.concatenate(mus), np.concatenate(scs))
+    assert payload == lat
