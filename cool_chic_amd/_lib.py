@@ -113,6 +113,10 @@ def lib():
     global _lib
     if _lib is None:
         path = _build.build_lib()
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; load it FIRST so that libccd.so (same SONAME)
+        # binds to that copy. Two HIP runtimes in one process cannot both own the device.
+        import torch  # noqa: F401
+
         L = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
