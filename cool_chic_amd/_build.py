@@ -4,7 +4,7 @@ import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["ccd_format.cpp", "ccd_writer.cpp", "ccd_api.cpp", "ccd_entropy.hip", "ccd_float.hip"]
+SOURCES = ["ccd_format.cpp", "ccd_writer.cpp", "ccd_api.cpp", "ccd_entropy.hip", "ccd_entropy_pipe.hip", "ccd_float.hip"]
 HEADERS = ["ccd_format.hpp", "ccd_device.hpp", "../../include/ccd.h", "../../include/ccd_scale_table.inc"]
 LIB = os.path.join(_HERE, "libccd.so")
 
@@ -31,6 +31,8 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            # every fused multiply-add of the float stages is an explicit __fmaf_rn (bit parity with the oracle)
            "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-o", LIB]
+    if os.environ.get("CCD_PIPE_PROFILE"):
+        cmd.append("-DCCD_PIPE_PROFILE")  # cycle counters in the entropy kernel (ccd_batch_slot_stats)
     cmd += [os.path.join(_HERE, "csrc", s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))

@@ -15,6 +15,9 @@ namespace ccd {
 // kernels (ccd_entropy.hip, ccd_float.hip)
 size_t entropy_lds_bytes(int dim, int arm_len);
 hipError_t launch_entropy(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream);
+size_t entropy_pipe_lds_bytes(int dim, int n_layers);
+bool entropy_pipe_supports(int dim, int n_layers, int narrow, int max_grid_w);
+hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_laplace_bounds(const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* sym,
                                  const float* scale_table, int64_t n, uint32_t* left, uint32_t* right, hipStream_t stream);
 hipError_t launch_upsample_level(const UpsampleLevel& L, hipStream_t stream);
@@ -77,8 +80,10 @@ struct Slot {
     void* d_plane[3] = {nullptr, nullptr, nullptr};
     int plane_h[3] = {0, 0, 0}, plane_w[3] = {0, 0, 0};
     int32_t* d_status = nullptr;
+    bool use_pipe = false;   // pipelined entropy kernel (32-bit operands) or the generic one
+    size_t lds_generic = 0, lds_pipe = 0;
     int status = CCD_OK;
-    int32_t host_status[4] = {0, 0, 0, 0};
+    int32_t host_status[32] = {0};
 };
 
 }  // namespace
@@ -86,10 +91,13 @@ struct Slot {
 struct ccd_batch {
     int device = 0;
     std::vector<std::unique_ptr<Slot>> slots;
-    EntropyParams* d_params = nullptr;
+    EntropyParams* d_params = nullptr;   // [pipe slots..., generic slots...]
     int n_params_uploaded = 0;
+    int n_pipe = 0, n_generic = 0;
     float* d_scale_table = nullptr;
-    size_t lds_bytes = 0;
+    double* d_rcp_table = nullptr;
+    size_t lds_generic = 0, lds_pipe = 0;
+    int force_generic = 0;               // CCD_FORCE_GENERIC_ENTROPY=1: tests exercise the fallback kernel
 };
 
 extern "C" {
@@ -127,9 +135,22 @@ int ccd_batch_create(int device, ccd_batch** out) {
     ccd_batch* b = new (std::nothrow) ccd_batch();
     if (!b) return CCD_ERR_NOMEM;
     b->device = device;
+    if (const char* e = std::getenv("CCD_FORCE_GENERIC_ENTROPY")) b->force_generic = std::atoi(e);
     if (hipMalloc(&b->d_scale_table, sizeof(kScaleBits)) != hipSuccess) { delete b; return CCD_ERR_NOMEM; }
     if (hipMemcpy(b->d_scale_table, kScaleBits, sizeof(kScaleBits), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(b->d_scale_table); delete b; return CCD_ERR_HIP;
+    }
+    {
+        std::vector<double> rcp(kNumScale);
+        for (int i = 0; i < kNumScale; ++i) {
+            float f;
+            std::memcpy(&f, &kScaleBits[i], 4);
+            rcp[i] = 1.0 / static_cast<double>(f);  // IEEE division on the host: correctly rounded
+        }
+        if (hipMalloc(&b->d_rcp_table, sizeof(double) * kNumScale) != hipSuccess ||
+            hipMemcpy(b->d_rcp_table, rcp.data(), sizeof(double) * kNumScale, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(b->d_scale_table); if (b->d_rcp_table) (void)hipFree(b->d_rcp_table); delete b; return CCD_ERR_HIP;
+        }
     }
     *out = b;
     return CCD_OK;
@@ -141,6 +162,7 @@ void ccd_batch_destroy(ccd_batch* b) {
     for (auto& s : b->slots) s->arena.release();
     if (b->d_params) (void)hipFree(b->d_params);
     if (b->d_scale_table) (void)hipFree(b->d_scale_table);
+    if (b->d_rcp_table) (void)hipFree(b->d_rcp_table);
     delete b;
 }
 
@@ -187,8 +209,12 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
         ifce_blob.insert(ifce_blob.end(), L.w.begin(), L.w.end());
         ifce_blob.insert(ifce_blob.end(), L.b.begin(), L.b.end());
     }
-    const size_t lds = entropy_lds_bytes(h.total_context_arm, static_cast<int>(arm_blob.size()));
-    if (lds > 160 * 1024) return CCD_ERR_UNSUPPORTED;  // ARM too large for the LDS-resident kernel
+    int max_w = 0;
+    for (int g = 0; g < h.n_grids; ++g) max_w = std::max(max_w, static_cast<int>(h.grid_w[g]));
+    s.use_pipe = !b->force_generic && entropy_pipe_supports(h.total_context_arm, h.n_hidden_layers_arm + 1, net.arm.narrow ? 1 : 0, max_w);
+    s.lds_pipe = entropy_pipe_lds_bytes(h.total_context_arm, h.n_hidden_layers_arm + 1);
+    s.lds_generic = entropy_lds_bytes(h.total_context_arm, static_cast<int>(arm_blob.size()));
+    if (!s.use_pipe && s.lds_generic > 160 * 1024) return CCD_ERR_UNSUPPORTED;  // ARM too large for the LDS-resident kernels
 
     // ---- geometry of the float stages ------------------------------------------------------------------
     std::vector<int> lat_grids;
@@ -218,7 +244,7 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
         }
     }
     const size_t o_feat = A.reserve(feat_px * std::max(h.output_feature_ifce, 1) * 4);
-    const size_t o_status = A.reserve(64);
+    const size_t o_status = A.reserve(256);
     const size_t dense_elems = static_cast<size_t>(n_levels) * s.dense_h * s.dense_w;
     const size_t o_stack_a = A.reserve(dense_elems * 4);
     size_t stack_b_elems = 1;
@@ -286,6 +312,7 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     E.ifce = A.at<int64_t>(o_ifce);
     E.ifce_feat = A.at<int32_t>(o_feat);
     E.scale_table = b->d_scale_table;
+    E.rcp_table = b->d_rcp_table;
     E.status = A.at<int32_t>(o_status);
     s.d_status = E.status;
 
@@ -321,7 +348,8 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     s.d_out = A.at<float>(o_out);
     for (int p = 0; p < 3; ++p) s.d_plane[p] = bitdepth ? A.at<void>(o_plane[p]) : nullptr;
 
-    b->lds_bytes = std::max(b->lds_bytes, lds);
+    if (s.use_pipe) b->lds_pipe = std::max(b->lds_pipe, s.lds_pipe);
+    else b->lds_generic = std::max(b->lds_generic, s.lds_generic);
     b->slots.push_back(std::move(sp));
     return static_cast<int>(b->slots.size()) - 1;
 }
@@ -330,8 +358,11 @@ static int upload_params(ccd_batch* b) {
     const int n = static_cast<int>(b->slots.size());
     if (b->n_params_uploaded == n) return CCD_OK;
     if (b->d_params) { (void)hipFree(b->d_params); b->d_params = nullptr; }
-    std::vector<EntropyParams> host(n);
-    for (int i = 0; i < n; ++i) host[i] = b->slots[i]->ep;
+    std::vector<EntropyParams> host;
+    for (int i = 0; i < n; ++i) if (b->slots[i]->use_pipe) host.push_back(b->slots[i]->ep);
+    b->n_pipe = static_cast<int>(host.size());
+    for (int i = 0; i < n; ++i) if (!b->slots[i]->use_pipe) host.push_back(b->slots[i]->ep);
+    b->n_generic = n - b->n_pipe;
     if (hipMalloc(&b->d_params, sizeof(EntropyParams) * std::max(n, 1)) != hipSuccess) return CCD_ERR_NOMEM;
     if (n && hipMemcpy(b->d_params, host.data(), sizeof(EntropyParams) * n, hipMemcpyHostToDevice) != hipSuccess) return CCD_ERR_HIP;
     b->n_params_uploaded = n;
@@ -383,7 +414,8 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
     int rc = upload_params(b);
     if (rc < 0) return rc;
     if (stage == 0) {
-        HIP_TRY(launch_entropy(b->d_params, static_cast<int>(b->slots.size()), b->lds_bytes, st));
+        HIP_TRY(launch_entropy_pipe(b->d_params, b->n_pipe, b->lds_pipe, st));
+        HIP_TRY(launch_entropy(b->d_params + b->n_pipe, b->n_generic, b->lds_generic, st));
         return CCD_OK;
     }
     for (auto& sp : b->slots) {
@@ -417,6 +449,12 @@ int ccd_batch_wait(ccd_batch* b, void* stream) {
 int ccd_batch_slot_status(const ccd_batch* b, int slot) {
     if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
     return b->slots[slot]->status;
+}
+
+int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out32) {
+    if (!b || !out32 || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
+    std::memcpy(out32, b->slots[slot]->host_status, sizeof(b->slots[slot]->host_status));
+    return CCD_OK;
 }
 
 const float* ccd_batch_output(const ccd_batch* b, int slot) {

@@ -32,6 +32,7 @@ struct EntropyParams {
     const int64_t* ifce;     // per grid with IFCE: w[in][out], b[out]
     int32_t* ifce_feat;      // scratch [n_ifce_out][fh][fw] (features at the previous grid's size)
     const float* scale_table;  // 2561 float32 scales
+    const double* rcp_table;   // RN(1 / (double)scale): correctly rounded reciprocals for the f64 quotient
     int32_t* status;         // [0] error code, [1] words consumed, [2..3] symbols decoded (lo, hi)
 };
 

@@ -1,0 +1,656 @@
+// ccd_entropy_pipe.hip - the production entropy kernel: a software pipeline inside one workgroup per
+// cool-chic.  Same arithmetic as ccd_entropy.hip (the generic, barrier-phased kernel, kept as the
+// fallback for networks whose operands do not fit 32 bits), restructured around what the serial
+// chain costs on CDNA4: a lone wave issues one instruction every ~5 cycles and every VALU->SALU
+// hand-over adds ~13 (tools/ubench/lat.hip), so
+//
+//   * wave 0 (the DECODER) runs nothing but the range-decoder recurrence: per symbol one LDS read of
+//     a 64-entry window of cumulatives (L, P = R - L), two multiply-adds, one compare, s_ff1 on the
+//     ballot, three readlanes and ~8 scalar ops.  Symbols outside the window hit a sentinel lane whose
+//     P = 0, which makes the new range 0 and so rides the (rare) renormalisation branch into the slow
+//     path - no extra test on the common path;
+//   * waves 1..N-1 (PRODUCERS) run ahead: for each batch of <= 16 pixels of a wavefront diagonal they
+//     gather the contexts from an LDS ring of recently decoded symbols, evaluate the integer MLP with
+//     4 lanes per pixel (32x32->64 multiply-adds, weights read as 16-byte LDS vectors, activations
+//     exchanged through a per-wave LDS tile) and expand (mu, scale) into the window table with one
+//     f64 exp per lane;
+//   * hand-over is by sequence numbers in LDS; a batch of diagonal c+1 only needs its own rows' pixels
+//     of diagonal c, so producers work on c+1 while the decoder is still finishing c.
+//
+// Reference behaviour restated: bitstream/component/latent.py:18-187, armint.py:180-203,
+// coolchic.py:89-169, rangecoder.py:80-94 (constriction RangeDecoder + QuantizedLaplace(-64,63)).
+#include <hip/hip_runtime.h>
+
+#include "ccd_device.hpp"
+
+namespace ccd {
+
+#ifdef CCD_PIPE_PROFILE
+#define PROF_T() __builtin_amdgcn_s_memtime()
+#define PROF_ADD(var, t0) var += __builtin_amdgcn_s_memtime() - (t0)
+#else
+#define PROF_T() 0ull
+#define PROF_ADD(var, t0) (void)(t0)
+#endif
+
+constexpr int kPipeThreads = 512;           // 8 waves: 1 decoder + 7 producers
+constexpr int kPipeWaves = kPipeThreads / 64;
+constexpr int kProducers = kPipeWaves - 1;
+constexpr int kBatch = 16;                  // pixels per batch (4 lanes per pixel in the MLP)
+constexpr int kSlots = 10;                  // ring of batch slots
+constexpr int kMaxNV = 8;                   // MLP width <= 32 (in 4-wide vectors)
+constexpr int kRingRows = 512;              // rows of the decoded-symbol ring (>= live rows + 4; 4K: 384 + 4)
+constexpr unsigned kSpinLimit = 1u << 27;   // bounded spins: a lost hand-over becomes an error, not a hang
+
+// exp(x) for x <= 0 in f64: range reduction by ln 2 (two-part constant) + degree-13 Taylor/Horner.
+// Error ~1 ulp; what matters is floor(16777088 * cdf), which tests/test_gpu_parity.py compares
+// against libm over millions of reachable arguments.
+__device__ __forceinline__ double exp_nonpos(double x) {
+    if (x < -60.0) return 0.0;  // below 2^-86: contributes nothing to a 24-bit cumulative, and 1 - e/2 == 1
+    const double k = rint(x * 1.44269504088896338700e+00);
+    double r = fma(k, -6.93147180369123816490e-01, x);
+    r = fma(k, -1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;           // 1/13!
+    p = fma(p, r, 2.08767569878681e-09);         // 1/12!
+    p = fma(p, r, 2.505210838544172e-08);        // 1/11!
+    p = fma(p, r, 2.755731922398589e-07);        // 1/10!
+    p = fma(p, r, 2.7557319223985893e-06);       // 1/9!
+    p = fma(p, r, 2.48015873015873e-05);         // 1/8!
+    p = fma(p, r, 1.984126984126984e-04);        // 1/7!
+    p = fma(p, r, 1.388888888888889e-03);        // 1/6!
+    p = fma(p, r, 8.333333333333333e-03);        // 1/5!
+    p = fma(p, r, 4.1666666666666664e-02);       // 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);       // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, static_cast<int>(k));
+}
+
+// Left cumulative of symbol s; b and rcp = RN(1 / b): the quotient (x - mu) / b is formed with one
+// Newton correction, which is the correctly rounded quotient (Markstein) for these operands.
+__device__ __forceinline__ uint32_t window_left(double mu, double b, double rcp, int s) {
+    if (s <= kAcLo) return 0u;
+    if (s > kAcLo + kAlphabet - 1) return 1u << kRcPrecision;
+    const double x = static_cast<double>(s) - 0.5;
+    const double a = (x <= mu) ? (x - mu) : (mu - x);  // <= 0
+    const double q0 = a * rcp;
+    const double q = fma(fma(-q0, b, a), rcp, q0);
+    const double e = 0.5 * exp_nonpos(q);
+    const double cdf = (x <= mu) ? e : 1.0 - e;
+    return static_cast<uint32_t>(16777088.0 * cdf) + static_cast<uint32_t>(s - kAcLo);
+}
+
+struct alignas(16) BatchMeta {
+    double b[kBatch];       // Laplace scale (float32 table value widened)
+    double rcp[kBatch];     // RN(1 / b)
+    int32_t mu_idx[kBatch];
+    int32_t top[kBatch];    // symbol of window lane 1
+};
+
+struct PipeCtx {
+    const EntropyParams* P;
+    uint2* s_tab;          // [kSlots][kBatch][64] (L, P)
+    BatchMeta* s_meta;     // [kSlots]
+    int32_t* s_w;          // transposed int32 weights Wt[out][in_pad]
+    int64_t* s_b;          // biases: hidden layers, output (2), stabiliser (2)
+    int32_t* s_act;        // [kProducers][kBatch][in_pad]
+    int8_t* s_ring;        // [kRingRows][64]
+    uint32_t* s_ready;     // [kSlots]
+    uint32_t* s_consumed;
+    uint32_t* s_abort;
+    int dim, n_layers, n_sp, n_if, n_w_hidden;
+    // per grid
+    int H, W, fin, fh, fw;
+    int8_t* lat;
+    uint32_t seq_base;
+};
+
+struct DecState {
+    uint64_t dist, range;  // dist = point - lower (all the decoder ever uses)
+    uint32_t word_pos, wbase, wbuf;
+    uint64_t n_decoded;
+    unsigned long long prof_wait, prof_work;
+};
+
+__device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// LDS requests of one wave are performed in order, so a relaxed flag store issued after the payload
+// stores is enough for hand-over inside the workgroup; unlike a release it does not also wait for the
+// wave's outstanding GLOBAL stores (the decoder's writes to the latent grid).
+__device__ __forceinline__ void lds_store_ordered(uint32_t* p, uint32_t v) {
+    asm volatile("" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+// All lanes read the same word; readfirstlane tells the compiler the result is wave-uniform so that the
+// control flow hanging off it (and every value defined inside) stays scalar.
+__device__ __forceinline__ uint32_t lds_load_acquire(const uint32_t* p) {
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uni(uint64_t v) {
+    return (static_cast<uint64_t>(uni(static_cast<uint32_t>(v >> 32))) << 32) | uni(static_cast<uint32_t>(v));
+}
+
+// Spin until *p >= want (sequence numbers only grow). Returns false on abort / timeout.
+__device__ __forceinline__ bool wait_ge(const uint32_t* p, uint32_t want, uint32_t* s_abort) {
+    if (static_cast<int32_t>(lds_load_acquire(p) - want) >= 0) return true;
+    unsigned spins = 0;
+    while (static_cast<int32_t>(lds_load_acquire(p) - want) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0) {
+            if (lds_load_acquire(s_abort) != 0) return false;
+            if (spins > kSpinLimit) { lds_store_release(s_abort, static_cast<uint32_t>(-CCD_ERR_HIP)); return false; }
+        }
+    }
+    return true;
+}
+
+// Iterates the wavefront steps of one grid (latent.py:66-140).
+struct StepIter {
+    int H, W, raster, n_steps;
+    int c, y0, x0, n;
+    __device__ void init(int h, int w) { H = h; W = w; raster = w <= 9; n_steps = raster ? h * w : w + 10 * (h - 1); c = -1; }
+    __device__ bool next() {
+        if (++c >= n_steps) return false;
+        if (raster) { y0 = c / W; x0 = c - y0 * W; n = 1; }
+        else {
+            if (c < W) { y0 = 0; x0 = c; }
+            else { y0 = (c - W) / 10 + 1; x0 = W - 10 + (c - W) % 10; }
+            n = min(H - y0, x0 / 10 + 1);
+        }
+        return true;
+    }
+};
+
+// =================================================================================================
+// DECODER (wave 0): one grid.  Returns the batch sequence number after the grid.
+// =================================================================================================
+__device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) {
+    const int lane = threadIdx.x & 63;
+    const EntropyParams& P = *C.P;
+    // Everything that steers the decoder is wave-uniform; `uni` (readfirstlane) states it to the compiler,
+    // which otherwise treats values loaded through the parameter block as divergent and moves the whole
+    // recurrence to VGPRs with exec-mask control flow.
+    StepIter it;
+    it.init(uni(C.H), uni(C.W));
+    uint32_t seq = uni(C.seq_base);
+    uint64_t rc_dist = uni(S.dist), rc_range = uni(S.range);
+    uint32_t word_pos = uni(S.word_pos), wbase = uni(S.wbase), wbuf = S.wbuf;
+    const uint32_t n_words = uni(P.n_words);
+    bool ok = true;
+    while (ok && it.next()) {
+        for (int i0 = 0; i0 < it.n; i0 += kBatch, ++seq) {
+            const int cnt = uni(min(kBatch, it.n - i0));
+            const int slot = uni(static_cast<int>(seq % kSlots));
+            {
+                const unsigned long long t0 = PROF_T();
+                if (!wait_ge(&C.s_ready[slot], seq + 1, C.s_abort)) { ok = false; break; }
+                PROF_ADD(S.prof_wait, t0);
+            }
+            const unsigned long long t_dec = PROF_T();
+            const uint2* tab = C.s_tab + static_cast<size_t>(slot) * kBatch * 64 + lane;
+            const BatchMeta& meta = C.s_meta[slot];
+            int raw = 0;  // lane i: window lane chosen for pixel i
+            // ---- symbol loop: hand-scheduled recurrence (see the file header).  The asm block walks symbols
+            // i .. cnt-1 and stops early (status 1) at the first symbol whose new range has a zero high word:
+            // renormalisation, window miss or invalid data - all handled in C++ below, then the loop resumes.
+            uint32_t i = 0;
+            const uint32_t tab_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));  // LDS byte address of this lane's (L, P)
+            while (i < static_cast<uint32_t>(cnt)) {
+                uint32_t status, k_rare;
+                uint32_t taddr = tab_addr + i * 512u;
+                asm volatile(
+                    "s_mov_b64 s[50:51], %[dst]\n\t"
+                    "s_mov_b64 s[52:53], %[rng]\n\t"
+                    "ds_read_b64 v[40:41], %[ta]\n\t"
+                    "1:\n\t"
+                    "ds_read_b64 v[42:43], %[ta] offset:512\n\t"
+                    "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                    "s_waitcnt lgkmcnt(1)\n\t"
+                    "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
+                    "v_mad_u32_u24 v45, v40, s41, v45\n\t"
+                    "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                    "s_ff1_i32_b64 s44, vcc\n\t"
+                    "v_readlane_b32 s45, v41, s44\n\t"
+                    "v_readlane_b32 s46, v44, s44\n\t"
+                    "v_readlane_b32 s47, v45, s44\n\t"
+                    "s_mul_i32 s48, s40, s45\n\t"
+                    "s_mul_hi_u32 s49, s40, s45\n\t"
+                    "s_mul_i32 s45, s41, s45\n\t"
+                    "s_add_u32 s49, s49, s45\n\t"
+                    "s_cmp_eq_u32 s49, 0\n\t"
+                    "s_cbranch_scc1 3f\n\t"
+                    "s_sub_u32 s50, s50, s46\n\t"
+                    "s_subb_u32 s51, s51, s47\n\t"
+                    "s_mov_b64 s[52:53], s[48:49]\n\t"
+                    "s_mov_b32 m0, %[i]\n\t"
+                    "v_writelane_b32 %[raw], s44, m0\n\t"
+                    "s_add_u32 %[i], %[i], 1\n\t"
+                    "s_cmp_lt_u32 %[i], %[cnt]\n\t"
+                    "s_cbranch_scc0 2f\n\t"
+                    // ---- second copy: registers swapped (v[42:43] current, v[40:41] prefetch)
+                    "ds_read_b64 v[40:41], %[ta] offset:1024\n\t"
+                    "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                    "s_waitcnt lgkmcnt(1)\n\t"
+                    "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
+                    "v_mad_u32_u24 v45, v42, s41, v45\n\t"
+                    "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                    "s_ff1_i32_b64 s44, vcc\n\t"
+                    "v_readlane_b32 s45, v43, s44\n\t"
+                    "v_readlane_b32 s46, v44, s44\n\t"
+                    "v_readlane_b32 s47, v45, s44\n\t"
+                    "s_mul_i32 s48, s40, s45\n\t"
+                    "s_mul_hi_u32 s49, s40, s45\n\t"
+                    "s_mul_i32 s45, s41, s45\n\t"
+                    "s_add_u32 s49, s49, s45\n\t"
+                    "s_cmp_eq_u32 s49, 0\n\t"
+                    "s_cbranch_scc1 3f\n\t"
+                    "s_sub_u32 s50, s50, s46\n\t"
+                    "s_subb_u32 s51, s51, s47\n\t"
+                    "s_mov_b64 s[52:53], s[48:49]\n\t"
+                    "s_mov_b32 m0, %[i]\n\t"
+                    "v_writelane_b32 %[raw], s44, m0\n\t"
+                    "s_add_u32 %[i], %[i], 1\n\t"
+                    "v_add_u32 %[ta], 0x400, %[ta]\n\t"
+                    "s_cmp_lt_u32 %[i], %[cnt]\n\t"
+                    "s_cbranch_scc1 1b\n\t"
+                    "2:\n\t"
+                    "s_mov_b32 %[st], 0\n\t"
+                    "s_branch 4f\n\t"
+                    "3:\n\t"
+                    "s_mov_b32 %[st], 1\n\t"
+                    "4:\n\t"
+                    "s_mov_b32 %[kr], s44\n\t"
+                    "s_mov_b64 %[dst], s[50:51]\n\t"
+                    "s_mov_b64 %[rng], s[52:53]\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [i] "+s"(i), [raw] "+v"(raw), [ta] "+v"(taddr), [st] "=s"(status),
+                      [kr] "=s"(k_rare)
+                    : [cnt] "s"(static_cast<uint32_t>(cnt))
+                    : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "v40", "v41",
+                      "v42", "v43", "v44", "v45");
+                if (status == 0) break;
+                // ---- rare path for symbol i (state untouched by the asm block) -----------------------------------
+                const uint2 cur = tab[i * 64];
+                const uint32_t sc_lo = static_cast<uint32_t>(rc_range >> 24);
+                const uint32_t sc_hi = static_cast<uint32_t>(rc_range >> 56);
+                const uint64_t p0 = static_cast<uint64_t>(sc_lo) * cur.x;
+                const uint32_t p_lo = static_cast<uint32_t>(p0);
+                const uint32_t p_hi = static_cast<uint32_t>(p0 >> 32) + __umul24(sc_hi, cur.x);
+                int k = static_cast<int>(k_rare);
+                const uint32_t l_lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(p_lo, k));
+                const uint32_t l_hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(p_hi, k));
+                const uint32_t psel = static_cast<uint32_t>(__builtin_amdgcn_readlane(cur.y, k));
+                uint64_t nd = rc_dist - ((static_cast<uint64_t>(l_hi) << 32) | l_lo);
+                uint64_t nr = static_cast<uint64_t>(sc_lo) * psel + (static_cast<uint64_t>(sc_hi * psel) << 32);
+                if (nr == 0) {
+                    // symbol outside the window (or invalid data): full 128-way search
+                    const uint64_t scale = rc_range >> kRcPrecision;
+                    if ((rc_dist >> kRcPrecision) >= scale) {
+                        lds_store_release(C.s_abort, static_cast<uint32_t>(-CCD_ERR_INVALID_DATA));
+                        ok = false;
+                        break;
+                    }
+                    const double mu = -64.0 + static_cast<double>(meta.mu_idx[i]) * (1.0 / 256.0);
+                    const double b = meta.b[i], rcp = meta.rcp[i];
+                    const uint32_t f0 = window_left(mu, b, rcp, kAcLo + lane);
+                    const uint32_t f1 = window_left(mu, b, rcp, kAcLo + 64 + lane);
+                    const unsigned long long m0 = __ballot(scale * f0 <= rc_dist), m1 = __ballot(scale * f1 <= rc_dist);
+                    const int sidx = __popcll(m0) + __popcll(m1) - 1;
+                    const uint32_t left = uni(static_cast<uint32_t>(__shfl(sidx < 64 ? f0 : f1, sidx & 63)));
+                    uint32_t right = uni(static_cast<uint32_t>(__shfl(sidx + 1 < 64 ? f0 : f1, (sidx + 1) & 63)));
+                    if (sidx == kAlphabet - 1) right = 1u << kRcPrecision;
+                    nd = rc_dist - scale * left;
+                    nr = scale * static_cast<uint64_t>(right - left);
+                    k = uni(1 - ((sidx + kAcLo) - meta.top[i]));  // top - (k - 1) == symbol
+                }
+                if (static_cast<uint32_t>(nr >> 32) == 0) {
+                    nr <<= 32;
+                    nd = (nd << 32) | static_cast<uint32_t>(__builtin_amdgcn_readlane(wbuf, (word_pos - wbase) & 63));
+                    ++word_pos;
+                    if (word_pos - wbase == 64) { wbase = word_pos; wbuf = (wbase + lane < n_words) ? P.words[wbase + lane] : 0u; }
+                }
+                rc_dist = uni(nd); rc_range = uni(nr);
+                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(raw) : "s"(k), "s"(i));
+                ++i;
+            }
+            if (!ok) break;
+            // ---- vector epilogue of the batch: symbols -> ring + global grid ------------------------
+            if (lane < cnt) {
+                const int y = it.y0 + i0 + lane, x = it.x0 - 10 * (i0 + lane);
+                const int sym = meta.top[lane] - (raw - 1);
+                C.s_ring[(y & (kRingRows - 1)) * 64 + ((x + 10 * y) & 63)] = static_cast<int8_t>(sym);
+                C.lat[y * C.W + x] = static_cast<int8_t>(sym);
+            }
+            S.n_decoded += cnt;
+            lds_store_ordered(C.s_consumed, seq + 1);
+            PROF_ADD(S.prof_work, t_dec);
+        }
+    }
+    S.dist = rc_dist; S.range = rc_range; S.word_pos = word_pos; S.wbase = wbase; S.wbuf = wbuf;
+    return seq;
+}
+
+// =================================================================================================
+// PRODUCERS (waves 1..): one grid.  NV = in_pad / 4.
+// =================================================================================================
+__device__ __forceinline__ int64_t dot4(int4 x, int4 w) {
+    return static_cast<int64_t>(x.x) * w.x + static_cast<int64_t>(x.y) * w.y + static_cast<int64_t>(x.z) * w.z +
+           static_cast<int64_t>(x.w) * w.w;
+}
+
+template <int NV>
+__device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned long long* prof) {
+    constexpr int in_pad = 4 * NV;
+    const int lane = threadIdx.x & 63;
+    const int pw = (threadIdx.x >> 6) - 1;
+    const EntropyParams& P = *C.P;
+    const int dim = C.dim, n_layers = C.n_layers, n_sp = C.n_sp, W = C.W;
+    int32_t* act = C.s_act + pw * kBatch * in_pad;   // this wave's activation tile [kBatch][in_pad]
+    const int px = lane >> 2, q = lane & 3;          // pixel of the batch, lane within its quad
+    const int4* act_row = reinterpret_cast<const int4*>(act + px * in_pad);
+    StepIter it;
+    it.init(C.H, C.W);
+    uint32_t seq = C.seq_base, prev_first = C.seq_base;
+    int prev_nb = 0;
+    bool ok = true;
+    while (ok && it.next()) {
+        const int nb = (it.n + kBatch - 1) / kBatch;
+        for (int j = 0; j < nb; ++j, ++seq) {
+            if (static_cast<int>(seq % kProducers) != pw) continue;
+            const int i0 = j * kBatch;
+            const int cnt = min(kBatch, it.n - i0);
+            const int slot = seq % kSlots;
+            // Slot free again?  Pixels this batch reads decoded?  Its left neighbours sit in the previous step at
+            // pixel index <= i0 + cnt, i.e. in that step's batch min(j + 1, nb_prev - 1).
+            uint32_t need = seq >= static_cast<uint32_t>(kSlots) ? seq - kSlots + 1 : 0;
+            if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(j + 1, prev_nb - 1)) + 1);
+            need = max(need, C.seq_base);
+            {
+                const unsigned long long t0 = PROF_T();
+                if (!wait_ge(C.s_consumed, need, C.s_abort)) { ok = false; break; }
+                PROF_ADD(prof[0], t0);
+            }
+            const unsigned long long t_g = PROF_T();
+            // ---- gather: quad lane q fetches inputs k = q, q+4, ... of pixel px ------------------------
+            const int y = it.y0 + i0 + px, x = it.x0 - 10 * (i0 + px);
+            if (px < cnt) {
+#pragma unroll
+                for (int t = 0; t < NV; ++t) {
+                    const int k = q + 4 * t;
+                    int32_t v = 0;
+                    if (k < n_sp) {
+                        const int yy = y - P.ctx_dy[k], xx = x + P.ctx_dx[k];
+                        if (yy >= 0 && xx >= 0 && xx < W) v = C.s_ring[(yy & (kRingRows - 1)) * 64 + ((xx + 10 * yy) & 63)];
+                    } else if (k < dim && C.fin > 0) {
+                        v = P.ifce_feat[(k - n_sp) * C.fh * C.fw + (y >> 1) * C.fw + (x >> 1)];
+                    }
+                    act[px * in_pad + k] = v << 16;  // armint.py:193
+                }
+            }
+            PROF_ADD(prof[1], t_g);
+            const unsigned long long t_m = PROF_T();
+            // ---- MLP: lane computes outputs o = q + 4 t of its pixel --------------------------------------
+            int4 xv[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) xv[v] = act_row[v];
+            int64_t stab = 0;
+            if (q < 2) {  // stabiliser branch on the raw inputs
+                const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + 2 * in_pad + q * in_pad);
+                stab = C.s_b[(n_layers - 1) * dim + 2 + q];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) stab += dot4(xv[v], wr[v]);
+            }
+            for (int l = 0; l < n_layers - 1; ++l) {
+                const int32_t* wl = C.s_w + l * dim * in_pad;
+                const int64_t* bl = C.s_b + l * dim;
+                int32_t outv[NV];
+#pragma unroll
+                for (int t = 0; t < NV; ++t) {
+                    const int o = q + 4 * t;
+                    outv[t] = 0;
+                    if (o < dim) {
+                        const int4* wr = reinterpret_cast<const int4*>(wl + o * in_pad);
+                        int64_t acc = bl[o];
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) acc += dot4(xv[v], wr[v]);
+                        acc = acc < 0 ? 0 : acc;
+                        outv[t] = static_cast<int32_t>(acc >> 16);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NV; ++t) act[px * in_pad + q + 4 * t] = outv[t];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) xv[v] = act_row[v];
+            }
+            // output layer (q = 0: mu, q = 1: log-scale) -> table indices -> per-pixel table parameters
+            BatchMeta& meta = C.s_meta[slot];
+            if (q < 2) {
+                const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + q * in_pad);
+                int64_t acc = C.s_b[(n_layers - 1) * dim + q] + stab;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) acc += dot4(xv[v], wr[v]);
+                const int64_t q8 = acc >> 24;
+                const int64_t off = q8 + (q == 0 ? kMuOffset : kScaleOffset);
+                const int64_t hi = q == 0 ? kNumMu - 1 : kNumScale - 1;
+                const int32_t idx = static_cast<int32_t>(off < 0 ? 0 : (off > hi ? hi : off));
+                if (px < cnt) {
+                    if (q == 0) {
+                        int top = ((idx + 128) >> 8) - 64 + 30;  // round(mu) + 30: window = [round(mu) - 31, round(mu) + 30]
+                        top = max(kAcLo + 61, min(kAcLo + kAlphabet - 1, top));
+                        meta.mu_idx[px] = idx;
+                        meta.top[px] = top;
+                    } else {
+                        meta.b[px] = static_cast<double>(P.scale_table[idx]);
+                        meta.rcp[px] = P.rcp_table[idx];
+                    }
+                }
+            }
+            PROF_ADD(prof[2], t_m);
+            const unsigned long long t_t = PROF_T();
+            // ---- window tables: one pass of the whole wave per pixel, lane = window slot --------------------
+            // lanes 1..62 = symbols top, top-1, ..., top-61; lane 0 / 63 = sentinels (P = 0)
+            uint2* tab = C.s_tab + static_cast<size_t>(slot) * kBatch * 64;
+#pragma unroll 2
+            for (int i = 0; i < cnt; ++i) {
+                const double mu = -64.0 + static_cast<double>(meta.mu_idx[i]) * (1.0 / 256.0);
+                const double b = meta.b[i], rcp = meta.rcp[i];
+                const int s = meta.top[i] - (lane - 1);  // lane 0 -> top + 1: its left bound is the window's upper edge
+                // every stored bound must fit 24 bits (v_mad_u32_u24 in the decoder): the upper sentinel of a window
+                // that reaches symbol 63 is clamped to 2^24 - 1; a hit on it only costs a detour through the slow path
+                const uint32_t left = (lane == 63) ? 0u : min(window_left(mu, b, rcp, s), (1u << kRcPrecision) - 1u);
+                const uint32_t right = __shfl_up(left, 1);  // lane k-1 holds symbol s+1: its left bound is our right bound
+                uint2 e;
+                e.x = left;
+                e.y = (lane == 0 || lane == 63) ? 0u : ((lane == 1 && s == kAcLo + kAlphabet - 1) ? (1u << kRcPrecision) - left : right - left);
+                tab[i * 64 + lane] = e;
+            }
+            if (lane == 0) lds_store_release(&C.s_ready[slot], seq + 1);
+            PROF_ADD(prof[3], t_t);
+        }
+        if (!ok) break;
+        prev_first = seq - nb;
+        prev_nb = nb;
+    }
+    return seq;
+}
+
+__device__ __forceinline__ uint32_t producer_dispatch(const PipeCtx& C, int nv, unsigned long long* prof) {
+    switch (nv) {
+        case 1: return producer_grid<1>(C, prof);
+        case 2: return producer_grid<2>(C, prof);
+        case 3: return producer_grid<3>(C, prof);
+        case 4: return producer_grid<4>(C, prof);
+        case 5: return producer_grid<5>(C, prof);
+        case 6: return producer_grid<6>(C, prof);
+        case 7: return producer_grid<7>(C, prof);
+        default: return producer_grid<8>(C, prof);
+    }
+}
+
+__global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const EntropyParams* slots_desc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const EntropyParams& P = slots_desc[blockIdx.x];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dim = P.dim;
+    const int in_pad = (dim + 3) & ~3;
+    const int n_layers = P.n_layers;
+    const int n_if = P.has_ifce ? P.n_ifce_out : 0;
+
+    // ---- LDS carve-up (all offsets multiples of 16) ----------------------------------------------
+    PipeCtx C;
+    C.P = &P;
+    C.s_tab = reinterpret_cast<uint2*>(smem);
+    C.s_meta = reinterpret_cast<BatchMeta*>(C.s_tab + kSlots * kBatch * 64);
+    C.s_w = reinterpret_cast<int32_t*>(C.s_meta + kSlots);
+    C.n_w_hidden = (n_layers - 1) * dim * in_pad;
+    const int n_w_total = C.n_w_hidden + 4 * in_pad;  // + output layer (2 rows) + stabiliser (2 rows)
+    C.s_b = reinterpret_cast<int64_t*>(C.s_w + ((n_w_total + 3) & ~3));
+    const int n_b_total = (n_layers - 1) * dim + 4;
+    C.s_act = reinterpret_cast<int32_t*>(C.s_b + ((n_b_total + 1) & ~1));
+    C.s_ring = reinterpret_cast<int8_t*>(C.s_act + kProducers * kBatch * in_pad);
+    uint32_t* s_sync = reinterpret_cast<uint32_t*>(C.s_ring + kRingRows * 64);
+    C.s_ready = s_sync;
+    C.s_consumed = s_sync + kSlots;
+    C.s_abort = C.s_consumed + 1;
+    C.dim = dim; C.n_layers = n_layers; C.n_sp = P.n_spatial; C.n_if = n_if;
+
+    // ---- stage the network: int64 blob (w[in][out], b[out] per layer; ws[dim][2], bs[2]) -> int32 Wt[out][in_pad]
+    {
+        const int64_t* src = P.arm;
+        for (int l = 0; l < n_layers; ++l) {
+            const int n_out = (l == n_layers - 1) ? 2 : dim;
+            int32_t* wt = C.s_w + (l < n_layers - 1 ? l * dim * in_pad : C.n_w_hidden);
+            for (int i = tid; i < n_out * in_pad; i += kPipeThreads) {
+                const int o = i / in_pad, k = i - o * in_pad;
+                wt[i] = k < dim ? static_cast<int32_t>(src[k * n_out + o]) : 0;
+            }
+            int64_t* bb = C.s_b + (l < n_layers - 1 ? l * dim : (n_layers - 1) * dim);
+            for (int i = tid; i < n_out; i += kPipeThreads) bb[i] = src[dim * n_out + i];
+            src += dim * n_out + n_out;
+        }
+        int32_t* wst = C.s_w + C.n_w_hidden + 2 * in_pad;
+        for (int i = tid; i < 2 * in_pad; i += kPipeThreads) {
+            const int o = i / in_pad, k = i - o * in_pad;
+            wst[i] = k < dim ? static_cast<int32_t>(src[k * 2 + o]) : 0;
+        }
+        if (tid < 2) C.s_b[(n_layers - 1) * dim + 2 + tid] = src[dim * 2 + tid];
+    }
+    for (int i = tid; i < kProducers * kBatch * in_pad; i += kPipeThreads) C.s_act[i] = 0;
+    if (tid < kSlots) C.s_ready[tid] = 0;
+    if (tid == 0) { *C.s_consumed = 0; *C.s_abort = 0; }
+
+    DecState S;
+    S.range = ~uint64_t{0}; S.dist = 0; S.word_pos = 2; S.wbase = 2; S.wbuf = 0; S.n_decoded = 0;
+    S.prof_wait = 0; S.prof_work = 0;
+    if (wave == 0) {
+        // loads through pointers stored in the parameter block are FLAT loads, which the compiler treats as
+        // divergent; readfirstlane keeps the coder state (and all control flow depending on it) scalar
+        const uint32_t w0 = __builtin_amdgcn_readfirstlane(P.n_words > 0 ? P.words[0] : 0u);
+        const uint32_t w1 = __builtin_amdgcn_readfirstlane(P.n_words > 1 ? P.words[1] : 0u);
+        S.dist = (static_cast<uint64_t>(w0) << 32) | w1;
+        S.wbuf = (S.wbase + lane < P.n_words) ? P.words[S.wbase + lane] : 0u;
+    }
+    unsigned long long prof[4] = {0, 0, 0, 0};
+    const unsigned long long prof_total0 = PROF_T();
+    C.seq_base = 0;
+    __syncthreads();
+
+    for (int g = P.n_grids - 1; g >= 0; --g) {
+        C.H = P.grid_h[g]; C.W = P.grid_w[g];
+        C.lat = P.latent[g];
+        C.fin = P.ifce_in[g];
+        C.fh = (g == P.n_grids - 1) ? C.H : P.grid_h[g + 1];
+        C.fw = (g == P.n_grids - 1) ? C.W : P.grid_w[g + 1];
+        // ---- IFCE features at the previously decoded grid's size (coolchic.py:94-146) -------------
+        if (C.fin > 0) {
+            const int fin = C.fin, fh = C.fh, fw = C.fw;
+            const int64_t* fw_ = P.ifce + P.ifce_off[g];
+            const int64_t* fb_ = fw_ + fin * n_if;
+            const int base_level = (g == P.n_grids - 1) ? 0 : P.level[g + 1];
+            for (int p = tid; p < fh * fw; p += kPipeThreads) {
+                const int y = p / fw, x = p - y * fw;
+                for (int o = 0; o < n_if; ++o) {
+                    uint64_t acc = static_cast<uint64_t>(fb_[o]);
+                    if (g != P.n_grids - 1) {
+                        for (int c = 0; c < fin; ++c) {
+                            const int m = g + 1 + c;
+                            const int sh = P.level[m] - base_level;
+                            const int64_t v = P.latent[m][(y >> sh) * P.grid_w[m] + (x >> sh)];
+                            acc += static_cast<uint64_t>(v << 16) * static_cast<uint64_t>(fw_[c * n_if + o]);
+                        }
+                    }
+                    const int64_t q8 = static_cast<int64_t>(acc) >> 24;
+                    P.ifce_feat[o * fh * fw + p] = static_cast<int32_t>(static_cast<int64_t>(static_cast<float>(q8)));
+                }
+            }
+        }
+        __syncthreads();  // features visible; every wave finished the previous grid
+
+        uint32_t seq_end;
+        if (wave == 0) {
+            __builtin_amdgcn_s_setprio(3);
+            seq_end = decoder_grid(C, S);
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            seq_end = producer_dispatch(C, in_pad / 4, prof);
+        }
+        __syncthreads();  // also makes the decoder's global writes of this grid visible to every wave
+        if (lds_load_acquire(C.s_abort) != 0) break;
+        C.seq_base = seq_end;  // every wave walked the same batches
+    }
+    if (tid == 0) {
+        const uint32_t ab = *C.s_abort;
+        P.status[0] = ab ? -static_cast<int32_t>(ab) : 0;
+        P.status[1] = static_cast<int32_t>(S.word_pos);
+        P.status[2] = static_cast<int32_t>(S.n_decoded & 0xffffffffu);
+        P.status[3] = static_cast<int32_t>(S.n_decoded >> 32);
+    }
+#ifdef CCD_PIPE_PROFILE
+    if (lane == 0 && wave < 2) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(P.status + 4) + wave * 5;
+        o[0] = __builtin_amdgcn_s_memtime() - prof_total0;
+        if (wave == 0) { o[1] = S.prof_wait; o[2] = S.prof_work; o[3] = 0; o[4] = 0; }
+        else { o[1] = prof[0]; o[2] = prof[1]; o[3] = prof[2]; o[4] = prof[3]; }
+    }
+#else
+    (void)prof_total0;
+#endif
+}
+
+size_t entropy_pipe_lds_bytes(int dim, int n_layers) {
+    const int in_pad = (dim + 3) & ~3;
+    const int n_w_total = (n_layers - 1) * dim * in_pad + 4 * in_pad;
+    const int n_b_total = (n_layers - 1) * dim + 4;
+    size_t n = static_cast<size_t>(kSlots) * kBatch * 64 * sizeof(uint2);
+    n += static_cast<size_t>(kSlots) * sizeof(BatchMeta);
+    n += static_cast<size_t>((n_w_total + 3) & ~3) * 4;
+    n += static_cast<size_t>((n_b_total + 1) & ~1) * 8;
+    n += static_cast<size_t>(kProducers) * kBatch * in_pad * 4;
+    n += static_cast<size_t>(kRingRows) * 64;
+    n += (kSlots + 8) * 4;
+    return (n + 15) & ~size_t{15};
+}
+
+bool entropy_pipe_supports(int dim, int n_layers, int narrow, int max_grid_w) {
+    return narrow && dim <= 4 * kMaxNV && n_layers <= 8 && max_grid_w / 10 + 6 <= kRingRows &&
+           entropy_pipe_lds_bytes(dim, n_layers) <= 160 * 1024;
+}
+
+hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream) {
+    if (n_slots <= 0) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(entropy_pipe_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(entropy_pipe_kernel, dim3(n_slots), dim3(kPipeThreads), lds_bytes, stream, d_slots);
+    return hipGetLastError();
+}
+
+}  // namespace ccd

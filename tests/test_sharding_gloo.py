@@ -1,0 +1,61 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the frame sharding + plane gather used by
+bench.py --gpus N and decode of image sets."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cool_chic_amd.parallel import gather_bytes, pack_planes, shard_indices, unshard
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _frame(i):  # deterministic fake decoded frame of a size that depends on i
+    rng = np.random.default_rng(i)
+    h, w = 8 + i, 12 + 2 * i
+    return [torch.from_numpy(rng.integers(0, 256, (h, w), dtype=np.uint8)) for _ in range(3)]
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = shard_indices(n_frames, rank, world)
+    local = [pack_planes(_frame(i)) for i in mine]
+    lens = torch.tensor([t.numel() for t in local], dtype=torch.int64)
+    blob = torch.cat(local) if local else torch.empty(0, dtype=torch.uint8)
+    got = gather_bytes(blob, dst=0)
+    got_lens = gather_bytes(lens.view(torch.uint8).reshape(-1), dst=0)
+    if rank == 0:
+        per_rank = []
+        for b, l in zip(got, got_lens):
+            l = l.view(torch.int64)
+            per_rank.append(list(torch.split(b, [int(x) for x in l])))
+        frames = unshard(per_rank, n_frames)
+        ok = all(torch.equal(f, pack_planes(_frame(i))) for i, f in enumerate(frames))
+        q.put(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_round_robin_and_gather_world2():
+    assert shard_indices(5, 0, 2) == [0, 2, 4] and shard_indices(5, 1, 2) == [1, 3]
+    assert shard_indices(1, 1, 2) == []
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, 5, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert ok

@@ -1,0 +1,21 @@
+import sys, ctypes as C
+sys.path.insert(0,'/root/repo')
+import numpy as np, torch
+from cool_chic_amd import DecodeBatch
+from cool_chic_amd._lib import lib
+from oracle import oracle_py as O
+bs=open('/root/repo/tests/golden/kodim14.cool','rb').read()
+fh,ccs=O.split_stream(bs)[1][0]
+b=DecodeBatch(0)
+n=int(sys.argv[1]) if len(sys.argv)>1 else 1
+for i in range(n): b.add(*ccs[0],8,0)
+import time
+for rep in range(2):
+    torch.cuda.synchronize(); t=time.time(); b.run(stage=0); b.wait(); dt=time.time()-t
+print('entropy stage wall ms', dt*1e3)
+st=np.zeros(32,np.int32); lib().ccd_batch_slot_stats(b._h,0,st.ctypes.data)
+u=st[4:].view(np.uint64)
+print('decoder : total %d wait %d decode %d'%(u[0],u[1],u[2]), ' per symbol decode cycles %.1f'%(u[2]/526272), 'wait frac %.2f'%(u[1]/u[0]))
+print('producer1: total %d wait %d gather %d mlp %d table %d'%(u[5],u[6],u[7],u[8],u[9]))
+nb=526272/16/7
+print(' per batch (approx %d batches): gather %.0f mlp %.0f table %.0f cycles'%(nb,u[7]/nb,u[8]/nb,u[9]/nb))
