@@ -36,7 +36,10 @@ namespace ccd {
 constexpr int kPipeThreads = 512;           // 8 waves: 1 decoder + 7 producers
 constexpr int kPipeWaves = kPipeThreads / 64;
 constexpr int kProducers = kPipeWaves - 1;
-constexpr int kBatch = 16;                  // pixels per batch (4 lanes per pixel in the MLP)
+constexpr int kBatch = 16;                  // pixels per decoder batch (one slot)
+constexpr int kLpp = 8;                     // producer: lanes per pixel in the MLP
+constexpr int kTaskPix = 64 / kLpp;         // producer task = half a batch (8 pixels)
+constexpr int kHalves = kBatch / kTaskPix;
 constexpr int kSlots = 10;                  // ring of batch slots
 constexpr int kMaxNV = 8;                   // MLP width <= 32 (in 4-wide vectors)
 constexpr int kRingRows = 512;              // rows of the decoded-symbol ring (>= live rows + 4; 4K: 384 + 4)
@@ -46,39 +49,45 @@ constexpr unsigned kSpinLimit = 1u << 27;   // bounded spins: a lost hand-over b
 // Error ~1 ulp; what matters is floor(16777088 * cdf), which tests/test_gpu_parity.py compares
 // against libm over millions of reachable arguments.
 __device__ __forceinline__ double exp_nonpos(double x) {
-    if (x < -60.0) return 0.0;  // below 2^-86: contributes nothing to a 24-bit cumulative, and 1 - e/2 == 1
+    // branch-free on purpose: four of these chains are interleaved by the table builder
+    const bool tiny = x < -60.0;  // below 2^-86: contributes nothing to a 24-bit cumulative, and 1 - e/2 == 1
+    x = tiny ? -60.0 : x;
     const double k = rint(x * 1.44269504088896338700e+00);
     double r = fma(k, -6.93147180369123816490e-01, x);
     r = fma(k, -1.90821492927058770002e-10, r);
-    double p = 1.6059043836821613e-10;           // 1/13!
-    p = fma(p, r, 2.08767569878681e-09);         // 1/12!
-    p = fma(p, r, 2.505210838544172e-08);        // 1/11!
-    p = fma(p, r, 2.755731922398589e-07);        // 1/10!
-    p = fma(p, r, 2.7557319223985893e-06);       // 1/9!
-    p = fma(p, r, 2.48015873015873e-05);         // 1/8!
-    p = fma(p, r, 1.984126984126984e-04);        // 1/7!
-    p = fma(p, r, 1.388888888888889e-03);        // 1/6!
-    p = fma(p, r, 8.333333333333333e-03);        // 1/5!
-    p = fma(p, r, 4.1666666666666664e-02);       // 1/4!
-    p = fma(p, r, 1.6666666666666666e-01);       // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, static_cast<int>(k));
+    // e^r = E(r^2) + r * O(r^2): two independent Horner chains of 7 instead of one of 14
+    const double r2 = r * r;
+    double pe = 1.1470745597729725e-11;           // 1/14!
+    double po = 1.6059043836821613e-10;           // 1/13!
+    pe = fma(pe, r2, 2.08767569878681e-09);       // 1/12!
+    po = fma(po, r2, 2.505210838544172e-08);      // 1/11!
+    pe = fma(pe, r2, 2.755731922398589e-07);      // 1/10!
+    po = fma(po, r2, 2.7557319223985893e-06);     // 1/9!
+    pe = fma(pe, r2, 2.48015873015873e-05);       // 1/8!
+    po = fma(po, r2, 1.984126984126984e-04);      // 1/7!
+    pe = fma(pe, r2, 1.388888888888889e-03);      // 1/6!
+    po = fma(po, r2, 8.333333333333333e-03);      // 1/5!
+    pe = fma(pe, r2, 4.1666666666666664e-02);     // 1/4!
+    po = fma(po, r2, 1.6666666666666666e-01);     // 1/3!
+    pe = fma(pe, r2, 0.5);                        // 1/2!
+    po = fma(po, r2, 1.0);                        // 1/1!
+    pe = fma(pe, r2, 1.0);                        // 1/0!
+    const double e = ldexp(fma(po, r, pe), static_cast<int>(k));
+    return tiny ? 0.0 : e;
 }
 
 // Left cumulative of symbol s; b and rcp = RN(1 / b): the quotient (x - mu) / b is formed with one
 // Newton correction, which is the correctly rounded quotient (Markstein) for these operands.
 __device__ __forceinline__ uint32_t window_left(double mu, double b, double rcp, int s) {
-    if (s <= kAcLo) return 0u;
-    if (s > kAcLo + kAlphabet - 1) return 1u << kRcPrecision;
     const double x = static_cast<double>(s) - 0.5;
-    const double a = (x <= mu) ? (x - mu) : (mu - x);  // <= 0
+    const bool below = x <= mu;
+    const double a = below ? (x - mu) : (mu - x);  // <= 0
     const double q0 = a * rcp;
     const double q = fma(fma(-q0, b, a), rcp, q0);
     const double e = 0.5 * exp_nonpos(q);
-    const double cdf = (x <= mu) ? e : 1.0 - e;
-    return static_cast<uint32_t>(16777088.0 * cdf) + static_cast<uint32_t>(s - kAcLo);
+    const double cdf = below ? e : 1.0 - e;
+    const uint32_t v = static_cast<uint32_t>(16777088.0 * cdf) + static_cast<uint32_t>(s - kAcLo);
+    return s <= kAcLo ? 0u : (s > kAcLo + kAlphabet - 1 ? (1u << kRcPrecision) : v);
 }
 
 struct alignas(16) BatchMeta {
@@ -96,7 +105,7 @@ struct PipeCtx {
     int64_t* s_b;          // biases: hidden layers, output (2), stabiliser (2)
     int32_t* s_act;        // [kProducers][kBatch][in_pad]
     int8_t* s_ring;        // [kRingRows][64]
-    uint32_t* s_ready;     // [kSlots]
+    uint32_t* s_ready;     // [kSlots][kHalves]
     uint32_t* s_consumed;
     uint32_t* s_abort;
     int dim, n_layers, n_sp, n_if, n_w_hidden;
@@ -189,7 +198,8 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
             const int slot = uni(static_cast<int>(seq % kSlots));
             {
                 const unsigned long long t0 = PROF_T();
-                if (!wait_ge(&C.s_ready[slot], seq + 1, C.s_abort)) { ok = false; break; }
+                if (!wait_ge(&C.s_ready[slot * kHalves], seq + 1, C.s_abort)) { ok = false; break; }
+                if (cnt > kTaskPix && !wait_ge(&C.s_ready[slot * kHalves + 1], seq + 1, C.s_abort)) { ok = false; break; }
                 PROF_ADD(S.prof_wait, t0);
             }
             const unsigned long long t_dec = PROF_T();
@@ -347,135 +357,207 @@ __device__ __forceinline__ int64_t dot4(int4 x, int4 w) {
 template <int NV>
 __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned long long* prof) {
     constexpr int in_pad = 4 * NV;
+    constexpr int NOUT = (in_pad + kLpp - 1) / kLpp;  // outputs per lane in a hidden layer
     const int lane = threadIdx.x & 63;
     const int pw = (threadIdx.x >> 6) - 1;
     const EntropyParams& P = *C.P;
     const int dim = C.dim, n_layers = C.n_layers, n_sp = C.n_sp, W = C.W;
-    int32_t* act = C.s_act + pw * kBatch * in_pad;   // this wave's activation tile [kBatch][in_pad]
-    const int px = lane >> 2, q = lane & 3;          // pixel of the batch, lane within its quad
+    int32_t* act = C.s_act + pw * kBatch * in_pad;   // this wave's activation tile [kTaskPix][in_pad] (kBatch rows reserved)
+    const int px = lane / kLpp, q = lane % kLpp;     // pixel of the task, lane within its group
     const int4* act_row = reinterpret_cast<const int4*>(act + px * in_pad);
     StepIter it;
     it.init(C.H, C.W);
     uint32_t seq = C.seq_base, prev_first = C.seq_base;
-    int prev_nb = 0;
+    int prev_nb = 0, prev_n = 0;
     bool ok = true;
     while (ok && it.next()) {
         const int nb = (it.n + kBatch - 1) / kBatch;
-        for (int j = 0; j < nb; ++j, ++seq) {
-            if (static_cast<int>(seq % kProducers) != pw) continue;
-            const int i0 = j * kBatch;
-            const int cnt = min(kBatch, it.n - i0);
+        for (int j = 0; j < nb && ok; ++j, ++seq) {
             const int slot = seq % kSlots;
-            // Slot free again?  Pixels this batch reads decoded?  Its left neighbours sit in the previous step at
-            // pixel index <= i0 + cnt, i.e. in that step's batch min(j + 1, nb_prev - 1).
-            uint32_t need = seq >= static_cast<uint32_t>(kSlots) ? seq - kSlots + 1 : 0;
-            if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(j + 1, prev_nb - 1)) + 1);
-            need = max(need, C.seq_base);
-            {
-                const unsigned long long t0 = PROF_T();
-                if (!wait_ge(C.s_consumed, need, C.s_abort)) { ok = false; break; }
-                PROF_ADD(prof[0], t0);
-            }
-            const unsigned long long t_g = PROF_T();
-            // ---- gather: quad lane q fetches inputs k = q, q+4, ... of pixel px ------------------------
-            const int y = it.y0 + i0 + px, x = it.x0 - 10 * (i0 + px);
-            if (px < cnt) {
+            for (int half = 0; half < kHalves; ++half) {
+                const int i0 = j * kBatch + half * kTaskPix;     // first pixel of the task within the step
+                if (i0 >= it.n) break;
+                if (static_cast<int>((seq * kHalves + half) % kProducers) != pw) continue;
+                const int cnt = min(kTaskPix, it.n - i0);
+                const int y = it.y0 + i0 + px, x = it.x0 - 10 * (i0 + px);
+                // ---- IFCE features do not depend on this grid: fetch them before waiting on the decoder -------
+                int32_t fv[NOUT];
 #pragma unroll
-                for (int t = 0; t < NV; ++t) {
-                    const int k = q + 4 * t;
-                    int32_t v = 0;
-                    if (k < n_sp) {
-                        const int yy = y - P.ctx_dy[k], xx = x + P.ctx_dx[k];
-                        if (yy >= 0 && xx >= 0 && xx < W) v = C.s_ring[(yy & (kRingRows - 1)) * 64 + ((xx + 10 * yy) & 63)];
-                    } else if (k < dim && C.fin > 0) {
-                        v = P.ifce_feat[(k - n_sp) * C.fh * C.fw + (y >> 1) * C.fw + (x >> 1)];
-                    }
-                    act[px * in_pad + k] = v << 16;  // armint.py:193
+                for (int t = 0; t < NOUT; ++t) {
+                    const int k = q + kLpp * t;
+                    fv[t] = 0;
+                    if (px < cnt && k >= n_sp && k < dim && C.fin > 0)
+                        fv[t] = P.ifce_feat[(k - n_sp) * C.fh * C.fw + (y >> 1) * C.fw + (x >> 1)];
                 }
-            }
-            PROF_ADD(prof[1], t_g);
-            const unsigned long long t_m = PROF_T();
-            // ---- MLP: lane computes outputs o = q + 4 t of its pixel --------------------------------------
-            int4 xv[NV];
+                // Slot free again?  Pixels this task reads decoded?  Its left neighbours sit in the previous step at pixel
+                // index <= i0 + cnt, i.e. in that step's batch (i0 + cnt) / kBatch (clamped to its last batch).
+                uint32_t need = seq >= static_cast<uint32_t>(kSlots) ? seq - kSlots + 1 : 0;
+                if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(i0 + cnt, prev_n - 1) / kBatch) + 1);
+                need = max(need, C.seq_base);
+                {
+                    const unsigned long long t0 = PROF_T();
+                    if (!wait_ge(C.s_consumed, need, C.s_abort)) { ok = false; break; }
+                    PROF_ADD(prof[0], t0);
+                }
+                const unsigned long long t_g = PROF_T();
+                // ---- gather: lane q of the pixel's group fetches inputs k = q, q + 8, ... --------------------------
+                if (px < cnt) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) xv[v] = act_row[v];
-            int64_t stab = 0;
-            if (q < 2) {  // stabiliser branch on the raw inputs
-                const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + 2 * in_pad + q * in_pad);
-                stab = C.s_b[(n_layers - 1) * dim + 2 + q];
-#pragma unroll
-                for (int v = 0; v < NV; ++v) stab += dot4(xv[v], wr[v]);
-            }
-            for (int l = 0; l < n_layers - 1; ++l) {
-                const int32_t* wl = C.s_w + l * dim * in_pad;
-                const int64_t* bl = C.s_b + l * dim;
-                int32_t outv[NV];
-#pragma unroll
-                for (int t = 0; t < NV; ++t) {
-                    const int o = q + 4 * t;
-                    outv[t] = 0;
-                    if (o < dim) {
-                        const int4* wr = reinterpret_cast<const int4*>(wl + o * in_pad);
-                        int64_t acc = bl[o];
-#pragma unroll
-                        for (int v = 0; v < NV; ++v) acc += dot4(xv[v], wr[v]);
-                        acc = acc < 0 ? 0 : acc;
-                        outv[t] = static_cast<int32_t>(acc >> 16);
+                    for (int t = 0; t < NOUT; ++t) {
+                        const int k = q + kLpp * t;
+                        if (k < in_pad) {
+                            int32_t v = fv[t];
+                            if (k < n_sp) {
+                                const int yy = y - P.ctx_dy[k], xx = x + P.ctx_dx[k];
+                                v = (yy >= 0 && xx >= 0 && xx < W) ? C.s_ring[(yy & (kRingRows - 1)) * 64 + ((xx + 10 * yy) & 63)] : 0;
+                            }
+                            act[px * in_pad + k] = v << 16;  // armint.py:193
+                        }
                     }
                 }
-#pragma unroll
-                for (int t = 0; t < NV; ++t) act[px * in_pad + q + 4 * t] = outv[t];
+                PROF_ADD(prof[1], t_g);
+                const unsigned long long t_m = PROF_T();
+                // ---- MLP: lane computes outputs o = q + 8 t of its pixel ------------------------------------------
+                int4 xv[NV];
 #pragma unroll
                 for (int v = 0; v < NV; ++v) xv[v] = act_row[v];
-            }
-            // output layer (q = 0: mu, q = 1: log-scale) -> table indices -> per-pixel table parameters
-            BatchMeta& meta = C.s_meta[slot];
-            if (q < 2) {
-                const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + q * in_pad);
-                int64_t acc = C.s_b[(n_layers - 1) * dim + q] + stab;
+                int64_t stab = 0;
+                if (q < 2) {  // stabiliser branch on the raw inputs
+                    const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + 2 * in_pad + q * in_pad);
+                    stab = C.s_b[(n_layers - 1) * dim + 2 + q];
 #pragma unroll
-                for (int v = 0; v < NV; ++v) acc += dot4(xv[v], wr[v]);
-                const int64_t q8 = acc >> 24;
-                const int64_t off = q8 + (q == 0 ? kMuOffset : kScaleOffset);
-                const int64_t hi = q == 0 ? kNumMu - 1 : kNumScale - 1;
-                const int32_t idx = static_cast<int32_t>(off < 0 ? 0 : (off > hi ? hi : off));
-                if (px < cnt) {
-                    if (q == 0) {
-                        int top = ((idx + 128) >> 8) - 64 + 30;  // round(mu) + 30: window = [round(mu) - 31, round(mu) + 30]
-                        top = max(kAcLo + 61, min(kAcLo + kAlphabet - 1, top));
-                        meta.mu_idx[px] = idx;
-                        meta.top[px] = top;
-                    } else {
-                        meta.b[px] = static_cast<double>(P.scale_table[idx]);
-                        meta.rcp[px] = P.rcp_table[idx];
+                    for (int v = 0; v < NV; ++v) stab += dot4(xv[v], wr[v]);
+                }
+                for (int l = 0; l < n_layers - 1; ++l) {
+                    const int32_t* wl = C.s_w + l * dim * in_pad;
+                    const int64_t* bl = C.s_b + l * dim;
+                    int32_t outv[NOUT];
+#pragma unroll
+                    for (int t = 0; t < NOUT; ++t) {
+                        const int o = q + kLpp * t;
+                        outv[t] = 0;
+                        if (o < dim) {
+                            const int4* wr = reinterpret_cast<const int4*>(wl + o * in_pad);
+                            int64_t acc = bl[o];
+#pragma unroll
+                            for (int v = 0; v < NV; ++v) acc += dot4(xv[v], wr[v]);
+                            acc = acc < 0 ? 0 : acc;
+                            outv[t] = static_cast<int32_t>(acc >> 16);
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < NOUT; ++t)
+                        if (q + kLpp * t < in_pad) act[px * in_pad + q + kLpp * t] = outv[t];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) xv[v] = act_row[v];
+                }
+                // output layer (q = 0: mu, q = 1: log-scale) -> table indices -> per-pixel table parameters
+                BatchMeta& meta = C.s_meta[slot];
+                const int mpx = half * kTaskPix + px;  // pixel index inside the slot
+                if (q < 2) {
+                    const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + q * in_pad);
+                    int64_t acc = C.s_b[(n_layers - 1) * dim + q] + stab;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) acc += dot4(xv[v], wr[v]);
+                    const int64_t q8 = acc >> 24;
+                    const int64_t off = q8 + (q == 0 ? kMuOffset : kScaleOffset);
+                    const int64_t hi = q == 0 ? kNumMu - 1 : kNumScale - 1;
+                    const int32_t idx = static_cast<int32_t>(off < 0 ? 0 : (off > hi ? hi : off));
+                    if (px < cnt) {
+                        if (q == 0) {
+                            int top = ((idx + 128) >> 8) - 64 + 30;  // round(mu) + 30: window = [round(mu) - 31, round(mu) + 30]
+                            top = max(kAcLo + 61, min(kAcLo + kAlphabet - 1, top));
+                            meta.mu_idx[mpx] = idx;
+                            meta.top[mpx] = top;
+                        } else {
+                            meta.b[mpx] = static_cast<double>(P.scale_table[idx]);
+                            meta.rcp[mpx] = P.rcp_table[idx];
+                        }
                     }
                 }
+                PROF_ADD(prof[2], t_m);
+                const unsigned long long t_t = PROF_T();
+                // ---- window tables: one pass of the whole wave per pixel, lane = window slot; passes are issued four at
+                // a time so that their (long, dependent) f64 chains overlap.
+                // lanes 1..62 = symbols top, top-1, ..., top-61; lane 0 / 63 = sentinels (P = 0)
+                uint2* tab = C.s_tab + (static_cast<size_t>(slot) * kBatch + half * kTaskPix) * 64;
+                for (int g0 = 0; g0 < cnt; g0 += 4) {
+                    // Four passes in lock-step, written structure-of-arrays so that the four dependent f64 chains sit
+                    // in one basic block and interleave (no branches: out-of-range lanes are fixed up by selects).
+                    double mu4[4], b4[4], r4[4], a4[4], kq[4], rr[4], r2[4], pe[4], po[4], ex[4];
+                    int ssym[4];
+                    bool below[4], tiny[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = min(g0 + u, cnt - 1) + half * kTaskPix;
+                        mu4[u] = -64.0 + static_cast<double>(meta.mu_idx[i]) * (1.0 / 256.0);
+                        b4[u] = meta.b[i];
+                        r4[u] = meta.rcp[i];
+                        ssym[u] = meta.top[i] - (lane - 1);  // lane 0 -> top + 1: its left bound is the window's upper edge
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double x = static_cast<double>(ssym[u]) - 0.5;
+                        below[u] = x <= mu4[u];
+                        a4[u] = below[u] ? (x - mu4[u]) : (mu4[u] - x);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) kq[u] = a4[u] * r4[u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) kq[u] = fma(fma(-kq[u], b4[u], a4[u]), r4[u], kq[u]);  // correctly rounded a / b
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { tiny[u] = kq[u] < -60.0; a4[u] = tiny[u] ? -60.0 : kq[u]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) kq[u] = rint(a4[u] * 1.44269504088896338700e+00);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rr[u] = fma(kq[u], -1.90821492927058770002e-10, fma(kq[u], -6.93147180369123816490e-01, a4[u]));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { r2[u] = rr[u] * rr[u]; pe[u] = 1.1470745597729725e-11; po[u] = 1.6059043836821613e-10; }
+#define CCD_POLY_STEP(ce, co)                                               \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                          \
+        pe[u] = fma(pe[u], r2[u], ce);                                       \
+        po[u] = fma(po[u], r2[u], co);                                       \
+    }
+                    CCD_POLY_STEP(2.08767569878681e-09, 2.505210838544172e-08)
+                    CCD_POLY_STEP(2.755731922398589e-07, 2.7557319223985893e-06)
+                    CCD_POLY_STEP(2.48015873015873e-05, 1.984126984126984e-04)
+                    CCD_POLY_STEP(1.388888888888889e-03, 8.333333333333333e-03)
+                    CCD_POLY_STEP(4.1666666666666664e-02, 1.6666666666666666e-01)
+                    CCD_POLY_STEP(0.5, 1.0)
+#undef CCD_POLY_STEP
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) pe[u] = fma(pe[u], r2[u], 1.0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ex[u] = 0.5 * ldexp(fma(po[u], rr[u], pe[u]), static_cast<int>(kq[u]));
+                    uint32_t left[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double e = tiny[u] ? 0.0 : ex[u];
+                        const double cdf = below[u] ? e : 1.0 - e;
+                        uint32_t v = static_cast<uint32_t>(16777088.0 * cdf) + static_cast<uint32_t>(ssym[u] - kAcLo);
+                        v = ssym[u] <= kAcLo ? 0u : (ssym[u] > kAcLo + kAlphabet - 1 ? (1u << kRcPrecision) : v);
+                        // every stored bound must fit 24 bits (v_mad_u32_u24 in the decoder): the upper sentinel of a window
+                        // that reaches symbol 63 is clamped to 2^24 - 1; a hit on it only costs a detour through the slow path
+                        left[u] = (lane == 63) ? 0u : min(v, (1u << kRcPrecision) - 1u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t right = __shfl_up(left[u], 1);  // lane k-1 holds symbol s+1: its left bound is our right bound
+                        uint2 e;
+                        e.x = left[u];
+                        e.y = (lane == 0 || lane == 63) ? 0u
+                              : ((lane == 1 && ssym[u] == kAcLo + kAlphabet - 1) ? (1u << kRcPrecision) - left[u] : right - left[u]);
+                        if (g0 + u < cnt) tab[(g0 + u) * 64 + lane] = e;
+                    }
+                }
+                if (lane == 0) lds_store_release(&C.s_ready[slot * kHalves + half], seq + 1);
+                PROF_ADD(prof[3], t_t);
             }
-            PROF_ADD(prof[2], t_m);
-            const unsigned long long t_t = PROF_T();
-            // ---- window tables: one pass of the whole wave per pixel, lane = window slot --------------------
-            // lanes 1..62 = symbols top, top-1, ..., top-61; lane 0 / 63 = sentinels (P = 0)
-            uint2* tab = C.s_tab + static_cast<size_t>(slot) * kBatch * 64;
-#pragma unroll 2
-            for (int i = 0; i < cnt; ++i) {
-                const double mu = -64.0 + static_cast<double>(meta.mu_idx[i]) * (1.0 / 256.0);
-                const double b = meta.b[i], rcp = meta.rcp[i];
-                const int s = meta.top[i] - (lane - 1);  // lane 0 -> top + 1: its left bound is the window's upper edge
-                // every stored bound must fit 24 bits (v_mad_u32_u24 in the decoder): the upper sentinel of a window
-                // that reaches symbol 63 is clamped to 2^24 - 1; a hit on it only costs a detour through the slow path
-                const uint32_t left = (lane == 63) ? 0u : min(window_left(mu, b, rcp, s), (1u << kRcPrecision) - 1u);
-                const uint32_t right = __shfl_up(left, 1);  // lane k-1 holds symbol s+1: its left bound is our right bound
-                uint2 e;
-                e.x = left;
-                e.y = (lane == 0 || lane == 63) ? 0u : ((lane == 1 && s == kAcLo + kAlphabet - 1) ? (1u << kRcPrecision) - left : right - left);
-                tab[i * 64 + lane] = e;
-            }
-            if (lane == 0) lds_store_release(&C.s_ready[slot], seq + 1);
-            PROF_ADD(prof[3], t_t);
         }
         if (!ok) break;
         prev_first = seq - nb;
         prev_nb = nb;
+        prev_n = it.n;
     }
     return seq;
 }
@@ -518,7 +600,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     C.s_ring = reinterpret_cast<int8_t*>(C.s_act + kProducers * kBatch * in_pad);
     uint32_t* s_sync = reinterpret_cast<uint32_t*>(C.s_ring + kRingRows * 64);
     C.s_ready = s_sync;
-    C.s_consumed = s_sync + kSlots;
+    C.s_consumed = s_sync + kSlots * kHalves;
     C.s_abort = C.s_consumed + 1;
     C.dim = dim; C.n_layers = n_layers; C.n_sp = P.n_spatial; C.n_if = n_if;
 
@@ -544,7 +626,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         if (tid < 2) C.s_b[(n_layers - 1) * dim + 2 + tid] = src[dim * 2 + tid];
     }
     for (int i = tid; i < kProducers * kBatch * in_pad; i += kPipeThreads) C.s_act[i] = 0;
-    if (tid < kSlots) C.s_ready[tid] = 0;
+    if (tid < kSlots * kHalves) C.s_ready[tid] = 0;
     if (tid == 0) { *C.s_consumed = 0; *C.s_abort = 0; }
 
     DecState S;
@@ -635,7 +717,7 @@ size_t entropy_pipe_lds_bytes(int dim, int n_layers) {
     n += static_cast<size_t>((n_b_total + 1) & ~1) * 8;
     n += static_cast<size_t>(kProducers) * kBatch * in_pad * 4;
     n += static_cast<size_t>(kRingRows) * 64;
-    n += (kSlots + 8) * 4;
+    n += (kSlots * kHalves + 8) * 4;
     return (n + 15) & ~size_t{15};
 }
 
