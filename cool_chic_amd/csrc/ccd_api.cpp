@@ -24,6 +24,10 @@ hipError_t launch_upsample_level(const UpsampleLevel& L, hipStream_t stream);
 hipError_t launch_i8_to_f32(const int8_t* in, float* out, size_t n, hipStream_t stream);
 hipError_t launch_syn_layer(const float* in, const float* in2, const float* wt, const float* bias, float* out, int c_in,
                             int c_out, int k, int residual, int relu, int h, int w, hipStream_t stream);
+bool syn_fused_supports(int c_in, int c, int halo);
+void syn_fused_tiles(int h, int w, int halo, int* tiles_x, int* tiles_y);
+hipError_t launch_syn_fused(const SynthFused* d_frames, int n_frames, int c_in, int c, int max_tiles_x, int max_tiles_y,
+                            hipStream_t stream);
 hipError_t launch_resize_nearest(const float* in, float* out, int c, int h_in, int w_in, int h_out, int w_out,
                                  hipStream_t stream);
 hipError_t launch_planes(const float* src, void* p0, void* p1, void* p2, int h, int w, int bitdepth, int frame_data_type,
@@ -71,6 +75,8 @@ struct Slot {
     float* d_dense = nullptr;
     // synthesis
     float* d_syn_params = nullptr;
+    bool use_fused_syn = false;      // whole synthesis in one kernel (ccd_synth_fused.hip)
+    SynthFused fused;
     std::vector<size_t> w_off, b_off;  // per main layer
     size_t stab_w = 0, stab_b = 0, out_w = 0, out_b = 0;
     float* d_tmp[2] = {nullptr, nullptr};
@@ -97,7 +103,11 @@ struct ccd_batch {
     float* d_scale_table = nullptr;
     double* d_rcp_table = nullptr;
     size_t lds_generic = 0, lds_pipe = 0;
-    int force_generic = 0;               // CCD_FORCE_GENERIC_ENTROPY=1: tests exercise the fallback kernel
+    int force_generic = 0;               // CCD_FORCE_GENERIC=1: tests exercise the fallback kernels
+    // fused-synthesis launches: frames grouped by (padded input channels, output channels)
+    struct FusedGroup { int cp, c, c_in, n, first, max_tx, max_ty; };
+    std::vector<FusedGroup> fused_groups;
+    SynthFused* d_fused = nullptr;
 };
 
 extern "C" {
@@ -135,7 +145,7 @@ int ccd_batch_create(int device, ccd_batch** out) {
     ccd_batch* b = new (std::nothrow) ccd_batch();
     if (!b) return CCD_ERR_NOMEM;
     b->device = device;
-    if (const char* e = std::getenv("CCD_FORCE_GENERIC_ENTROPY")) b->force_generic = std::atoi(e);
+    if (const char* e = std::getenv("CCD_FORCE_GENERIC")) b->force_generic = std::atoi(e);
     if (hipMalloc(&b->d_scale_table, sizeof(kScaleBits)) != hipSuccess) { delete b; return CCD_ERR_NOMEM; }
     if (hipMemcpy(b->d_scale_table, kScaleBits, sizeof(kScaleBits), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(b->d_scale_table); delete b; return CCD_ERR_HIP;
@@ -161,6 +171,7 @@ void ccd_batch_destroy(ccd_batch* b) {
     (void)hipSetDevice(b->device);
     for (auto& s : b->slots) s->arena.release();
     if (b->d_params) (void)hipFree(b->d_params);
+    if (b->d_fused) (void)hipFree(b->d_fused);
     if (b->d_scale_table) (void)hipFree(b->d_scale_table);
     if (b->d_rcp_table) (void)hipFree(b->d_rcp_table);
     delete b;
@@ -261,6 +272,46 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     for (const SynLayerParams& L : net.syn) { s.w_off.push_back(push(L.w)); s.b_off.push_back(push(L.b)); max_c = std::max(max_c, L.c_out); }
     if (net.syn_stab.c_out) { s.stab_w = push(net.syn_stab.w); s.stab_b = push(net.syn_stab.b); }
     s.out_w = push(net.syn_out.w); s.out_b = push(net.syn_out.b);
+    // ---- fused-synthesis layout (zero-padded copies of the first two layers and the stabiliser) -------------
+    {
+        SynthFused& F = s.fused;
+        std::memset(&F, 0, sizeof(F));
+        const auto& L = net.syn;
+        bool ok = L.size() >= 2 && L.size() <= 5 && L[0].k == 1 && L[1].k == 1 && !L[0].residual && !L[1].residual &&
+                  L[1].c_out == h.out_channels && !b->force_generic;
+        int halo = 0;
+        for (size_t l = 2; ok && l < L.size(); ++l) {
+            ok = L[l].c_in == h.out_channels && L[l].c_out == h.out_channels && (L[l].k & 1) && L[l].k <= 7;
+            halo += (L[l].k - 1) / 2;
+        }
+        ok = ok && syn_fused_supports(n_levels, h.out_channels, halo) && (!net.syn_stab.c_out || net.syn_stab.c_in <= n_levels);
+        if (ok) {
+            const int cp = ((n_levels + 3) / 4) * 4, C = h.out_channels, N = L[0].c_out;
+            auto push_padded = [&](const std::vector<float>& w, int rows, int cols) {
+                const size_t off = syn_blob.size();
+                for (int r = 0; r < rows; ++r)
+                    for (int c = 0; c < cp; ++c) syn_blob.push_back(c < cols ? w[static_cast<size_t>(r) * cols + c] : 0.0f);
+                return static_cast<int32_t>(off);
+            };
+            F.c_in = n_levels; F.c = C; F.n_hidden = N; F.relu0 = L[0].relu; F.relu1 = L[1].relu;
+            F.w0_off = push_padded(L[0].w, N, n_levels); F.b0_off = static_cast<int32_t>(s.b_off[0]);
+            F.w1_off = static_cast<int32_t>(s.w_off[1]); F.b1_off = static_cast<int32_t>(s.b_off[1]);
+            F.n_conv = static_cast<int32_t>(L.size()) - 2;
+            for (int l = 0; l < F.n_conv; ++l) {
+                F.conv_k[l] = L[l + 2].k; F.conv_residual[l] = L[l + 2].residual; F.conv_relu[l] = L[l + 2].relu;
+                F.conv_w_off[l] = static_cast<int32_t>(s.w_off[l + 2]); F.conv_b_off[l] = static_cast<int32_t>(s.b_off[l + 2]);
+            }
+            F.has_stab = net.syn_stab.c_out ? 1 : 0;
+            if (F.has_stab) {
+                F.stab_c_in = net.syn_stab.c_in;
+                F.stab_w_off = push_padded(net.syn_stab.w, C, net.syn_stab.c_in);
+                F.stab_b_off = static_cast<int32_t>(s.stab_b);
+            }
+            F.out_w_off = static_cast<int32_t>(s.out_w); F.out_b_off = static_cast<int32_t>(s.out_b);
+            F.halo = halo;
+            s.use_fused_syn = true;
+        }
+    }
     const size_t o_synp = A.reserve(syn_blob.size() * 4);
     const size_t plane_px = static_cast<size_t>(s.dense_h) * s.dense_w;
     const size_t o_tmp0 = A.reserve(plane_px * max_c * 4);
@@ -347,6 +398,15 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     s.d_syn_out = A.at<float>(o_synout);
     s.d_out = A.at<float>(o_out);
     for (int p = 0; p < 3; ++p) s.d_plane[p] = bitdepth ? A.at<void>(o_plane[p]) : nullptr;
+    if (s.use_fused_syn) {
+        SynthFused& F = s.fused;
+        F.dense = s.d_dense; F.params = s.d_syn_params; F.h = s.dense_h; F.w = s.dense_w;
+        F.bitdepth = bitdepth ? bitdepth : 8;
+        // integer samples straight from the synthesis kernel for RGB / 4:4:4 frames at full resolution
+        F.write_planes = (bitdepth != 0 && frame_data_type != 1 && !need_resize) ? 1 : 0;
+        F.out = s.d_syn_out;
+        for (int p = 0; p < 3; ++p) F.plane[p] = s.d_plane[p];
+    }
 
     if (s.use_pipe) b->lds_pipe = std::max(b->lds_pipe, s.lds_pipe);
     else b->lds_generic = std::max(b->lds_generic, s.lds_generic);
@@ -365,6 +425,34 @@ static int upload_params(ccd_batch* b) {
     b->n_generic = n - b->n_pipe;
     if (hipMalloc(&b->d_params, sizeof(EntropyParams) * std::max(n, 1)) != hipSuccess) return CCD_ERR_NOMEM;
     if (n && hipMemcpy(b->d_params, host.data(), sizeof(EntropyParams) * n, hipMemcpyHostToDevice) != hipSuccess) return CCD_ERR_HIP;
+    // fused synthesis: one launch per (CP, C) group over all of its frames
+    if (b->d_fused) { (void)hipFree(b->d_fused); b->d_fused = nullptr; }
+    b->fused_groups.clear();
+    std::vector<SynthFused> fused;
+    for (int i = 0; i < n; ++i) {
+        const Slot& s = *b->slots[i];
+        if (!s.use_fused_syn) continue;
+        const int cp = (s.fused.c_in + 3) / 4;
+        bool placed = false;
+        for (auto& g : b->fused_groups) placed = placed || (g.cp == cp && g.c == s.fused.c);
+        if (!placed) b->fused_groups.push_back({cp, s.fused.c, s.fused.c_in, 0, 0, 0, 0});
+    }
+    for (auto& g : b->fused_groups) {
+        g.first = static_cast<int>(fused.size());
+        for (int i = 0; i < n; ++i) {
+            const Slot& s = *b->slots[i];
+            if (!s.use_fused_syn || (s.fused.c_in + 3) / 4 != g.cp || s.fused.c != g.c) continue;
+            int tx = 0, ty = 0;
+            syn_fused_tiles(s.fused.h, s.fused.w, s.fused.halo, &tx, &ty);
+            g.max_tx = std::max(g.max_tx, tx); g.max_ty = std::max(g.max_ty, ty);
+            fused.push_back(s.fused);
+            ++g.n;
+        }
+    }
+    if (!fused.empty()) {
+        if (hipMalloc(&b->d_fused, sizeof(SynthFused) * fused.size()) != hipSuccess) return CCD_ERR_NOMEM;
+        if (hipMemcpy(b->d_fused, fused.data(), sizeof(SynthFused) * fused.size(), hipMemcpyHostToDevice) != hipSuccess) return CCD_ERR_HIP;
+    }
     b->n_params_uploaded = n;
     return CCD_OK;
 }
@@ -382,6 +470,13 @@ static int run_upsampling(Slot& s, hipStream_t st) {
 static int run_synthesis(Slot& s, hipStream_t st) {
     const Network& net = s.net;
     const int h = s.dense_h, w = s.dense_w;
+    if (s.use_fused_syn) {  // the fused kernel itself was launched for the whole group (ccd_batch_run_stage)
+        const int H = s.hdr.img_size[0], W = s.hdr.img_size[1];
+        if (s.d_out != s.d_syn_out) HIP_TRY(launch_resize_nearest(s.d_syn_out, s.d_out, s.hdr.out_channels, h, w, H, W, st));
+        if (s.bitdepth && !s.fused.write_planes)
+            HIP_TRY(launch_planes(s.d_out, s.d_plane[0], s.d_plane[1], s.d_plane[2], H, W, s.bitdepth, s.frame_data_type, st));
+        return CCD_OK;
+    }
     const float* x = s.d_dense;
     int cur = 0;
     for (size_t l = 0; l < net.syn.size(); ++l) {
@@ -418,6 +513,9 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
         HIP_TRY(launch_entropy(b->d_params + b->n_pipe, b->n_generic, b->lds_generic, st));
         return CCD_OK;
     }
+    if (stage == 2)
+        for (const auto& g : b->fused_groups)
+            HIP_TRY(launch_syn_fused(b->d_fused + g.first, g.n, g.c_in, g.c, g.max_tx, g.max_ty, st));
     for (auto& sp : b->slots) {
         rc = (stage == 1) ? run_upsampling(*sp, st) : (stage == 2 ? run_synthesis(*sp, st) : CCD_ERR_ARG);
         if (rc < 0) return rc;

@@ -48,27 +48,23 @@ struct UpsampleLevel {
     float ups_w[16], pre_w[16];
 };
 
-constexpr int kMaxSynWeights = 8192;  // floats of synthesis parameters kept in LDS
-
-struct SynthLayerDesc {
-    int32_t c_in, c_out, k, residual, relu;
-    int32_t w_off, b_off;    // offsets in the parameter blob (floats)
-};
-
-struct SynthParams {
+// Fused synthesis (ccd_synth_fused.hip): [N-1x1] [C-1x1] then up to 3 k x k layers on C channels,
+// stabiliser and output transform.  All offsets index the float blob `params`.
+struct SynthFused {
     const float* dense;      // [c_in][h][w]
-    float* out;              // [c_out][h][w] synthesis output (f32), may be null
-    void* plane[3];          // integer planes (u8 / u16), may be null
-    int32_t h, w, c_in, c_out;
-    int32_t n_layers;
-    SynthLayerDesc layer[CCD_MAX_SYN_LAYERS];
-    SynthLayerDesc stab;     // c_out == 0 when absent
-    SynthLayerDesc out_tf;   // output transform
-    const float* params;     // blob
-    int32_t n_params;
-    int32_t bitdepth;        // 0 = no integer planes
-    int32_t frame_data_type; // 0 rgb 1 yuv420 2 yuv444
-    int32_t halo;            // sum of (k-1)/2 over the main branch
+    float* out;              // [c][h][w] synthesis output (f32) or null
+    void* plane[3];          // integer planes (u8 / u16), used when write_planes
+    const float* params;
+    int32_t h, w, c_in, c, n_hidden;
+    int32_t relu0, relu1;
+    int32_t w0_off, b0_off;  // [n_hidden][CP], [n_hidden]   (CP = c_in rounded up to 4, zero padded)
+    int32_t w1_off, b1_off;  // [c][n_hidden], [c]
+    int32_t n_conv;
+    int32_t conv_k[3], conv_residual[3], conv_relu[3], conv_w_off[3], conv_b_off[3];
+    int32_t has_stab, stab_c_in, stab_w_off, stab_b_off;  // [c][CP] zero padded, [c]
+    int32_t out_w_off, out_b_off;                         // [c][c], [c]
+    int32_t halo;            // sum of the conv radii
+    int32_t bitdepth, write_planes;
 };
 
 }  // namespace ccd
