@@ -66,6 +66,25 @@ def test_stream_parity(gpu, oracle, name):
         b.close()
 
 
+@pytest.mark.parametrize("name", ["rgb192", "yuv420_10b"])
+def test_generic_fallback_kernels(gpu, oracle, name, monkeypatch):
+    """The barrier-phased int64 entropy kernel and the per-layer synthesis kernels (used for networks
+    outside the fast paths' envelope) give the same bits as the production kernels."""
+    monkeypatch.setenv("CCD_FORCE_GENERIC", "1")
+    bs, z, j = load_golden(name)
+    fh, ccs = oracle.split_stream(bs)[1][0]
+    ref = oracle.decode_coolchic(*ccs[0])
+    b = _decode(gpu, ccs[:1], fh.bitdepth, fh.frame_data_type)
+    try:
+        for g in range(ref["n_grids"]):
+            assert np.array_equal(b.latent(0, g), ref["latent"][g])
+        assert np.array_equal(b.output(0).view(np.uint32), ref["out"].view(np.uint32))
+        for p, w in zip(b.planes(0), oracle.decode_video(bs)[0]["planes"]):
+            assert np.array_equal(p.astype(np.uint16), w)
+    finally:
+        b.close()
+
+
 def test_many_streams_in_one_batch(gpu, oracle):
     """Several different architectures / sizes in flight together decode like they do alone."""
     triples, refs, meta = [], [], []
