@@ -89,7 +89,7 @@ struct Slot {
     bool use_pipe = false;   // pipelined entropy kernel (32-bit operands) or the generic one
     size_t lds_generic = 0, lds_pipe = 0;
     int status = CCD_OK;
-    int32_t host_status[32] = {0};
+    int32_t host_status[64] = {0};
 };
 
 }  // namespace
@@ -255,7 +255,7 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
         }
     }
     const size_t o_feat = A.reserve(feat_px * std::max(h.output_feature_ifce, 1) * 4);
-    const size_t o_status = A.reserve(256);
+    const size_t o_status = A.reserve(512);
     const size_t dense_elems = static_cast<size_t>(n_levels) * s.dense_h * s.dense_w;
     const size_t o_stack_a = A.reserve(dense_elems * 4);
     size_t stack_b_elems = 1;
@@ -549,9 +549,9 @@ int ccd_batch_slot_status(const ccd_batch* b, int slot) {
     return b->slots[slot]->status;
 }
 
-int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out32) {
-    if (!b || !out32 || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
-    std::memcpy(out32, b->slots[slot]->host_status, sizeof(b->slots[slot]->host_status));
+int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64) {
+    if (!b || !out64 || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
+    std::memcpy(out64, b->slots[slot]->host_status, sizeof(b->slots[slot]->host_status));
     return CCD_OK;
 }
 

@@ -37,12 +37,15 @@ constexpr int kPipeThreads = 512;           // 8 waves: 1 decoder + 7 producers
 constexpr int kPipeWaves = kPipeThreads / 64;
 constexpr int kProducers = kPipeWaves - 1;
 constexpr int kBatch = 16;                  // pixels per decoder batch (one slot)
-constexpr int kLpp = 8;                     // producer: lanes per pixel in the MLP
-constexpr int kTaskPix = 64 / kLpp;         // producer task = half a batch (8 pixels)
-constexpr int kHalves = kBatch / kTaskPix;
-constexpr int kSlots = 10;                  // ring of batch slots
+// Producer task = a part of a batch: 8 pixels x 8 lanes on wide wavefronts, 4 pixels x 16 lanes on short ones
+// (small grids are bound by the producers' latency, not their throughput).
+constexpr int kMaxParts = 4;
+constexpr int kSlots = 8;                   // ring of batch slots (power of two: cheap modulo on the decoder's path)
 constexpr int kMaxNV = 8;                   // MLP width <= 32 (in 4-wide vectors)
 constexpr int kRingRows = 512;              // rows of the decoded-symbol ring (>= live rows + 4; 4K: 384 + 4)
+// Scale index up to which a 14-symbol window [round(mu) - 7, round(mu) + 6] is used (b <= 1: 99.3 % of the symbols of
+// a real stream, window misses ~3e-4): four pixels' windows are then built by ONE pass of the wave.
+constexpr int kNarrowMaxScale = kScaleOffset;
 constexpr unsigned kSpinLimit = 1u << 27;   // bounded spins: a lost hand-over becomes an error, not a hang
 
 // exp(x) for x <= 0 in f64: range reduction by ln 2 (two-part constant) + degree-13 Taylor/Horner.
@@ -95,6 +98,7 @@ struct alignas(16) BatchMeta {
     double rcp[kBatch];     // RN(1 / b)
     int32_t mu_idx[kBatch];
     int32_t top[kBatch];    // symbol of window lane 1
+    int32_t sc_idx[kBatch]; // scale index (narrow windows when <= kNarrowMaxScale)
 };
 
 struct PipeCtx {
@@ -105,12 +109,13 @@ struct PipeCtx {
     int64_t* s_b;          // biases: hidden layers, output (2), stabiliser (2)
     int32_t* s_act;        // [kProducers][kBatch][in_pad]
     int8_t* s_ring;        // [kRingRows][64]
-    uint32_t* s_ready;     // [kSlots][kHalves]
+    uint32_t* s_ready;     // [kSlots][kMaxParts]
     uint32_t* s_consumed;
     uint32_t* s_abort;
     int dim, n_layers, n_sp, n_if, n_w_hidden;
     // per grid
     int H, W, fin, fh, fw;
+    int task_pix;          // pixels per producer task in this grid (8 or 4)
     int8_t* lat;
     uint32_t seq_base;
 };
@@ -120,6 +125,7 @@ struct DecState {
     uint32_t word_pos, wbase, wbuf;
     uint64_t n_decoded;
     unsigned long long prof_wait, prof_work;
+    unsigned long long wait_by_j[6];  // grid 0, steps with n >= 64: decoder wait per batch position
 };
 
 __device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v) {
@@ -191,6 +197,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     uint64_t rc_dist = uni(S.dist), rc_range = uni(S.range);
     uint32_t word_pos = uni(S.word_pos), wbase = uni(S.wbase), wbuf = S.wbuf;
     const uint32_t n_words = uni(P.n_words);
+    const int task_pix = uni(C.task_pix);
     bool ok = true;
     while (ok && it.next()) {
         for (int i0 = 0; i0 < it.n; i0 += kBatch, ++seq) {
@@ -198,9 +205,24 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
             const int slot = uni(static_cast<int>(seq % kSlots));
             {
                 const unsigned long long t0 = PROF_T();
-                if (!wait_ge(&C.s_ready[slot * kHalves], seq + 1, C.s_abort)) { ok = false; break; }
-                if (cnt > kTaskPix && !wait_ge(&C.s_ready[slot * kHalves + 1], seq + 1, C.s_abort)) { ok = false; break; }
+                {   // all part flags of the slot with one 16-byte LDS read; fall back to per-flag spinning if any lags
+                    const int n_parts = (cnt + task_pix - 1) / task_pix;
+                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                    asm volatile("" ::: "memory");  // re-read the flags every time
+                    const u32x4 f = *reinterpret_cast<const u32x4*>(&C.s_ready[slot * kMaxParts]);
+                    const uint32_t want = seq + 1;
+                    bool ready = uni(f.x) == want && (n_parts < 2 || uni(f.y) == want) && (n_parts < 3 || uni(f.z) == want) &&
+                                 (n_parts < 4 || uni(f.w) == want);
+                    if (!ready)
+                        for (int part = 0; part < n_parts && ok; ++part)
+                            if (!wait_ge(&C.s_ready[slot * kMaxParts + part], want, C.s_abort)) ok = false;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                if (!ok) break;
                 PROF_ADD(S.prof_wait, t0);
+#ifdef CCD_PIPE_PROFILE
+                if (C.W == 768 && it.n >= 64) S.wait_by_j[min(i0 / kBatch, 5)] += __builtin_amdgcn_s_memtime() - t0;
+#endif
             }
             const unsigned long long t_dec = PROF_T();
             const uint2* tab = C.s_tab + static_cast<size_t>(slot) * kBatch * 64 + lane;
@@ -337,7 +359,6 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 C.s_ring[(y & (kRingRows - 1)) * 64 + ((x + 10 * y) & 63)] = static_cast<int8_t>(sym);
                 C.lat[y * C.W + x] = static_cast<int8_t>(sym);
             }
-            S.n_decoded += cnt;
             lds_store_ordered(C.s_consumed, seq + 1);
             PROF_ADD(S.prof_work, t_dec);
         }
@@ -354,9 +375,11 @@ __device__ __forceinline__ int64_t dot4(int4 x, int4 w) {
            static_cast<int64_t>(x.w) * w.w;
 }
 
-template <int NV>
+template <int NV, int kLpp>
 __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned long long* prof) {
     constexpr int in_pad = 4 * NV;
+    constexpr int kTaskPix = 64 / kLpp;
+    constexpr int kHalves = kBatch / kTaskPix;
     constexpr int NOUT = (in_pad + kLpp - 1) / kLpp;  // outputs per lane in a hidden layer
     const int lane = threadIdx.x & 63;
     const int pw = (threadIdx.x >> 6) - 1;
@@ -465,92 +488,85 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     const int32_t idx = static_cast<int32_t>(off < 0 ? 0 : (off > hi ? hi : off));
                     if (px < cnt) {
                         if (q == 0) {
-                            int top = ((idx + 128) >> 8) - 64 + 30;  // round(mu) + 30: window = [round(mu) - 31, round(mu) + 30]
-                            top = max(kAcLo + 61, min(kAcLo + kAlphabet - 1, top));
                             meta.mu_idx[mpx] = idx;
-                            meta.top[mpx] = top;
                         } else {
                             meta.b[mpx] = static_cast<double>(P.scale_table[idx]);
                             meta.rcp[mpx] = P.rcp_table[idx];
+                            meta.sc_idx[mpx] = idx;
                         }
                     }
                 }
                 PROF_ADD(prof[2], t_m);
                 const unsigned long long t_t = PROF_T();
-                // ---- window tables: one pass of the whole wave per pixel, lane = window slot; passes are issued four at
-                // a time so that their (long, dependent) f64 chains overlap.
-                // lanes 1..62 = symbols top, top-1, ..., top-61; lane 0 / 63 = sentinels (P = 0)
+                // ---- window tables (lanes hold symbols in DESCENDING order; entry 0 = upper sentinel, trailing entries =
+                // lower sentinels, both with P = 0).  Narrow pixels (small scale): 14 real symbols, four pixels per pass.
+                // Wide pixels: 62 real symbols, one pixel per pass.
                 uint2* tab = C.s_tab + (static_cast<size_t>(slot) * kBatch + half * kTaskPix) * 64;
-                for (int g0 = 0; g0 < cnt; g0 += 4) {
-                    // Four passes in lock-step, written structure-of-arrays so that the four dependent f64 chains sit
-                    // in one basic block and interleave (no branches: out-of-range lanes are fixed up by selects).
-                    double mu4[4], b4[4], r4[4], a4[4], kq[4], rr[4], r2[4], pe[4], po[4], ex[4];
-                    int ssym[4];
-                    bool below[4], tiny[4];
+                const int base = half * kTaskPix;
+                unsigned narrow_mask = 0;  // bit i: pixel i of the task is narrow (wave-uniform)
+                for (int i = 0; i < cnt; ++i) narrow_mask |= (uni(meta.sc_idx[base + i]) <= kNarrowMaxScale ? 1u : 0u) << i;
+                unsigned rest = narrow_mask;
+                while (rest) {
+                    // up to four narrow pixels: sub-wave u = lane >> 4 handles pixel pix[u], entry e = lane & 15
+                    int pix[4];
+                    int n_here = 0;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const int i = min(g0 + u, cnt - 1) + half * kTaskPix;
-                        mu4[u] = -64.0 + static_cast<double>(meta.mu_idx[i]) * (1.0 / 256.0);
-                        b4[u] = meta.b[i];
-                        r4[u] = meta.rcp[i];
-                        ssym[u] = meta.top[i] - (lane - 1);  // lane 0 -> top + 1: its left bound is the window's upper edge
+                        pix[u] = rest ? __builtin_ctz(rest) : -1;
+                        if (rest) { rest &= rest - 1; ++n_here; }
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const double x = static_cast<double>(ssym[u]) - 0.5;
-                        below[u] = x <= mu4[u];
-                        a4[u] = below[u] ? (x - mu4[u]) : (mu4[u] - x);
+                    const int u = lane >> 4, e = lane & 15;
+                    const int mine = u == 0 ? pix[0] : (u == 1 ? pix[1] : (u == 2 ? pix[2] : pix[3]));
+                    const int mi = base + (mine < 0 ? pix[0] : mine);
+                    const int mu_idx = meta.mu_idx[mi];
+                    int top = ((mu_idx + 128) >> 8) - 64 + 6;  // round(mu) + 6: window = [round(mu) - 7, round(mu) + 6]
+                    top = max(kAcLo + 13, min(kAcLo + kAlphabet - 1, top));
+                    const double mu = -64.0 + static_cast<double>(mu_idx) * (1.0 / 256.0);
+                    const int ssym = top - (e - 1);  // e = 0 -> top + 1: its left bound is the window's upper edge
+                    uint32_t left = min(window_left(mu, meta.b[mi], meta.rcp[mi], ssym), (1u << kRcPrecision) - 1u);
+                    left = e == 15 ? 0u : left;
+                    const uint32_t right = __shfl_up(left, 1);
+                    uint2 ent;
+                    ent.x = left;
+                    ent.y = (e == 0 || e == 15) ? 0u : ((e == 1 && ssym == kAcLo + kAlphabet - 1) ? (1u << kRcPrecision) - left : right - left);
+                    if (mine >= 0) {
+                        tab[mine * 64 + e] = ent;
+                        if (e == 0) meta.top[mi] = top;
                     }
+                    // entries 16..63 of the (up to) four rows: lower sentinels
+                    const uint2 zero = make_uint2(0u, 0u);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) kq[u] = a4[u] * r4[u];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) kq[u] = fma(fma(-kq[u], b4[u], a4[u]), r4[u], kq[u]);  // correctly rounded a / b
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { tiny[u] = kq[u] < -60.0; a4[u] = tiny[u] ? -60.0 : kq[u]; }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) kq[u] = rint(a4[u] * 1.44269504088896338700e+00);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) rr[u] = fma(kq[u], -1.90821492927058770002e-10, fma(kq[u], -6.93147180369123816490e-01, a4[u]));
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { r2[u] = rr[u] * rr[u]; pe[u] = 1.1470745597729725e-11; po[u] = 1.6059043836821613e-10; }
-#define CCD_POLY_STEP(ce, co)                                               \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                          \
-        pe[u] = fma(pe[u], r2[u], ce);                                       \
-        po[u] = fma(po[u], r2[u], co);                                       \
-    }
-                    CCD_POLY_STEP(2.08767569878681e-09, 2.505210838544172e-08)
-                    CCD_POLY_STEP(2.755731922398589e-07, 2.7557319223985893e-06)
-                    CCD_POLY_STEP(2.48015873015873e-05, 1.984126984126984e-04)
-                    CCD_POLY_STEP(1.388888888888889e-03, 8.333333333333333e-03)
-                    CCD_POLY_STEP(4.1666666666666664e-02, 1.6666666666666666e-01)
-                    CCD_POLY_STEP(0.5, 1.0)
-#undef CCD_POLY_STEP
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) pe[u] = fma(pe[u], r2[u], 1.0);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) ex[u] = 0.5 * ldexp(fma(po[u], rr[u], pe[u]), static_cast<int>(kq[u]));
-                    uint32_t left[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const double e = tiny[u] ? 0.0 : ex[u];
-                        const double cdf = below[u] ? e : 1.0 - e;
-                        uint32_t v = static_cast<uint32_t>(16777088.0 * cdf) + static_cast<uint32_t>(ssym[u] - kAcLo);
-                        v = ssym[u] <= kAcLo ? 0u : (ssym[u] > kAcLo + kAlphabet - 1 ? (1u << kRcPrecision) : v);
-                        // every stored bound must fit 24 bits (v_mad_u32_u24 in the decoder): the upper sentinel of a window
-                        // that reaches symbol 63 is clamped to 2^24 - 1; a hit on it only costs a detour through the slow path
-                        left[u] = (lane == 63) ? 0u : min(v, (1u << kRcPrecision) - 1u);
+                    for (int j = 0; j < 3; ++j) {
+                        const int t = lane + 64 * j;  // 0..191 = 4 rows x 48 entries
+                        const int ru = t / 48;
+                        const int rp = ru == 0 ? pix[0] : (ru == 1 ? pix[1] : (ru == 2 ? pix[2] : pix[3]));
+                        if (rp >= 0) tab[rp * 64 + 16 + t % 48] = zero;
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const uint32_t right = __shfl_up(left[u], 1);  // lane k-1 holds symbol s+1: its left bound is our right bound
-                        uint2 e;
-                        e.x = left[u];
-                        e.y = (lane == 0 || lane == 63) ? 0u
-                              : ((lane == 1 && ssym[u] == kAcLo + kAlphabet - 1) ? (1u << kRcPrecision) - left[u] : right - left[u]);
-                        if (g0 + u < cnt) tab[(g0 + u) * 64 + lane] = e;
-                    }
+                    (void)n_here;
                 }
-                if (lane == 0) lds_store_release(&C.s_ready[slot * kHalves + half], seq + 1);
+                unsigned wide = ((1u << cnt) - 1u) & ~narrow_mask;
+                while (wide) {
+                    const int i = __builtin_ctz(wide);
+                    wide &= wide - 1;
+                    const int mi = base + i;
+                    const int mu_idx = meta.mu_idx[mi];
+                    int top = ((mu_idx + 128) >> 8) - 64 + 30;  // round(mu) + 30: window = [round(mu) - 31, round(mu) + 30]
+                    top = max(kAcLo + 61, min(kAcLo + kAlphabet - 1, top));
+                    const double mu = -64.0 + static_cast<double>(mu_idx) * (1.0 / 256.0);
+                    const int ssym = top - (lane - 1);
+                    // every stored bound must fit 24 bits (v_mad_u32_u24 in the decoder): the upper sentinel of a window that
+                    // reaches symbol 63 is clamped to 2^24 - 1; a hit on it only costs a detour through the slow path
+                    uint32_t left = min(window_left(mu, meta.b[mi], meta.rcp[mi], ssym), (1u << kRcPrecision) - 1u);
+                    left = lane == 63 ? 0u : left;
+                    const uint32_t right = __shfl_up(left, 1);  // lane k-1 holds symbol s+1: its left bound is our right bound
+                    uint2 ent;
+                    ent.x = left;
+                    ent.y = (lane == 0 || lane == 63) ? 0u
+                            : ((lane == 1 && ssym == kAcLo + kAlphabet - 1) ? (1u << kRcPrecision) - left : right - left);
+                    tab[i * 64 + lane] = ent;
+                    if (lane == 0) meta.top[mi] = top;
+                }
+                if (lane == 0) lds_store_release(&C.s_ready[slot * kMaxParts + half], seq + 1);
                 PROF_ADD(prof[3], t_t);
             }
         }
@@ -562,16 +578,17 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     return seq;
 }
 
+template <int kLpp>
 __device__ __forceinline__ uint32_t producer_dispatch(const PipeCtx& C, int nv, unsigned long long* prof) {
     switch (nv) {
-        case 1: return producer_grid<1>(C, prof);
-        case 2: return producer_grid<2>(C, prof);
-        case 3: return producer_grid<3>(C, prof);
-        case 4: return producer_grid<4>(C, prof);
-        case 5: return producer_grid<5>(C, prof);
-        case 6: return producer_grid<6>(C, prof);
-        case 7: return producer_grid<7>(C, prof);
-        default: return producer_grid<8>(C, prof);
+        case 1: return producer_grid<1, kLpp>(C, prof);
+        case 2: return producer_grid<2, kLpp>(C, prof);
+        case 3: return producer_grid<3, kLpp>(C, prof);
+        case 4: return producer_grid<4, kLpp>(C, prof);
+        case 5: return producer_grid<5, kLpp>(C, prof);
+        case 6: return producer_grid<6, kLpp>(C, prof);
+        case 7: return producer_grid<7, kLpp>(C, prof);
+        default: return producer_grid<8, kLpp>(C, prof);
     }
 }
 
@@ -600,7 +617,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     C.s_ring = reinterpret_cast<int8_t*>(C.s_act + kProducers * kBatch * in_pad);
     uint32_t* s_sync = reinterpret_cast<uint32_t*>(C.s_ring + kRingRows * 64);
     C.s_ready = s_sync;
-    C.s_consumed = s_sync + kSlots * kHalves;
+    C.s_consumed = s_sync + kSlots * kMaxParts;
     C.s_abort = C.s_consumed + 1;
     C.dim = dim; C.n_layers = n_layers; C.n_sp = P.n_spatial; C.n_if = n_if;
 
@@ -626,12 +643,13 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         if (tid < 2) C.s_b[(n_layers - 1) * dim + 2 + tid] = src[dim * 2 + tid];
     }
     for (int i = tid; i < kProducers * kBatch * in_pad; i += kPipeThreads) C.s_act[i] = 0;
-    if (tid < kSlots * kHalves) C.s_ready[tid] = 0;
+    if (tid < kSlots * kMaxParts) C.s_ready[tid] = 0;
     if (tid == 0) { *C.s_consumed = 0; *C.s_abort = 0; }
 
     DecState S;
     S.range = ~uint64_t{0}; S.dist = 0; S.word_pos = 2; S.wbase = 2; S.wbuf = 0; S.n_decoded = 0;
     S.prof_wait = 0; S.prof_work = 0;
+    for (int i = 0; i < 6; ++i) S.wait_by_j[i] = 0;
     if (wave == 0) {
         // loads through pointers stored in the parameter block are FLAT loads, which the compiler treats as
         // divergent; readfirstlane keeps the coder state (and all control flow depending on it) scalar
@@ -645,46 +663,92 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     C.seq_base = 0;
     __syncthreads();
 
+    unsigned long long prof_ifce = 0, prof_bar = 0;
     for (int g = P.n_grids - 1; g >= 0; --g) {
+        const unsigned long long t_if = PROF_T();
         C.H = P.grid_h[g]; C.W = P.grid_w[g];
         C.lat = P.latent[g];
         C.fin = P.ifce_in[g];
         C.fh = (g == P.n_grids - 1) ? C.H : P.grid_h[g + 1];
         C.fw = (g == P.n_grids - 1) ? C.W : P.grid_w[g + 1];
+        {   // widest wavefront step of the grid decides the task shape
+            const int n_max = C.W <= 9 ? 1 : min(C.H, (C.W - 1) / 10 + 1);
+            C.task_pix = n_max >= 48 ? 8 : 4;
+        }
         // ---- IFCE features at the previously decoded grid's size (coolchic.py:94-146) -------------
+        // Per-channel source descriptors and the (tiny) linear layer are staged in LDS first: read through the
+        // parameter block inside the loops they would cost a dependent HBM round trip per multiply.
         if (C.fin > 0) {
             const int fin = C.fin, fh = C.fh, fw = C.fw;
-            const int64_t* fw_ = P.ifce + P.ifce_off[g];
-            const int64_t* fb_ = fw_ + fin * n_if;
-            const int base_level = (g == P.n_grids - 1) ? 0 : P.level[g + 1];
+            int64_t* s_fw = reinterpret_cast<int64_t*>(C.s_tab);                 // [fin][n_if] then bias [n_if] (tables are idle here)
+            const int8_t** s_src = reinterpret_cast<const int8_t**>(s_fw + fin * n_if + n_if);  // [fin]
+            int32_t* s_gw = reinterpret_cast<int32_t*>(s_src + fin);            // [fin]
+            int32_t* s_sh = s_gw + fin;                                          // [fin]
+            {
+                const int64_t* src = P.ifce + P.ifce_off[g];
+                for (int i = tid; i < fin * n_if + n_if; i += kPipeThreads) s_fw[i] = src[i];
+                const int base_level = (g == P.n_grids - 1) ? 0 : P.level[g + 1];
+                for (int c = tid; c < fin; c += kPipeThreads) {
+                    const int m = (g == P.n_grids - 1) ? g : g + 1 + c;
+                    s_src[c] = P.latent[m];
+                    s_gw[c] = P.grid_w[m];
+                    s_sh[c] = (g == P.n_grids - 1) ? 0 : P.level[m] - base_level;
+                }
+            }
+            __syncthreads();
+            const bool zero_input = g == P.n_grids - 1;  // first grid: the stack is one all-zero channel (coolchic.py:95-96)
+            int32_t* feat = P.ifce_feat;
             for (int p = tid; p < fh * fw; p += kPipeThreads) {
                 const int y = p / fw, x = p - y * fw;
-                for (int o = 0; o < n_if; ++o) {
-                    uint64_t acc = static_cast<uint64_t>(fb_[o]);
-                    if (g != P.n_grids - 1) {
+                for (int o0 = 0; o0 < n_if; o0 += 8) {
+                    uint64_t acc[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = o0 + j < n_if ? static_cast<uint64_t>(s_fw[fin * n_if + o0 + j]) : 0;
+                    if (!zero_input) {
                         for (int c = 0; c < fin; ++c) {
-                            const int m = g + 1 + c;
-                            const int sh = P.level[m] - base_level;
-                            const int64_t v = P.latent[m][(y >> sh) * P.grid_w[m] + (x >> sh)];
-                            acc += static_cast<uint64_t>(v << 16) * static_cast<uint64_t>(fw_[c * n_if + o]);
+                            const int sh = s_sh[c];
+                            const uint64_t v = static_cast<uint64_t>(static_cast<int64_t>(s_src[c][(y >> sh) * s_gw[c] + (x >> sh)]) << 16);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j)
+                                if (o0 + j < n_if) acc[j] += v * static_cast<uint64_t>(s_fw[c * n_if + o0 + j]);
                         }
                     }
-                    const int64_t q8 = static_cast<int64_t>(acc) >> 24;
-                    P.ifce_feat[o * fh * fw + p] = static_cast<int32_t>(static_cast<int64_t>(static_cast<float>(q8)));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (o0 + j < n_if) {
+                            const int64_t q8 = static_cast<int64_t>(acc[j]) >> 24;
+                            // .to(torch.float) / back to int64 round trip around F.interpolate (coolchic.py:142-144)
+                            feat[(o0 + j) * fh * fw + p] = static_cast<int32_t>(static_cast<int64_t>(static_cast<float>(q8)));
+                        }
+                    }
                 }
             }
         }
         __syncthreads();  // features visible; every wave finished the previous grid
+        PROF_ADD(prof_ifce, t_if);
 
         uint32_t seq_end;
         if (wave == 0) {
             __builtin_amdgcn_s_setprio(3);
+#ifdef CCD_PIPE_PROFILE
+            const unsigned long long w0 = S.prof_wait, k0 = S.prof_work;
+#endif
             seq_end = decoder_grid(C, S);
             __builtin_amdgcn_s_setprio(0);
+#ifdef CCD_PIPE_PROFILE
+            if (lane == 0 && g == 0)
+                for (int i = 0; i < 6; ++i) P.status[32 + i] = static_cast<int32_t>(S.wait_by_j[i] >> 10);
+            if (lane == 0 && g < 4) {  // per-grid decoder counters for the four finest grids: status[24 + 2 g ..]
+                P.status[24 + 2 * g] = static_cast<int32_t>((S.prof_wait - w0) >> 10);
+                P.status[25 + 2 * g] = static_cast<int32_t>((S.prof_work - k0) >> 10);
+            }
+#endif
         } else {
-            seq_end = producer_dispatch(C, in_pad / 4, prof);
+            seq_end = C.task_pix == 8 ? producer_dispatch<8>(C, in_pad / 4, prof) : producer_dispatch<16>(C, in_pad / 4, prof);
         }
+        const unsigned long long t_b = PROF_T();
         __syncthreads();  // also makes the decoder's global writes of this grid visible to every wave
+        PROF_ADD(prof_bar, t_b);
         if (lds_load_acquire(C.s_abort) != 0) break;
         C.seq_base = seq_end;  // every wave walked the same batches
     }
@@ -692,18 +756,23 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         const uint32_t ab = *C.s_abort;
         P.status[0] = ab ? -static_cast<int32_t>(ab) : 0;
         P.status[1] = static_cast<int32_t>(S.word_pos);
-        P.status[2] = static_cast<int32_t>(S.n_decoded & 0xffffffffu);
-        P.status[3] = static_cast<int32_t>(S.n_decoded >> 32);
+        {   // symbols decoded = all grids unless aborted
+            uint64_t n_sym = 0;
+            for (int g2 = 0; g2 < P.n_grids; ++g2) n_sym += static_cast<uint64_t>(P.grid_h[g2]) * P.grid_w[g2];
+            if (ab) n_sym = 0;
+            P.status[2] = static_cast<int32_t>(n_sym & 0xffffffffu);
+            P.status[3] = static_cast<int32_t>(n_sym >> 32);
+        }
     }
 #ifdef CCD_PIPE_PROFILE
     if (lane == 0 && wave < 2) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(P.status + 4) + wave * 5;
         o[0] = __builtin_amdgcn_s_memtime() - prof_total0;
-        if (wave == 0) { o[1] = S.prof_wait; o[2] = S.prof_work; o[3] = 0; o[4] = 0; }
+        if (wave == 0) { o[1] = S.prof_wait; o[2] = S.prof_work; o[3] = prof_ifce; o[4] = prof_bar; }
         else { o[1] = prof[0]; o[2] = prof[1]; o[3] = prof[2]; o[4] = prof[3]; }
     }
 #else
-    (void)prof_total0;
+    (void)prof_total0; (void)prof_ifce; (void)prof_bar;
 #endif
 }
 
@@ -717,7 +786,7 @@ size_t entropy_pipe_lds_bytes(int dim, int n_layers) {
     n += static_cast<size_t>((n_b_total + 1) & ~1) * 8;
     n += static_cast<size_t>(kProducers) * kBatch * in_pad * 4;
     n += static_cast<size_t>(kRingRows) * 64;
-    n += (kSlots * kHalves + 8) * 4;
+    n += (kSlots * kMaxParts + 8) * 4;
     return (n + 15) & ~size_t{15};
 }
 

@@ -132,8 +132,9 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage);
 int ccd_batch_wait(ccd_batch* b, void* stream);
 int ccd_batch_slot_status(const ccd_batch* b, int slot);
 /* Raw per-slot counters of the entropy kernel after ccd_batch_wait: [0] status, [1] payload words read,
- * [2..3] symbols decoded (lo, hi); [4..31] profiling cycle counters when built with -DCCD_PIPE_PROFILE. */
-int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out32);
+ * [2..3] symbols decoded (lo, hi); [4..63] profiling cycle counters when built with -DCCD_PIPE_PROFILE.
+ * `out64` receives 64 words. */
+int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64);
 
 /* Device pointers of a slot's results (valid until the batch is destroyed / re-run): */
 const float* ccd_batch_output(const ccd_batch* b, int slot);    /* [C][H][W] f32, synthesis output */

@@ -13,9 +13,18 @@ import time
 for rep in range(2):
     torch.cuda.synchronize(); t=time.time(); b.run(stage=0); b.wait(); dt=time.time()-t
 print('entropy stage wall ms', dt*1e3)
-st=np.zeros(32,np.int32); lib().ccd_batch_slot_stats(b._h,0,st.ctypes.data)
-u=st[4:].view(np.uint64)
+st=np.zeros(64,np.int32); lib().ccd_batch_slot_stats(b._h,0,st.ctypes.data)
+u=st[4:24].view(np.uint64)
 print('decoder : total %d wait %d decode %d'%(u[0],u[1],u[2]), ' per symbol decode cycles %.1f'%(u[2]/526272), 'wait frac %.2f'%(u[1]/u[0]))
+print('decoder outside grids: ifce+setup %d, end-of-grid barrier %d'%(u[3],u[4]))
 print('producer1: total %d wait %d gather %d mlp %d table %d'%(u[5],u[6],u[7],u[8],u[9]))
 nb=526272/16/7
 print(' per batch (approx %d batches): gather %.0f mlp %.0f table %.0f cycles'%(nb,u[7]/nb,u[8]/nb,u[9]/nb))
+
+hw=[(512,768),(256,384),(128,192),(64,96)]
+for g in range(4):
+    w,k=int(st[24+2*g])*1024,int(st[25+2*g])*1024
+    n=hw[g][0]*hw[g][1]
+    print(' grid %d (%dx%d): wait %.1fM work %.1fM cycles -> %.0f cycles/symbol total, wait share %.2f'%(g,hw[g][0],hw[g][1],w/1e6,k/1e6,(w+k)/n,w/(w+k+1)))
+
+print(' grid0 steady-state decoder wait by batch position j (Mcycles):', [round(int(x)*1024/1e6,2) for x in st[32:38]])

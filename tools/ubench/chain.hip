@@ -198,6 +198,257 @@ __global__ __launch_bounds__(64) void chain_d(const uint32_t* __restrict__ tbl, 
     if (lane == 0) { stats[0] = (uint64_t)total; stats[1] = wp; stats[2] = dist; }
 }
 
+// Variant E: the production hand-written loop (ccd_entropy_pipe.hip) on (L,P) pairs, batches of 16 symbols.
+__global__ __launch_bounds__(64) void chain_e(const uint32_t* __restrict__ tbl, const uint32_t* __restrict__ words, int n,
+                                             int8_t* out, uint64_t* stats) {
+    __shared__ uint2 s_lp[CH * 64];
+    __shared__ int8_t s_out[CH];
+    const int lane = threadIdx.x;
+    uint32_t wp = 2;
+    uint64_t rc_range = ~uint64_t{0};
+    uint64_t rc_dist = ((uint64_t)rfl(words[0]) << 32) | rfl(words[1]);
+    uint32_t wbuf = words[2 + lane];
+    uint32_t wbase = 2;
+    long long total = 0;
+    for (int c0 = 0; c0 < n; c0 += CH) {
+        for (int j = lane; j < CH * 64; j += 64) {
+            // descending order in lanes: lane k holds candidate 63 - k
+            const int sym = j / 64, k = j % 64, cand = 63 - k;
+            const uint32_t a = tbl[(size_t)(c0 + sym) * TBL + cand], b = tbl[(size_t)(c0 + sym) * TBL + cand + 1];
+            s_lp[j] = make_uint2(a, b - a);
+        }
+        __syncthreads();
+        long long t0 = clock64();
+        for (int b0 = 0; b0 < CH; b0 += 16) {
+            int raw = 0;
+            uint32_t i = 0;
+            const uint32_t cnt = 16;
+            const uint32_t tab_addr = (uint32_t)(uintptr_t)(s_lp + b0 * 64 + lane);
+            while (i < cnt) {
+                uint32_t status, k_rare;
+                uint32_t taddr = tab_addr + i * 512u;
+                asm volatile(
+                    "s_mov_b64 s[50:51], %[dst]\n\t"
+                    "s_mov_b64 s[52:53], %[rng]\n\t"
+                    "ds_read_b64 v[40:41], %[ta]\n\t"
+                    "1:\n\t"
+                    "ds_read_b64 v[42:43], %[ta] offset:512\n\t"
+                    "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                    "s_waitcnt lgkmcnt(1)\n\t"
+                    "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
+                    "v_mad_u32_u24 v45, v40, s41, v45\n\t"
+                    "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                    "s_ff1_i32_b64 s44, vcc\n\t"
+                    "v_readlane_b32 s45, v41, s44\n\t"
+                    "v_readlane_b32 s46, v44, s44\n\t"
+                    "v_readlane_b32 s47, v45, s44\n\t"
+                    "s_mul_i32 s48, s40, s45\n\t"
+                    "s_mul_hi_u32 s49, s40, s45\n\t"
+                    "s_mul_i32 s45, s41, s45\n\t"
+                    "s_add_u32 s49, s49, s45\n\t"
+                    "s_cmp_eq_u32 s49, 0\n\t"
+                    "s_cbranch_scc1 3f\n\t"
+                    "s_sub_u32 s50, s50, s46\n\t"
+                    "s_subb_u32 s51, s51, s47\n\t"
+                    "s_mov_b64 s[52:53], s[48:49]\n\t"
+                    "s_mov_b32 m0, %[i]\n\t"
+                    "v_writelane_b32 %[raw], s44, m0\n\t"
+                    "s_add_u32 %[i], %[i], 1\n\t"
+                    "s_cmp_lt_u32 %[i], %[cnt]\n\t"
+                    "s_cbranch_scc0 2f\n\t"
+                    "ds_read_b64 v[40:41], %[ta] offset:1024\n\t"
+                    "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                    "s_waitcnt lgkmcnt(1)\n\t"
+                    "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
+                    "v_mad_u32_u24 v45, v42, s41, v45\n\t"
+                    "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                    "s_ff1_i32_b64 s44, vcc\n\t"
+                    "v_readlane_b32 s45, v43, s44\n\t"
+                    "v_readlane_b32 s46, v44, s44\n\t"
+                    "v_readlane_b32 s47, v45, s44\n\t"
+                    "s_mul_i32 s48, s40, s45\n\t"
+                    "s_mul_hi_u32 s49, s40, s45\n\t"
+                    "s_mul_i32 s45, s41, s45\n\t"
+                    "s_add_u32 s49, s49, s45\n\t"
+                    "s_cmp_eq_u32 s49, 0\n\t"
+                    "s_cbranch_scc1 3f\n\t"
+                    "s_sub_u32 s50, s50, s46\n\t"
+                    "s_subb_u32 s51, s51, s47\n\t"
+                    "s_mov_b64 s[52:53], s[48:49]\n\t"
+                    "s_mov_b32 m0, %[i]\n\t"
+                    "v_writelane_b32 %[raw], s44, m0\n\t"
+                    "s_add_u32 %[i], %[i], 1\n\t"
+                    "v_add_u32 %[ta], 0x400, %[ta]\n\t"
+                    "s_cmp_lt_u32 %[i], %[cnt]\n\t"
+                    "s_cbranch_scc1 1b\n\t"
+                    "2:\n\t"
+                    "s_mov_b32 %[st], 0\n\t"
+                    "s_branch 4f\n\t"
+                    "3:\n\t"
+                    "s_mov_b32 %[st], 1\n\t"
+                    "4:\n\t"
+                    "s_mov_b32 %[kr], s44\n\t"
+                    "s_mov_b64 %[dst], s[50:51]\n\t"
+                    "s_mov_b64 %[rng], s[52:53]\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [i] "+s"(i), [raw] "+v"(raw), [ta] "+v"(taddr), [st] "=s"(status),
+                      [kr] "=s"(k_rare)
+                    : [cnt] "s"(cnt)
+                    : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
+                      "v40", "v41", "v42", "v43", "v44", "v45");
+                if (status == 0) break;
+                const uint2 cur = s_lp[(b0 + i) * 64 + lane];
+                const uint32_t sc_lo = (uint32_t)(rc_range >> 24), sc_hi = (uint32_t)(rc_range >> 56);
+                const uint64_t p0 = (uint64_t)sc_lo * cur.x;
+                const uint32_t p_lo = (uint32_t)p0, p_hi = (uint32_t)(p0 >> 32) + sc_hi * cur.x;
+                const int k = (int)k_rare;
+                const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(p_hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(p_lo, k);
+                const uint32_t psel = (uint32_t)__builtin_amdgcn_readlane(cur.y, k);
+                uint64_t nd = rc_dist - pl;
+                uint64_t nr = (uint64_t)sc_lo * psel + ((uint64_t)(sc_hi * psel) << 32);
+                nr <<= 32;
+                nd = (nd << 32) | (uint32_t)__builtin_amdgcn_readlane(wbuf, (wp - wbase) & 63);
+                wp++;
+                if (wp - wbase == 64) { wbase = wp; wbuf = words[wp + lane]; }
+                rc_dist = ((uint64_t)rfl((uint32_t)(nd >> 32)) << 32) | rfl((uint32_t)nd);
+                rc_range = ((uint64_t)rfl((uint32_t)(nr >> 32)) << 32) | rfl((uint32_t)nr);
+                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(raw) : "s"(k), "s"(i));
+                ++i;
+            }
+            if (lane < 16) s_out[b0 + lane] = (int8_t)(64 - raw);
+        }
+        total += clock64() - t0;
+        __syncthreads();
+        for (int j = lane; j < CH; j += 64) out[c0 + j] = s_out[j];
+    }
+    if (lane == 0) { stats[0] = (uint64_t)total; stats[1] = wp; stats[2] = rc_dist; }
+}
+
+// Variant F: trimmed loop (prodP in VALU, m0 as counter, alternating range registers) (ccd_entropy_pipe.hip) on (L,P) pairs, batches of 16 symbols.
+__global__ __launch_bounds__(64) void chain_f(const uint32_t* __restrict__ tbl, const uint32_t* __restrict__ words, int n,
+                                             int8_t* out, uint64_t* stats) {
+    __shared__ uint2 s_lp[CH * 64];
+    __shared__ int8_t s_out[CH];
+    const int lane = threadIdx.x;
+    uint32_t wp = 2;
+    uint64_t rc_range = ~uint64_t{0};
+    uint64_t rc_dist = ((uint64_t)rfl(words[0]) << 32) | rfl(words[1]);
+    uint32_t wbuf = words[2 + lane];
+    uint32_t wbase = 2;
+    long long total = 0;
+    for (int c0 = 0; c0 < n; c0 += CH) {
+        for (int j = lane; j < CH * 64; j += 64) {
+            // descending order in lanes: lane k holds candidate 63 - k
+            const int sym = j / 64, k = j % 64, cand = 63 - k;
+            const uint32_t a = tbl[(size_t)(c0 + sym) * TBL + cand], b = tbl[(size_t)(c0 + sym) * TBL + cand + 1];
+            s_lp[j] = make_uint2(a, b - a);
+        }
+        __syncthreads();
+        long long t0 = clock64();
+        for (int b0 = 0; b0 < CH; b0 += 16) {
+            int raw = 0;
+            uint32_t i = 0;
+            const uint32_t cnt = 16;
+            const uint32_t tab_addr = (uint32_t)(uintptr_t)(s_lp + b0 * 64 + lane);
+            while (i < cnt) {
+                uint32_t status, k_rare;
+                uint32_t taddr = tab_addr + i * 512u;
+                asm volatile(
+                    "s_mov_b64 s[50:51], %[dst]\n\t"
+                    "s_mov_b64 s[52:53], %[rng]\n\t"
+                    "s_mov_b32 m0, %[i]\n\t"
+                    "ds_read_b64 v[40:41], %[ta]\n\t"
+                    "1:\n\t"
+                    "ds_read_b64 v[42:43], %[ta] offset:512\n\t"
+                    "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                    "s_waitcnt lgkmcnt(1)\n\t"
+                    "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
+                    "v_mad_u64_u32 v[46:47], s[42:43], s40, v41, 0\n\t"
+                    "v_mad_u32_u24 v45, v40, s41, v45\n\t"
+                    "v_mad_u32_u24 v47, v41, s41, v47\n\t"
+                    "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                    "s_ff1_i32_b64 s44, vcc\n\t"
+                    "v_readlane_b32 s49, v47, s44\n\t"
+                    "v_readlane_b32 s48, v46, s44\n\t"
+                    "v_readlane_b32 s46, v44, s44\n\t"
+                    "v_readlane_b32 s47, v45, s44\n\t"
+                    "v_writelane_b32 %[raw], s44, m0\n\t"
+                    "s_add_u32 m0, m0, 1\n\t"
+                    "s_cmp_eq_u32 s49, 0\n\t"
+                    "s_cbranch_scc1 3f\n\t"
+                    "s_sub_u32 s50, s50, s46\n\t"
+                    "s_subb_u32 s51, s51, s47\n\t"
+                    "s_mov_b64 s[52:53], s[48:49]\n\t"
+                    "s_cmp_lt_u32 m0, %[cnt]\n\t"
+                    "s_cbranch_scc0 2f\n\t"
+                    "ds_read_b64 v[40:41], %[ta] offset:1024\n\t"
+                    "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                    "s_waitcnt lgkmcnt(1)\n\t"
+                    "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
+                    "v_mad_u64_u32 v[46:47], s[42:43], s40, v43, 0\n\t"
+                    "v_mad_u32_u24 v45, v42, s41, v45\n\t"
+                    "v_mad_u32_u24 v47, v43, s41, v47\n\t"
+                    "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                    "s_ff1_i32_b64 s44, vcc\n\t"
+                    "v_readlane_b32 s49, v47, s44\n\t"
+                    "v_readlane_b32 s48, v46, s44\n\t"
+                    "v_readlane_b32 s46, v44, s44\n\t"
+                    "v_readlane_b32 s47, v45, s44\n\t"
+                    "v_writelane_b32 %[raw], s44, m0\n\t"
+                    "s_add_u32 m0, m0, 1\n\t"
+                    "s_cmp_eq_u32 s49, 0\n\t"
+                    "s_cbranch_scc1 3f\n\t"
+                    "s_sub_u32 s50, s50, s46\n\t"
+                    "s_subb_u32 s51, s51, s47\n\t"
+                    "s_mov_b64 s[52:53], s[48:49]\n\t"
+                    "v_add_u32 %[ta], 0x400, %[ta]\n\t"
+                    "s_cmp_lt_u32 m0, %[cnt]\n\t"
+                    "s_cbranch_scc1 1b\n\t"
+                    "2:\n\t"
+                    "s_mov_b32 %[st], 0\n\t"
+                    "s_mov_b32 %[i], m0\n\t"
+                    "s_branch 4f\n\t"
+                    "3:\n\t"
+                    "s_mov_b32 %[st], 1\n\t"
+                    "s_sub_u32 %[i], m0, 1\n\t"
+                    "4:\n\t"
+                    "s_mov_b32 %[kr], s44\n\t"
+                    "s_mov_b64 %[dst], s[50:51]\n\t"
+                    "s_mov_b64 %[rng], s[52:53]\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [i] "+s"(i), [raw] "+v"(raw), [ta] "+v"(taddr), [st] "=s"(status),
+                      [kr] "=s"(k_rare)
+                    : [cnt] "s"(cnt)
+                    : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
+                      "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+                if (status == 0) break;
+                const uint2 cur = s_lp[(b0 + i) * 64 + lane];
+                const uint32_t sc_lo = (uint32_t)(rc_range >> 24), sc_hi = (uint32_t)(rc_range >> 56);
+                const uint64_t p0 = (uint64_t)sc_lo * cur.x;
+                const uint32_t p_lo = (uint32_t)p0, p_hi = (uint32_t)(p0 >> 32) + sc_hi * cur.x;
+                const int k = (int)k_rare;
+                const uint64_t pl = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(p_hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(p_lo, k);
+                const uint32_t psel = (uint32_t)__builtin_amdgcn_readlane(cur.y, k);
+                uint64_t nd = rc_dist - pl;
+                uint64_t nr = (uint64_t)sc_lo * psel + ((uint64_t)(sc_hi * psel) << 32);
+                nr <<= 32;
+                nd = (nd << 32) | (uint32_t)__builtin_amdgcn_readlane(wbuf, (wp - wbase) & 63);
+                wp++;
+                if (wp - wbase == 64) { wbase = wp; wbuf = words[wp + lane]; }
+                rc_dist = ((uint64_t)rfl((uint32_t)(nd >> 32)) << 32) | rfl((uint32_t)nd);
+                rc_range = ((uint64_t)rfl((uint32_t)(nr >> 32)) << 32) | rfl((uint32_t)nr);
+                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(raw) : "s"(k), "s"(i));
+                ++i;
+            }
+            if (lane < 16) s_out[b0 + lane] = (int8_t)(64 - raw);
+        }
+        total += clock64() - t0;
+        __syncthreads();
+        for (int j = lane; j < CH; j += 64) out[c0 + j] = s_out[j];
+    }
+    if (lane == 0) { stats[0] = (uint64_t)total; stats[1] = wp; stats[2] = rc_dist; }
+}
+
 int main() {
     const int n = 200064;
     std::vector<uint32_t> tbl((size_t)(n + 2) * TBL, 0);
@@ -244,6 +495,16 @@ int main() {
     CHECK(hipDeviceSynchronize());
     CHECK(hipMemcpy(st, d_stats, 24, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(ob.data(), d_out, n, hipMemcpyDeviceToHost));
     printf("chain_d (L+P tables, writelane, unroll4): %.1f clk/symbol, words %llu, dist %llx, same symbols: %d\n", (double)st[0] / n, (unsigned long long)st[1],
+           (unsigned long long)st[2], (int)(oa == ob));
+    hipLaunchKernelGGL(chain_e, dim3(1), dim3(64), 0, 0, d_tbl, d_words, n, d_out, d_stats);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(st, d_stats, 24, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(ob.data(), d_out, n, hipMemcpyDeviceToHost));
+    printf("chain_e (production asm loop): %.1f clk/symbol, words %llu, dist %llx, same symbols: %d\n", (double)st[0] / n, (unsigned long long)st[1],
+           (unsigned long long)st[2], (int)(oa == ob));
+    hipLaunchKernelGGL(chain_f, dim3(1), dim3(64), 0, 0, d_tbl, d_words, n, d_out, d_stats);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipMemcpy(st, d_stats, 24, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(ob.data(), d_out, n, hipMemcpyDeviceToHost));
+    printf("chain_f (trimmed asm loop): %.1f clk/symbol, words %llu, dist %llx, same symbols: %d\n", (double)st[0] / n, (unsigned long long)st[1],
            (unsigned long long)st[2], (int)(oa == ob));
     // wall time for reference
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
