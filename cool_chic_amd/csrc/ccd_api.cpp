@@ -20,7 +20,7 @@ bool entropy_pipe_supports(int dim, int n_layers, int narrow, int max_grid_w);
 hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_laplace_bounds(const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* sym,
                                  const float* scale_table, int64_t n, uint32_t* left, uint32_t* right, hipStream_t stream);
-hipError_t launch_upsample_level(const UpsampleLevel& L, hipStream_t stream);
+hipError_t launch_upsample_step(const UpsampleLevel* d_levels, const uint32_t* d_zmap, int n_z, int max_w, int max_h, hipStream_t stream);
 hipError_t launch_i8_to_f32(const int8_t* in, float* out, size_t n, hipStream_t stream);
 hipError_t launch_syn_layer(const float* in, const float* in2, const float* wt, const float* bias, float* out, int c_in,
                             int c_out, int k, int residual, int relu, int h, int w, hipStream_t stream);
@@ -108,6 +108,11 @@ struct ccd_batch {
     struct FusedGroup { int cp, c, c_in, n, first, max_tx, max_ty; };
     std::vector<FusedGroup> fused_groups;
     SynthFused* d_fused = nullptr;
+    // upsampling: step k of every slot's pyramid in one launch
+    struct UpsStep { int first_z, n_z, max_w, max_h; };
+    std::vector<UpsStep> ups_steps;
+    UpsampleLevel* d_levels = nullptr;
+    uint32_t* d_zmap = nullptr;
 };
 
 extern "C" {
@@ -172,6 +177,8 @@ void ccd_batch_destroy(ccd_batch* b) {
     for (auto& s : b->slots) s->arena.release();
     if (b->d_params) (void)hipFree(b->d_params);
     if (b->d_fused) (void)hipFree(b->d_fused);
+    if (b->d_levels) (void)hipFree(b->d_levels);
+    if (b->d_zmap) (void)hipFree(b->d_zmap);
     if (b->d_scale_table) (void)hipFree(b->d_scale_table);
     if (b->d_rcp_table) (void)hipFree(b->d_rcp_table);
     delete b;
@@ -453,6 +460,38 @@ static int upload_params(ccd_batch* b) {
         if (hipMalloc(&b->d_fused, sizeof(SynthFused) * fused.size()) != hipSuccess) return CCD_ERR_NOMEM;
         if (hipMemcpy(b->d_fused, fused.data(), sizeof(SynthFused) * fused.size(), hipMemcpyHostToDevice) != hipSuccess) return CCD_ERR_HIP;
     }
+    // upsampling steps: step k (k-th from the coarsest level) of all slots together
+    if (b->d_levels) { (void)hipFree(b->d_levels); b->d_levels = nullptr; }
+    if (b->d_zmap) { (void)hipFree(b->d_zmap); b->d_zmap = nullptr; }
+    b->ups_steps.clear();
+    std::vector<UpsampleLevel> levels;
+    std::vector<uint32_t> zmap;
+    size_t max_steps = 0;
+    for (int i = 0; i < n; ++i) max_steps = std::max(max_steps, b->slots[i]->levels.size());
+    for (size_t k = 0; k < max_steps; ++k) {
+        ccd_batch::UpsStep st{static_cast<int>(zmap.size()), 0, 0, 0};
+        for (int i = 0; i < n; ++i) {
+            const Slot& s = *b->slots[i];
+            if (k >= s.levels.size()) continue;
+            if (levels.size() >= 65535) return CCD_ERR_UNSUPPORTED;
+            const uint32_t li = static_cast<uint32_t>(levels.size());
+            levels.push_back(s.levels[k]);
+            // group 0 = pre-concat conv; group g >= 1 = transposed conv of input channels 2g-2, 2g-1
+            for (int grp = 0; grp <= (s.levels[k].c_in + 1) / 2; ++grp) zmap.push_back((li << 16) | static_cast<uint32_t>(grp));
+            st.max_w = std::max(st.max_w, static_cast<int>(s.levels[k].w_out));
+            st.max_h = std::max(st.max_h, static_cast<int>(s.levels[k].h_out));
+        }
+        st.n_z = static_cast<int>(zmap.size()) - st.first_z;
+        b->ups_steps.push_back(st);
+    }
+    if (!levels.empty()) {
+        if (hipMalloc(&b->d_levels, sizeof(UpsampleLevel) * levels.size()) != hipSuccess ||
+            hipMalloc(&b->d_zmap, sizeof(uint32_t) * zmap.size()) != hipSuccess)
+            return CCD_ERR_NOMEM;
+        if (hipMemcpy(b->d_levels, levels.data(), sizeof(UpsampleLevel) * levels.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(b->d_zmap, zmap.data(), sizeof(uint32_t) * zmap.size(), hipMemcpyHostToDevice) != hipSuccess)
+            return CCD_ERR_HIP;
+    }
     b->n_params_uploaded = n;
     return CCD_OK;
 }
@@ -463,8 +502,7 @@ static int run_upsampling(Slot& s, hipStream_t st) {
         HIP_TRY(launch_i8_to_f32(s.ep.latent[g], s.d_dense, static_cast<size_t>(s.dense_h) * s.dense_w, st));
         return CCD_OK;
     }
-    for (const UpsampleLevel& L : s.levels) HIP_TRY(launch_upsample_level(L, st));
-    return CCD_OK;
+    return CCD_OK;  // the pyramid steps were launched for the whole batch (ccd_batch_run_stage)
 }
 
 static int run_synthesis(Slot& s, hipStream_t st) {
@@ -513,6 +551,9 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
         HIP_TRY(launch_entropy(b->d_params + b->n_pipe, b->n_generic, b->lds_generic, st));
         return CCD_OK;
     }
+    if (stage == 1)
+        for (const auto& u : b->ups_steps)
+            HIP_TRY(launch_upsample_step(b->d_levels, b->d_zmap + u.first_z, u.n_z, u.max_w, u.max_h, st));
     if (stage == 2)
         for (const auto& g : b->fused_groups)
             HIP_TRY(launch_syn_fused(b->d_fused + g.first, g.n, g.c_in, g.c, g.max_tx, g.max_ty, st));

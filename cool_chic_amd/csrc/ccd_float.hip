@@ -24,14 +24,14 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // Upsampling: one launch per pyramid level.  blockIdx.z = output channel: 0 is the pre-concat conv of
 // the level's own latent, c >= 1 is the x2 transposed conv of input channel c-1.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void upsample_level_kernel(UpsampleLevel L) {
-    const int ox = blockIdx.x * 32 + (threadIdx.x & 31);
-    const int oy = blockIdx.y * 8 + (threadIdx.x >> 5);
-    if (ox >= L.w_out || oy >= L.h_out) return;
-    const int ch = blockIdx.z;
+// Each thread produces a 2x2 output quad.  For the x2 transposed conv the four outputs of a quad read one
+// shared (k/2+1)^2 window of the input (5x5 for k = 8) and the k x k kron products are formed once per
+// thread and reused by every channel; accumulation order per output is unchanged (ky ascending, kx ascending).
+constexpr int kUpsMaxK = 8;   // fast path for ups_k <= 8 / pre_k <= 7; larger kernels use the generic body
+
+__device__ __forceinline__ void upsample_generic_one(const UpsampleLevel& L, int ch, int ox, int oy) {
     float acc = 0.0f;
     if (ch == 0) {
-        // pre-concatenation filter: zero padding, kron kernel, residual (upsampling.py:189-196)
         const int k = L.pre_k, pad = k / 2;
         const int8_t* t = L.target;
         for (int ky = 0; ky < k; ++ky) {
@@ -46,7 +46,6 @@ __global__ __launch_bounds__(256) void upsample_level_kernel(UpsampleLevel L) {
         }
         acc = acc + static_cast<float>(t[oy * L.w_out + ox]);
     } else {
-        // x2 transposed conv on the replicate-padded input, cropped by C (upsampling.py:306-325)
         const int k = L.ups_k, p0 = k / 2, crop = 2 * p0 - 1 + k / 2;
         const int h = L.h_in, w = L.w_in;
         const int py = oy + crop, px = ox + crop;
@@ -68,9 +67,128 @@ __global__ __launch_bounds__(256) void upsample_level_kernel(UpsampleLevel L) {
     L.out[(static_cast<size_t>(ch) * L.h_out + oy) * L.w_out + ox] = acc;
 }
 
-hipError_t launch_upsample_level(const UpsampleLevel& L, hipStream_t stream) {
-    dim3 grid((L.w_out + 31) / 32, (L.h_out + 7) / 8, L.c_in + 1);
-    hipLaunchKernelGGL(upsample_level_kernel, grid, dim3(256), 0, stream, L);
+// x2 transposed conv, k == 8 (the value every preset uses): quad (qy, qx) -> outputs (2qy + dy, 2qx + dx).
+// With crop 11 and pad 4: output row 2qy   (py odd ) uses ky = 1,3,5,7 on source rows qy+1, qy, qy-1, qy-2
+//                         output row 2qy+1 (py even) uses ky = 0,2,4,6 on source rows qy+2, qy+1, qy, qy-1
+__device__ __forceinline__ void tconv8_quad(const UpsampleLevel& L, int qx, int qy, int ch_first, int ch_last) {
+    const int h = L.h_in, w = L.w_in;
+    float wv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) wv[i] = L.ups_w[i];
+    int sy[5], sx[5];
+#pragma unroll
+    for (int d = 0; d < 5; ++d) {
+        sy[d] = clampi(qy - 2 + d, 0, h - 1) * w;
+        sx[d] = clampi(qx - 2 + d, 0, w - 1);
+    }
+    const int oy0 = 2 * qy, ox0 = 2 * qx;
+    for (int ch = ch_first; ch <= ch_last; ++ch) {
+        float v[5][5];
+        if (L.in_f32) {
+            const float* src = L.in_f32 + static_cast<size_t>(ch - 1) * h * w;
+#pragma unroll
+            for (int a = 0; a < 5; ++a)
+#pragma unroll
+                for (int b = 0; b < 5; ++b) v[a][b] = src[sy[a] + sx[b]];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 5; ++a)
+#pragma unroll
+                for (int b = 0; b < 5; ++b) v[a][b] = static_cast<float>(L.in_i8[sy[a] + sx[b]]);
+        }
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int ty = 0; ty < 4; ++ty) {
+                    const int ky = (1 - dy) + 2 * ty;          // ascending ky
+                    const int ra = (dy == 0 ? 3 : 4) - ty;     // row index in v (source row descends as ky ascends)
+#pragma unroll
+                    for (int tx = 0; tx < 4; ++tx) {
+                        const int kx = (1 - dx) + 2 * tx;
+                        const int cb = (dx == 0 ? 3 : 4) - tx;
+                        acc = __fmaf_rn(v[ra][cb], wv[ky] * wv[kx], acc);
+                    }
+                }
+                const int oy = oy0 + dy, ox = ox0 + dx;
+                if (oy < L.h_out && ox < L.w_out) L.out[(static_cast<size_t>(ch) * L.h_out + oy) * L.w_out + ox] = acc;
+            }
+        }
+    }
+}
+
+// Pre-concatenation 7x7 conv (zero padding, kron kernel, residual) for a 2x2 output quad: one 8x8 window of
+// the int8 latent feeds the four outputs.  Out-of-range taps are loaded as 0: fma(0, k2, acc) == acc bit for bit
+// (acc is never -0), which equals the oracle's skipping of those taps.
+__device__ __forceinline__ void preconv7_quad(const UpsampleLevel& L, int qx, int qy) {
+    const int h = L.h_out, w = L.w_out;
+    const int8_t* __restrict__ t = L.target;
+    float wv[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) wv[i] = L.pre_w[i];
+    const int y0 = 2 * qy - 3, x0 = 2 * qx - 3;
+    float v[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int yy = y0 + a;
+        const bool row_ok = yy >= 0 && yy < h;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int xx = x0 + b;
+            v[a][b] = (row_ok && xx >= 0 && xx < w) ? static_cast<float>(t[yy * w + xx]) : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) acc = __fmaf_rn(v[dy + ky][dx + kx], wv[ky] * wv[kx], acc);
+            acc = acc + v[dy + 3][dx + 3];
+            const int oy = 2 * qy + dy, ox = 2 * qx + dx;
+            if (oy < h && ox < w) L.out[static_cast<size_t>(oy) * w + ox] = acc;
+        }
+    }
+}
+
+// One launch per pyramid step for ALL frames of a batch: z enumerates (frame, channel group) pairs through
+// `zmap` (high 16 bits: index into `levels`, low 16 bits: channel group); the x/y grid covers the largest frame.
+// Channel group 0 = pre-concat conv of the level's latent; group g >= 1 = transposed conv of input channels
+// 2g-2 .. 2g-1 (two channels per thread share the kron products).
+__global__ __launch_bounds__(256) void upsample_step_kernel(const UpsampleLevel* __restrict__ levels, const uint32_t* __restrict__ zmap) {
+    const uint32_t z = zmap[blockIdx.z];
+    const UpsampleLevel& L = levels[z >> 16];
+    const int grp = static_cast<int>(z & 0xffffu);
+    // a block covers 64 x 16 outputs = 32 x 8 quads
+    if (static_cast<int>(blockIdx.x) * 64 >= L.w_out || static_cast<int>(blockIdx.y) * 16 >= L.h_out) return;
+    const int qx = blockIdx.x * 32 + (threadIdx.x & 31), qy = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (2 * qx >= L.w_out || 2 * qy >= L.h_out) return;
+    if (grp == 0 && L.pre_k == 7) { preconv7_quad(L, qx, qy); return; }
+    if (grp == 0) {
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx)
+                if (2 * qy + dy < L.h_out && 2 * qx + dx < L.w_out) upsample_generic_one(L, 0, 2 * qx + dx, 2 * qy + dy);
+        return;
+    }
+    const int ch_first = 2 * grp - 1, ch_last = min(2 * grp, static_cast<int>(L.c_in));
+    if (L.ups_k == 8) { tconv8_quad(L, qx, qy, ch_first, ch_last); return; }
+    for (int ch = ch_first; ch <= ch_last; ++ch)
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx)
+                if (2 * qy + dy < L.h_out && 2 * qx + dx < L.w_out) upsample_generic_one(L, ch, 2 * qx + dx, 2 * qy + dy);
+}
+
+hipError_t launch_upsample_step(const UpsampleLevel* d_levels, const uint32_t* d_zmap, int n_z, int max_w, int max_h, hipStream_t stream) {
+    if (n_z <= 0) return hipSuccess;
+    dim3 grid((max_w + 63) / 64, (max_h + 15) / 16, n_z);
+    hipLaunchKernelGGL(upsample_step_kernel, grid, dim3(256), 0, stream, d_levels, d_zmap);
     return hipGetLastError();
 }
 
