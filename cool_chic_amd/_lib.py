@@ -97,6 +97,9 @@ SIGNATURES = {
     "ccd_batch_copy_output": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ccd_batch_copy_dense": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "ccd_decode_video": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int, C.POINTER(Video)]),
+    "ccd_inter_reconstruct": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int,
+                                        C.POINTER(C.c_void_p)]),
     "ccd_video_free": (None, [C.POINTER(Video)]),
     "ccd_range_encode": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(_u8p)]),
     "ccd_encode_stream": (C.c_int64, [C.POINTER(CCHeader), C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_int,

@@ -106,16 +106,16 @@ def decode_video(bitstream_path: str, decoded_path: Optional[str] = None, max_de
             batch.close()
         print(f"Decoding {len(frames)} intra frame(s) time = {time.time() - start:6.2f} seconds.")
     else:
-        from .codingstructure import coding_structure
-
-        order = coding_structure(n_frames, vh.get_value("intra_pos"), vh.get_value("p_pos"))
+        # P / B frames: frames arrive in coding order and name their references by display index
+        # (frame header); the reference recomputes the same from the coding structure (decode.py:54,70-73).
         for coding_idx in range(max_decoding_order + 1):
             start = time.time()
-            fr = order[coding_idx]
-            refs = [frames[r] for r in fr["index_references"]]
+            fh = FrameHeader()
+            fh.read_header(bitstream_bytes)
+            refs = [frames[r] for r in fh.get_value("index_references")]
             frame_data, bitstream_bytes = decode_frame(bitstream_bytes, refs, verbosity, device)
-            frames[fr["display_order"]] = frame_data
-            print(f"Decoding frame {fr['display_order']:<4} time = {time.time() - start:6.2f} seconds.")
+            frames[fh.get_value("display_index")] = frame_data
+            print(f"Decoding frame {fh.get_value('display_index'):<4} time = {time.time() - start:6.2f} seconds.")
     all_frames = {}
     for display_idx in sorted(frames):
         all_frames[str(display_idx)] = frames[display_idx]

@@ -30,6 +30,10 @@ hipError_t launch_syn_fused(const SynthFused* d_frames, int n_frames, int c_in, 
                             hipStream_t stream);
 hipError_t launch_resize_nearest(const float* in, float* out, int c, int h_in, int w_in, int h_out, int w_out,
                                  hipStream_t stream);
+hipError_t launch_planes_to_444(const void* p0, const void* p1, const void* p2, float* out, int h, int w, int bitdepth,
+                                int frame_data_type, hipStream_t stream);
+hipError_t launch_inter_recon(int frame_type, int h, int w, int n_taps, const int* gflow, const float* residue, const float* motion,
+                              const float* ref0, const float* ref1, float* out, hipStream_t stream);
 hipError_t launch_planes(const float* src, void* p0, void* p1, void* p2, int h, int w, int bitdepth, int frame_data_type,
                          hipStream_t stream);
 
@@ -683,6 +687,35 @@ void ccd_video_free(ccd_video* v) {
     v->frames = nullptr; v->n_frames = 0;
 }
 
+int ccd_inter_reconstruct(int device, void* stream, int frame_type, int h, int w, int bitdepth, int frame_data_type,
+                          const float* residue, const float* motion, const void* const* ref0_planes,
+                          const void* const* ref1_planes, const int32_t* global_flow, int warp_filter_size,
+                          void* const* out_planes) {
+    if ((frame_type != 1 && frame_type != 2) || !residue || !motion || !ref0_planes || !global_flow || !out_planes ||
+        (frame_type == 2 && !ref1_planes) || h <= 0 || w <= 0 || bitdepth < 8 || bitdepth > 16)
+        return CCD_ERR_ARG;
+    if (warp_filter_size < 6) return CCD_ERR_UNSUPPORTED;  // 2 / 4 taps = torch grid_sample bilinear / bicubic (warp.py:49-56)
+    if (warp_filter_size > 16 || (warp_filter_size & 1)) return CCD_ERR_VALUE;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t frame_bytes = static_cast<size_t>(3) * h * w * sizeof(float);
+    float* tmp = nullptr;
+    if (hipMalloc(&tmp, 3 * frame_bytes) != hipSuccess) return CCD_ERR_NOMEM;
+    float* ref0 = tmp;
+    float* ref1 = tmp + static_cast<size_t>(3) * h * w;
+    float* out = tmp + static_cast<size_t>(6) * h * w;
+    int rc = CCD_OK;
+    int gf[4] = {global_flow[0], global_flow[1], frame_type == 2 ? global_flow[2] : 0, frame_type == 2 ? global_flow[3] : 0};
+    if (launch_planes_to_444(ref0_planes[0], ref0_planes[1], ref0_planes[2], ref0, h, w, bitdepth, frame_data_type, st) != hipSuccess) rc = CCD_ERR_HIP;
+    if (rc == CCD_OK && frame_type == 2 &&
+        launch_planes_to_444(ref1_planes[0], ref1_planes[1], ref1_planes[2], ref1, h, w, bitdepth, frame_data_type, st) != hipSuccess) rc = CCD_ERR_HIP;
+    if (rc == CCD_OK && launch_inter_recon(frame_type, h, w, warp_filter_size, gf, residue, motion, ref0, frame_type == 2 ? ref1 : ref0, out, st) != hipSuccess) rc = CCD_ERR_HIP;
+    if (rc == CCD_OK && launch_planes(out, out_planes[0], out_planes[1], out_planes[2], h, w, bitdepth, frame_data_type, st) != hipSuccess) rc = CCD_ERR_HIP;
+    if (hipStreamSynchronize(st) != hipSuccess) rc = CCD_ERR_HIP;
+    (void)hipFree(tmp);
+    return rc;
+}
+
 int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
     if (!bs || !v) return CCD_ERR_ARG;
     v->n_frames = 0; v->frames = nullptr;
@@ -695,49 +728,89 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
     ccd_batch* b = nullptr;
     int rc = ccd_batch_create(device, &b);
     if (rc < 0) return rc;
+    // Every cool-chic of every frame is independent: all of them go into ONE batch and decode concurrently; the cheap
+    // reconstruction then walks the frames in coding order (decode.py:67-81).
     std::vector<ccd_frame_header> fhs(n_frames);
+    std::vector<int> first_slot(n_frames, 0);
     for (int f = 0; f < n_frames && rc >= 0; ++f) {
         used = read_frame_header(bs + pos, n - pos, &fhs[f]);
         if (used < 0) { rc = used; break; }
         pos += static_cast<size_t>(used);
-        if (fhs[f].frame_type != 0) { rc = CCD_ERR_UNSUPPORTED; break; }  // P/B reconstruction: next round
-        ccd_cc_header ch;
-        used = read_cc_header(bs + pos, n - pos, &ch);
-        if (used < 0) { rc = used; break; }
-        const uint8_t* hdr = bs + pos;
-        pos += static_cast<size_t>(used);
-        if (pos + static_cast<size_t>(ch.nn_n_bytes) + static_cast<size_t>(ch.n_bytes_latent) > n) { rc = CCD_ERR_TRUNCATED; break; }
-        rc = ccd_batch_add(b, hdr, static_cast<size_t>(used), bs + pos, ch.nn_n_bytes, bs + pos + ch.nn_n_bytes,
-                           ch.n_bytes_latent, fhs[f].bitdepth, fhs[f].frame_data_type);
-        pos += static_cast<size_t>(ch.nn_n_bytes) + static_cast<size_t>(ch.n_bytes_latent);
+        first_slot[f] = ccd_batch_size(b);
+        const int n_cc = fhs[f].frame_type == 0 ? 1 : 2;  // residue (+ motion), decode.py:126-128
+        for (int c = 0; c < n_cc && rc >= 0; ++c) {
+            ccd_cc_header ch;
+            used = read_cc_header(bs + pos, n - pos, &ch);
+            if (used < 0) { rc = used; break; }
+            const uint8_t* hdr = bs + pos;
+            pos += static_cast<size_t>(used);
+            if (pos + static_cast<size_t>(ch.nn_n_bytes) + static_cast<size_t>(ch.n_bytes_latent) > n) { rc = CCD_ERR_TRUNCATED; break; }
+            const bool intra = fhs[f].frame_type == 0;
+            rc = ccd_batch_add(b, hdr, static_cast<size_t>(used), bs + pos, ch.nn_n_bytes, bs + pos + ch.nn_n_bytes, ch.n_bytes_latent,
+                               intra ? fhs[f].bitdepth : 0, fhs[f].frame_data_type);
+            pos += static_cast<size_t>(ch.nn_n_bytes) + static_cast<size_t>(ch.n_bytes_latent);
+        }
     }
     if (rc >= 0) rc = ccd_batch_run(b, nullptr);
     if (rc >= 0) rc = ccd_batch_wait(b, nullptr);
+    // ---- frame reconstruction in coding order; device planes of every decoded frame are kept for references ------
+    struct DevFrame { void* plane[3] = {nullptr, nullptr, nullptr}; int h = 0, w = 0, ch = 0, cw = 0, bitdepth = 0, fdt = 0; bool owned = false; };
+    std::vector<DevFrame> dev(n_frames);  // by display index
+    for (int f = 0; f < n_frames && rc >= 0; ++f) {
+        const ccd_frame_header& fh = fhs[f];
+        if (fh.display_index < 0 || fh.display_index >= n_frames) { rc = CCD_ERR_VALUE; break; }
+        DevFrame& d = dev[fh.display_index];
+        const Slot& s0 = *b->slots[first_slot[f]];
+        d.h = s0.hdr.img_size[0]; d.w = s0.hdr.img_size[1]; d.bitdepth = fh.bitdepth; d.fdt = fh.frame_data_type;
+        d.ch = fh.frame_data_type == 1 ? d.h / 2 : d.h; d.cw = fh.frame_data_type == 1 ? d.w / 2 : d.w;
+        if (fh.frame_type == 0) {
+            if (s0.hdr.out_channels < 3) { rc = CCD_ERR_VALUE; break; }
+            for (int p = 0; p < 3; ++p) d.plane[p] = s0.d_plane[p];
+        } else {
+            const Slot& s1 = *b->slots[first_slot[f] + 1];
+            const int need_res = fh.frame_type == 1 ? 4 : 5, need_mot = fh.frame_type == 1 ? 2 : 4;
+            if (s0.hdr.out_channels < need_res || s1.hdr.out_channels < need_mot || s1.hdr.img_size[0] != d.h || s1.hdr.img_size[1] != d.w) { rc = CCD_ERR_VALUE; break; }
+            const void* refs[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+            for (int k = 0; k < fh.n_refs && rc >= 0; ++k) {
+                const int ri = fh.index_references[k];
+                if (ri < 0 || ri >= n_frames || !dev[ri].plane[0] || dev[ri].h != d.h || dev[ri].w != d.w || dev[ri].bitdepth != d.bitdepth) { rc = CCD_ERR_VALUE; break; }
+                for (int p = 0; p < 3; ++p) refs[k][p] = dev[ri].plane[p];
+            }
+            if (rc < 0) break;
+            const size_t sb = d.bitdepth == 8 ? 1 : 2;
+            for (int p = 0; p < 3 && rc >= 0; ++p) {
+                const size_t px = p == 0 ? static_cast<size_t>(d.h) * d.w : static_cast<size_t>(d.ch) * d.cw;
+                if (hipMalloc(&d.plane[p], px * sb + 16) != hipSuccess) rc = CCD_ERR_NOMEM;
+            }
+            d.owned = true;
+            if (rc >= 0)
+                rc = ccd_inter_reconstruct(device, nullptr, fh.frame_type, d.h, d.w, d.bitdepth, d.fdt, s0.d_out, s1.d_out, refs[0],
+                                           fh.frame_type == 2 ? refs[1] : nullptr, fh.global_flow, fh.warp_filter_size, d.plane);
+        }
+    }
     if (rc >= 0) {
         v->frames = static_cast<ccd_frame*>(std::calloc(std::max(n_frames, 1), sizeof(ccd_frame)));
         v->n_frames = n_frames;
         for (int f = 0; f < n_frames && rc >= 0; ++f) {
-            const Slot& s = *b->slots[f];
             const int di = fhs[f].display_index;
-            if (di < 0 || di >= n_frames) { rc = CCD_ERR_VALUE; break; }
+            const DevFrame& d = dev[di];
             ccd_frame& fr = v->frames[di];
-            fr.display_index = di; fr.frame_type = fhs[f].frame_type; fr.frame_data_type = fhs[f].frame_data_type;
-            fr.bitdepth = fhs[f].bitdepth;
-            fr.h = s.plane_h[0]; fr.w = s.plane_w[0]; fr.ch = s.plane_h[1]; fr.cw = s.plane_w[1];
+            fr.display_index = di; fr.frame_type = fhs[f].frame_type; fr.frame_data_type = d.fdt; fr.bitdepth = d.bitdepth;
+            fr.h = d.h; fr.w = d.w; fr.ch = d.ch; fr.cw = d.cw;
             for (int p = 0; p < 3 && rc >= 0; ++p) {
-                const size_t px = static_cast<size_t>(s.plane_h[p]) * s.plane_w[p];
+                const size_t px = p == 0 ? static_cast<size_t>(d.h) * d.w : static_cast<size_t>(d.ch) * d.cw;
                 fr.plane[p] = static_cast<uint16_t*>(std::malloc(px * 2 + 2));
-                if (s.bitdepth == 8) {
+                if (d.bitdepth == 8) {
                     std::vector<uint8_t> tmp(px);
-                    rc = ccd_batch_copy_plane(b, f, p, tmp.data(), nullptr);
+                    if (hipMemcpy(tmp.data(), d.plane[p], px, hipMemcpyDeviceToHost) != hipSuccess) rc = CCD_ERR_HIP;
                     for (size_t i = 0; i < px; ++i) fr.plane[p][i] = tmp[i];
-                } else {
-                    rc = ccd_batch_copy_plane(b, f, p, fr.plane[p], nullptr);
-                }
+                } else if (hipMemcpy(fr.plane[p], d.plane[p], px * 2, hipMemcpyDeviceToHost) != hipSuccess) rc = CCD_ERR_HIP;
             }
         }
         if (rc < 0) ccd_video_free(v);
     }
+    for (auto& d : dev)
+        if (d.owned) for (int p = 0; p < 3; ++p) if (d.plane[p]) (void)hipFree(d.plane[p]);
     ccd_batch_destroy(b);
     return rc < 0 ? rc : CCD_OK;
 }

@@ -1,0 +1,171 @@
+// ccd_inter.hip - P / B frame reconstruction on the device (SURVEY.md section 8f "next-1").
+//
+// Reference behaviour (paths relative to /root/reference/coolchic):
+//   bitstream/decode.py:156-189                      global shift, warp, alpha / beta blend, + residue
+//   component/intercoding/globalmotion.py:151-160    integer global translation (nearest, border clamp)
+//   component/intercoding/warp.py:226-243,294-397    sinc-windowed N-tap warp, TRAINING mode (the decoder never
+//                                                    calls .eval(): flows are NOT quantised), border clamp
+//   io/format/yuv.py:303-316                         4:2:0 references -> 4:4:4 by nearest x2
+//
+// Numerics: identical formulas to oracle/cc_oracle.c section 11 (sin / cos in f64 with explicit fma, rounded to
+// f32; separable passes accumulated with fmaf, taps ascending) -> bit-identical to the oracle.
+#include <hip/hip_runtime.h>
+
+#include "ccd_device.hpp"
+
+namespace ccd {
+
+__device__ __forceinline__ int ic_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ double ic_sin_core(double r) {
+    const double r2 = r * r;
+    double p = -7.6471637318198164759e-13;
+    p = fma(p, r2, 1.6059043836821614599e-10);
+    p = fma(p, r2, -2.5052108385441718775e-08);
+    p = fma(p, r2, 2.7557319223985890653e-06);
+    p = fma(p, r2, -1.9841269841269841270e-04);
+    p = fma(p, r2, 8.3333333333333333333e-03);
+    p = fma(p, r2, -1.6666666666666666667e-01);
+    return fma(p * r2, r, r);
+}
+__device__ __forceinline__ double ic_cos_core(double r) {
+    const double r2 = r * r;
+    double p = 4.7794773323873852974e-14;
+    p = fma(p, r2, -1.1470745597729724714e-11);
+    p = fma(p, r2, 2.0876756987868098979e-09);
+    p = fma(p, r2, -2.7557319223985890653e-07);
+    p = fma(p, r2, 2.4801587301587301587e-05);
+    p = fma(p, r2, -1.3888888888888888889e-03);
+    p = fma(p, r2, 4.1666666666666666667e-02);
+    p = fma(p, r2, -0.5);
+    return fma(p, r2, 1.0);
+}
+__device__ __forceinline__ void ic_sincos(float a, float* s_out, float* c_out) {
+    const double x = static_cast<double>(a);
+    const double q = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-q, 1.57079632679489655800e+00, x);
+    r = fma(-q, 6.12323399573676603587e-17, r);
+    const int n = static_cast<int>(q) & 3;
+    const double sn = ic_sin_core(r), cs = ic_cos_core(r);
+    double sv = (n & 1) ? cs : sn, cv = (n & 1) ? sn : cs;
+    if (n & 2) sv = -sv;
+    if (n == 1 || n == 2) cv = -cv;
+    *s_out = static_cast<float>(sv);
+    *c_out = static_cast<float>(cv);
+}
+
+constexpr int kMaxTaps = 16;
+
+// warp.py:238-243
+__device__ __forceinline__ void ic_coeffs(float s, int n_taps, float* coef) {
+    const float pi_f = 3.14159265358979323846f;
+    for (int j = 0; j < n_taps; ++j) {
+        const float d = s - static_cast<float>(j - n_taps / 2 + 1);
+        float sn, unused_c, unused_s, win;
+        ic_sincos(pi_f * d / static_cast<float>(n_taps), &unused_s, &win);
+        float snc = 1.0f;
+        if (d != 0.0f) { const float a = pi_f * d; ic_sincos(a, &sn, &unused_c); snc = sn / a; }
+        coef[j] = win * snc;
+    }
+}
+
+// Integer planes of a decoded frame -> the [3][H][W] float tensor the warper reads (value = q / (2^bd - 1),
+// 4:2:0 chroma repeated 2x2).
+template <typename T>
+__global__ void planes_to_444_kernel(const T* p0, const T* p1, const T* p2, float* out, int h, int w, int chroma_half, float maxv) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t plane = static_cast<size_t>(h) * w, i = static_cast<size_t>(y) * w + x;
+    out[i] = static_cast<float>(p0[i]) / maxv;
+    const int cw = chroma_half ? w / 2 : w;
+    const size_t ci = chroma_half ? static_cast<size_t>(y >> 1) * cw + (x >> 1) : i;
+    out[plane + i] = static_cast<float>(p1[ci]) / maxv;
+    out[2 * plane + i] = static_cast<float>(p2[ci]) / maxv;
+}
+
+hipError_t launch_planes_to_444(const void* p0, const void* p1, const void* p2, float* out, int h, int w, int bitdepth,
+                                int frame_data_type, hipStream_t stream) {
+    dim3 grid((w + 63) / 64, (h + 3) / 4);
+    const float maxv = static_cast<float>((1 << bitdepth) - 1);
+    const int half = frame_data_type == 1;
+    if (bitdepth == 8)
+        hipLaunchKernelGGL(planes_to_444_kernel<uint8_t>, grid, dim3(256), 0, stream, static_cast<const uint8_t*>(p0),
+                           static_cast<const uint8_t*>(p1), static_cast<const uint8_t*>(p2), out, h, w, half, maxv);
+    else
+        hipLaunchKernelGGL(planes_to_444_kernel<uint16_t>, grid, dim3(256), 0, stream, static_cast<const uint16_t*>(p0),
+                           static_cast<const uint16_t*>(p1), static_cast<const uint16_t*>(p2), out, h, w, half, maxv);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ void ic_warp_pixel(const float* __restrict__ ref, int H, int W, int gx, int gy, int n_taps, float fx,
+                                              float fy, int y, int x, float out[3]) {
+    const float rxf = floorf(fx), ryf = floorf(fy);
+    const float sx = fx - rxf, sy = fy - ryf;
+    const int rx = static_cast<int>(rxf), ry = static_cast<int>(ryf);
+    float cx[kMaxTaps], cy[kMaxTaps];
+    ic_coeffs(sx, n_taps, cx);
+    ic_coeffs(sy, n_taps, cy);
+    const int lo = -(n_taps / 2) + 1;
+    const size_t plane = static_cast<size_t>(H) * W;
+    int xs[kMaxTaps];
+    for (int j = 0; j < n_taps; ++j) xs[j] = ic_clamp(ic_clamp(x + lo + j + rx, 0, W - 1) + gx, 0, W - 1);
+    for (int c = 0; c < 3; ++c) {
+        float acc = 0.0f;
+        for (int i = 0; i < n_taps; ++i) {
+            const int yy = ic_clamp(ic_clamp(y + lo + i + ry, 0, H - 1) + gy, 0, H - 1);
+            const float* row = ref + c * plane + static_cast<size_t>(yy) * W;
+            float line = 0.0f;
+            for (int j = 0; j < n_taps; ++j) line = __fmaf_rn(row[xs[j]], cx[j], line);
+            acc = __fmaf_rn(line, cy[i], acc);
+        }
+        out[c] = acc;
+    }
+}
+
+struct InterParams {
+    const float* residue;  // [4 | 5][H][W]
+    const float* motion;   // [2 | 4][H][W]
+    const float* ref0;     // [3][H][W]
+    const float* ref1;     // B frames
+    float* out;            // [3][H][W]
+    int frame_type, H, W, n_taps;
+    int gflow[4];
+};
+
+__global__ __launch_bounds__(256) void inter_recon_kernel(InterParams p) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.W || y >= p.H) return;
+    const size_t plane = static_cast<size_t>(p.H) * p.W, i = static_cast<size_t>(y) * p.W + x;
+    float a = p.residue[3 * plane + i] + 0.5f;
+    a = a < 0.0f ? 0.0f : (a > 1.0f ? 1.0f : a);
+    float w0[3], pred[3];
+    ic_warp_pixel(p.ref0, p.H, p.W, p.gflow[0], p.gflow[1], p.n_taps, p.motion[i], p.motion[plane + i], y, x, w0);
+    if (p.frame_type == 2) {
+        float b = p.residue[4 * plane + i] + 0.5f;
+        b = b < 0.0f ? 0.0f : (b > 1.0f ? 1.0f : b);
+        float w1[3];
+        ic_warp_pixel(p.ref1, p.H, p.W, p.gflow[2], p.gflow[3], p.n_taps, p.motion[2 * plane + i], p.motion[3 * plane + i], y, x, w1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float t0 = b * w0[c], t1 = (1.0f - b) * w1[c]; pred[c] = t0 + t1; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pred[c] = w0[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const float m = a * pred[c]; p.out[c * plane + i] = m + p.residue[c * plane + i]; }
+}
+
+hipError_t launch_inter_recon(int frame_type, int h, int w, int n_taps, const int* gflow, const float* residue, const float* motion,
+                              const float* ref0, const float* ref1, float* out, hipStream_t stream) {
+    InterParams p;
+    p.residue = residue; p.motion = motion; p.ref0 = ref0; p.ref1 = ref1; p.out = out;
+    p.frame_type = frame_type; p.H = h; p.W = w; p.n_taps = n_taps;
+    for (int i = 0; i < 4; ++i) p.gflow[i] = gflow[i];
+    dim3 grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(inter_recon_kernel, grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace ccd

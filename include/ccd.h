@@ -162,6 +162,17 @@ typedef struct {
 } ccd_video;
 
 int ccd_decode_video(const uint8_t* bitstream, size_t n, int device, ccd_video* v);
+
+/* ---- P / B frame reconstruction: decode.py:156-206 ------------------------------------------- */
+/* All pointers are DEVICE pointers. residue = synthesis output of the "residue" cool-chic ([4][h][w] for P,
+ * [5][h][w] for B: rgb/yuv residue, alpha, beta), motion = output of the "motion" cool-chic ([2] or [4][h][w]:
+ * (x, y) flow per reference), refN_planes = the three integer planes of each reference frame (u8 if
+ * bitdepth == 8 else u16; half-size chroma for yuv420), global_flow = (x, y) integer translation per reference
+ * (frame header), warp_filter_size = taps of the sinc warp (>= 6).  Writes the integer planes of the frame. */
+int ccd_inter_reconstruct(int device, void* stream, int frame_type, int h, int w, int bitdepth, int frame_data_type,
+                          const float* residue, const float* motion, const void* const* ref0_planes,
+                          const void* const* ref1_planes, const int32_t* global_flow, int warp_filter_size,
+                          void* const* out_planes);
 void ccd_video_free(ccd_video* v);
 
 /* ---- bitstream writer + synthetic streams ("next-2" row of SURVEY section 8f) -------------- */

@@ -945,8 +945,116 @@ int ora_decode_coolchic(const uint8_t* cc_header, size_t n_hdr, const uint8_t* b
 }
 
 /* ------------------------------------------------------------------------------------------------
- * 11. Whole stream (bitstream/decode.py:26-212). Intra frames only for now; P/B frames need the
- *     warper (component/intercoding/warp.py) which is a "next" row of the scope table.
+ * 11. Inter-frame reconstruction (bitstream/decode.py:156-189): global translation
+ *     (component/intercoding/globalmotion.py:151-160), sinc-windowed N-tap warp in TRAINING mode
+ *     (component/intercoding/warp.py:226-243, 294-397: no flow quantisation), alpha / beta blending.
+ *
+ *     Canon of this build: sin / cos are evaluated in double (pi/2 reduction + Taylor cores) and
+ *     rounded to float - the correctly rounded float in all but ~1e-7 of the cases, i.e. what glibc's
+ *     sinf (torch.sinc) returns; the two separable passes accumulate with fmaf, taps ascending.
+ *     The HIP kernel uses the very same formulas (ccd_inter.hip).
+ * ---------------------------------------------------------------------------------------------- */
+static double sin_core(double r) { /* |r| <= pi/4 */
+    const double r2 = r * r;
+    double p = -7.6471637318198164759e-13;              /* -1/15! */
+    p = fma(p, r2, 1.6059043836821614599e-10);           /*  1/13! */
+    p = fma(p, r2, -2.5052108385441718775e-08);          /* -1/11! */
+    p = fma(p, r2, 2.7557319223985890653e-06);           /*  1/9!  */
+    p = fma(p, r2, -1.9841269841269841270e-04);          /* -1/7!  */
+    p = fma(p, r2, 8.3333333333333333333e-03);           /*  1/5!  */
+    p = fma(p, r2, -1.6666666666666666667e-01);          /* -1/3!  */
+    return fma(p * r2, r, r);
+}
+static double cos_core(double r) {
+    const double r2 = r * r;
+    double p = 4.7794773323873852974e-14;                /*  1/16! */
+    p = fma(p, r2, -1.1470745597729724714e-11);          /* -1/14! */
+    p = fma(p, r2, 2.0876756987868098979e-09);           /*  1/12! */
+    p = fma(p, r2, -2.7557319223985890653e-07);          /* -1/10! */
+    p = fma(p, r2, 2.4801587301587301587e-05);           /*  1/8!  */
+    p = fma(p, r2, -1.3888888888888888889e-03);          /* -1/6!  */
+    p = fma(p, r2, 4.1666666666666666667e-02);           /*  1/4!  */
+    p = fma(p, r2, -0.5);
+    return fma(p, r2, 1.0);
+}
+static void sincos_f32(float a, float* s_out, float* c_out) {
+    const double x = (double)a;
+    const double q = rint(x * 6.36619772367581382433e-01); /* 2/pi */
+    double r = fma(-q, 1.57079632679489655800e+00, x);     /* pi/2 hi */
+    r = fma(-q, 6.12323399573676603587e-17, r);            /* pi/2 lo */
+    const int n = (int)q & 3;
+    const double sn = sin_core(r), cs = cos_core(r);
+    double sv = (n & 1) ? cs : sn, cv = (n & 1) ? sn : cs;
+    if (n & 2) sv = -sv;
+    if (n == 1 || n == 2) cv = -cv;
+    *s_out = (float)sv; *c_out = (float)cv;
+}
+
+/* warp.py:238-243: coeff[j] = cos(pi (s - rel_j) / N) * sinc(s - rel_j), rel_j = -N/2+1 .. N/2, all float32 */
+static void sinc_coeffs(float s, int n_taps, float* coef) {
+    const float pi_f = 3.14159265358979323846f;
+    for (int j = 0; j < n_taps; ++j) {
+        const float d = s - (float)(j - n_taps / 2 + 1);
+        float sn, cs_unused, win_s_unused, win;
+        sincos_f32(pi_f * d / (float)n_taps, &win_s_unused, &win);
+        float snc = 1.0f;
+        if (d != 0.0f) { const float a = pi_f * d; sincos_f32(a, &sn, &cs_unused); snc = sn / a; }
+        coef[j] = win * snc;
+    }
+}
+
+/* One warped sample: ref is [3][H][W] float (already 4:4:4), (gx, gy) the integer global translation. */
+static void warp_pixel(const float* ref, int H, int W, int gx, int gy, int n_taps, float fx, float fy, int y, int x, float out[3]) {
+    const float rxf = floorf(fx), ryf = floorf(fy);
+    const float sx = fx - rxf, sy = fy - ryf;
+    const int rx = (int)rxf, ry = (int)ryf;
+    float cx[16], cy[16];
+    sinc_coeffs(sx, n_taps, cx);
+    sinc_coeffs(sy, n_taps, cy);
+    const int lo = -(n_taps / 2) + 1;
+    const size_t plane = (size_t)H * W;
+    for (int c = 0; c < 3; ++c) {
+        float acc = 0.0f;
+        for (int i = 0; i < n_taps; ++i) {
+            /* grid_sample(nearest, border) on the globally shifted reference: two clamps in sequence */
+            const int yy = clip_i(clip_i(y + lo + i + ry, 0, H - 1) + gy, 0, H - 1);
+            float line = 0.0f;
+            for (int j = 0; j < n_taps; ++j) {
+                const int xx = clip_i(clip_i(x + lo + j + rx, 0, W - 1) + gx, 0, W - 1);
+                line = fmaf(ref[c * plane + (size_t)yy * W + xx], cx[j], line);
+            }
+            acc = fmaf(line, cy[i], acc);
+        }
+        out[c] = acc;
+    }
+}
+
+/* decode.py:156-189 for one P / B frame. residue [3+1(+1)][H][W], motion [2(+2)][H][W], refs [3][H][W] each. */
+static void reconstruct_inter(int frame_type, int H, int W, const float* residue, const float* motion, const float* ref0,
+                              const float* ref1, const int* global_flow, int n_taps, float* out /* [3][H][W] */) {
+    const size_t plane = (size_t)H * W;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const size_t p = (size_t)y * W + x;
+            float a = residue[3 * plane + p] + 0.5f;
+            a = a < 0.0f ? 0.0f : (a > 1.0f ? 1.0f : a);
+            float w0[3], pred[3];
+            warp_pixel(ref0, H, W, global_flow[0], global_flow[1], n_taps, motion[p], motion[plane + p], y, x, w0);
+            if (frame_type == 2) {
+                float b = residue[4 * plane + p] + 0.5f;
+                b = b < 0.0f ? 0.0f : (b > 1.0f ? 1.0f : b);
+                float w1[3];
+                warp_pixel(ref1, H, W, global_flow[2], global_flow[3], n_taps, motion[2 * plane + p], motion[3 * plane + p], y, x, w1);
+                for (int c = 0; c < 3; ++c) { const float t0 = b * w0[c], t1 = (1.0f - b) * w1[c]; pred[c] = t0 + t1; }
+            } else {
+                for (int c = 0; c < 3; ++c) pred[c] = w0[c];
+            }
+            for (int c = 0; c < 3; ++c) { const float m = a * pred[c]; out[c * plane + p] = m + residue[c * plane + p]; }
+        }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 12. Whole stream (bitstream/decode.py:26-212).
  * ---------------------------------------------------------------------------------------------- */
 void ora_video_free(ora_video* v) {
     if (!v || !v->frames) return;
@@ -963,71 +1071,120 @@ static uint16_t quantise_sample(float x, float maxv) {
     return (uint16_t)rintf(q * maxv);
 }
 
+/* decode.py:191-206 for a [3][H][W] float frame -> integer planes of `fr` */
+static void finish_frame(const float* img, int H, int W, int bitdepth, int frame_data_type, ora_frame* fr) {
+    const float maxv = (float)((1 << bitdepth) - 1);
+    fr->h = H; fr->w = W;
+    if (frame_data_type == 1) { /* yuv420: decode.py:191-206, yuv.py:274-300 */
+        fr->ch = H / 2; fr->cw = W / 2;
+        fr->plane[0] = (uint16_t*)malloc((size_t)H * W * 2);
+        for (size_t i = 0; i < (size_t)H * W; ++i) fr->plane[0][i] = quantise_sample(img[i], maxv);
+        for (int p = 1; p < 3; ++p) {
+            fr->plane[p] = (uint16_t*)malloc((size_t)fr->ch * fr->cw * 2 + 2);
+            const float* src = img + (size_t)p * H * W;
+            for (int y = 0; y < fr->ch; ++y)
+                for (int x = 0; x < fr->cw; ++x) {
+                    /* round to the bit-depth grid, THEN average (decode.py:191 before :196);
+                     * F.avg_pool2d: sequential f32 sum over the 2x2 window, divided by 4 */
+                    float s = 0.0f;
+                    for (int dy = 0; dy < 2; ++dy)
+                        for (int dx = 0; dx < 2; ++dx)
+                            s += rintf(maxv * src[(size_t)(2 * y + dy) * W + 2 * x + dx]) / maxv;
+                    float a = s / 4.0f;
+                    a = a < 0.0f ? 0.0f : (a > 1.0f ? 1.0f : a);
+                    a = rintf(a * maxv) / maxv;
+                    fr->plane[p][(size_t)y * fr->cw + x] = (uint16_t)rintf(a * maxv);
+                }
+        }
+    } else {
+        fr->ch = H; fr->cw = W;
+        for (int p = 0; p < 3; ++p) {
+            fr->plane[p] = (uint16_t*)malloc((size_t)H * W * 2);
+            const float* src = img + (size_t)p * H * W;
+            for (size_t i = 0; i < (size_t)H * W; ++i) fr->plane[p][i] = quantise_sample(src[i], maxv);
+        }
+    }
+}
+
+/* FrameData of a decoded frame as the [3][H][W] float tensor decode_frame feeds to the warper
+ * (decode.py:159-162: yuv420 references go through convert_420_to_444 = nearest x2 of u and v) */
+static float* frame_as_444(const ora_frame* fr) {
+    const int H = fr->h, W = fr->w;
+    const float maxv = (float)((1 << fr->bitdepth) - 1);
+    float* out = (float*)malloc((size_t)3 * H * W * sizeof(float));
+    for (int p = 0; p < 3; ++p)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const int sy = (p && fr->frame_data_type == 1) ? y >> 1 : y, sx = (p && fr->frame_data_type == 1) ? x >> 1 : x;
+                const int pw = p ? fr->cw : fr->w;
+                out[((size_t)p * H + y) * W + x] = (float)fr->plane[p][(size_t)sy * pw + sx] / maxv;
+            }
+    return out;
+}
+
 int ora_decode_video(const uint8_t* bs, size_t n, ora_video* v) {
     memset(v, 0, sizeof(*v));
     ora_video_header* vh = (ora_video_header*)malloc(sizeof(ora_video_header));
     int used = ora_read_video_header(bs, n, vh);
     if (used < 0) { free(vh); return used; }
-    int n_frames = vh->n_frames, n_intras = vh->n_intras;
+    int n_frames = vh->n_frames;
     free(vh);
-    if (n_frames != n_intras) return ORA_ERR_UNSUPPORTED; /* P/B frames: not restated yet */
     size_t pos = (size_t)used;
     v->n_frames = n_frames;
     v->frames = (ora_frame*)calloc((size_t)n_frames, sizeof(ora_frame));
+    /* frames arrive in coding order; references are named by display index in each frame header
+     * (the reference recomputes them from the coding structure, utils/codingstructure.py:267-436) */
     for (int f = 0; f < n_frames; ++f) {
         ora_frame_header fh;
         used = ora_read_frame_header(bs + pos, n - pos, &fh);
         if (used < 0) return used;
         pos += (size_t)used;
-        if (fh.frame_type != 0) return ORA_ERR_UNSUPPORTED;
-        ora_cc_header ch;
-        used = ora_read_cc_header(bs + pos, n - pos, &ch);
-        if (used < 0) return used;
-        const uint8_t* hdr = bs + pos; size_t n_hdr = (size_t)used;
-        pos += n_hdr;
-        if (pos + (size_t)ch.nn_n_bytes + (size_t)ch.n_bytes_latent > n) return ORA_ERR_TRUNCATED;
-        ora_cc_result r;
-        int rc = ora_decode_coolchic(hdr, n_hdr, bs + pos, (size_t)ch.nn_n_bytes, bs + pos + ch.nn_n_bytes,
-                                     (size_t)ch.n_bytes_latent, 0, &r);
-        pos += (size_t)ch.nn_n_bytes + (size_t)ch.n_bytes_latent;
-        if (rc < 0) { ora_cc_result_free(&r); return rc; }
-        if (fh.display_index >= n_frames || r.out_c < 3) { ora_cc_result_free(&r); return ORA_ERR_VALUE; }
+        if (fh.display_index >= n_frames) return ORA_ERR_VALUE;
+        const int n_cc = fh.frame_type == 0 ? 1 : 2; /* decode.py:126-128: residue (+ motion) */
+        ora_cc_result r[2];
+        memset(r, 0, sizeof(r));
+        int rc = ORA_OK;
+        for (int c = 0; c < n_cc && rc == ORA_OK; ++c) {
+            ora_cc_header ch;
+            used = ora_read_cc_header(bs + pos, n - pos, &ch);
+            if (used < 0) { rc = used; break; }
+            const uint8_t* hdr = bs + pos; size_t n_hdr = (size_t)used;
+            pos += n_hdr;
+            if (pos + (size_t)ch.nn_n_bytes + (size_t)ch.n_bytes_latent > n) { rc = ORA_ERR_TRUNCATED; break; }
+            rc = ora_decode_coolchic(hdr, n_hdr, bs + pos, (size_t)ch.nn_n_bytes, bs + pos + ch.nn_n_bytes,
+                                     (size_t)ch.n_bytes_latent, 0, &r[c]);
+            pos += (size_t)ch.nn_n_bytes + (size_t)ch.n_bytes_latent;
+        }
         ora_frame* fr = &v->frames[fh.display_index];
         fr->display_index = fh.display_index; fr->frame_type = fh.frame_type;
         fr->frame_data_type = fh.frame_data_type; fr->bitdepth = fh.bitdepth;
-        int H = r.out_h, W = r.out_w;
-        fr->h = H; fr->w = W;
-        float maxv = (float)((1 << fh.bitdepth) - 1);
-        if (fh.frame_data_type == 1) { /* yuv420: decode.py:191-206, yuv.py:274-300 */
-            fr->ch = H / 2; fr->cw = W / 2;
-            fr->plane[0] = (uint16_t*)malloc((size_t)H * W * 2);
-            for (size_t i = 0; i < (size_t)H * W; ++i) fr->plane[0][i] = quantise_sample(r.out[i], maxv);
-            for (int p = 1; p < 3; ++p) {
-                fr->plane[p] = (uint16_t*)malloc((size_t)fr->ch * fr->cw * 2 + 2);
-                const float* src = r.out + (size_t)p * H * W;
-                for (int y = 0; y < fr->ch; ++y)
-                    for (int x = 0; x < fr->cw; ++x) {
-                        /* round to the bit-depth grid, THEN average (decode.py:191 before :196);
-                         * F.avg_pool2d: sequential f32 sum over the 2x2 window, divided by 4 */
-                        float s = 0.0f;
-                        for (int dy = 0; dy < 2; ++dy)
-                            for (int dx = 0; dx < 2; ++dx)
-                                s += rintf(maxv * src[(size_t)(2 * y + dy) * W + 2 * x + dx]) / maxv;
-                        float a = s / 4.0f;
-                        a = a < 0.0f ? 0.0f : (a > 1.0f ? 1.0f : a);
-                        a = rintf(a * maxv) / maxv;
-                        fr->plane[p][(size_t)y * fr->cw + x] = (uint16_t)rintf(a * maxv);
-                    }
-            }
-        } else {
-            fr->ch = H; fr->cw = W;
-            for (int p = 0; p < 3; ++p) {
-                fr->plane[p] = (uint16_t*)malloc((size_t)H * W * 2);
-                const float* src = r.out + (size_t)p * H * W;
-                for (size_t i = 0; i < (size_t)H * W; ++i) fr->plane[p][i] = quantise_sample(src[i], maxv);
+        if (rc == ORA_OK) {
+            const int H = r[0].out_h, W = r[0].out_w;
+            if (fh.frame_type == 0) {
+                if (r[0].out_c < 3) rc = ORA_ERR_VALUE;
+                else finish_frame(r[0].out, H, W, fh.bitdepth, fh.frame_data_type, fr);
+            } else {
+                const int need_res = fh.frame_type == 1 ? 4 : 5, need_mot = fh.frame_type == 1 ? 2 : 4;
+                if (r[0].out_c < need_res || r[1].out_c < need_mot || r[1].out_h != H || r[1].out_w != W ||
+                    fh.warp_filter_size < 6 || fh.warp_filter_size > 16) rc = fh.warp_filter_size < 6 ? ORA_ERR_UNSUPPORTED : ORA_ERR_VALUE;
+                float* refs[2] = {NULL, NULL};
+                for (int k = 0; k < fh.n_refs && rc == ORA_OK; ++k) {
+                    const int ri = fh.index_references[k];
+                    if (ri >= n_frames || !v->frames[ri].plane[0] || v->frames[ri].h != H || v->frames[ri].w != W) rc = ORA_ERR_VALUE;
+                    else refs[k] = frame_as_444(&v->frames[ri]);
+                }
+                if (rc == ORA_OK) {
+                    float* img = (float*)malloc((size_t)3 * H * W * sizeof(float));
+                    reconstruct_inter(fh.frame_type, H, W, r[0].out, r[1].out, refs[0], refs[1], fh.global_flow,
+                                      fh.warp_filter_size, img);
+                    finish_frame(img, H, W, fh.bitdepth, fh.frame_data_type, fr);
+                    free(img);
+                }
+                free(refs[0]); free(refs[1]);
             }
         }
-        ora_cc_result_free(&r);
+        ora_cc_result_free(&r[0]); ora_cc_result_free(&r[1]);
+        if (rc < 0) return rc;
     }
     return ORA_OK;
 }
