@@ -24,16 +24,40 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _flags():
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+             # every fused multiply-add of the float stages is an explicit __fmaf_rn (bit parity with the oracle)
+             "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+    if os.environ.get("CCD_PIPE_PROFILE"):
+        flags.append("-DCCD_PIPE_PROFILE")  # cycle counters in the entropy kernel (ccd_batch_slot_stats)
+    return flags
+
+
 def build_lib(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 ... -> cool_chic_amd/libccd.so (cross-compiles without a GPU)."""
+    """hipcc --offload-arch=gfx950 ... -> cool_chic_amd/libccd.so (cross-compiles without a GPU).
+    One object per source (compiled concurrently, rebuilt only when stale), then one link."""
     if not force and not is_stale():
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           # every fused multiply-add of the float stages is an explicit __fmaf_rn (bit parity with the oracle)
-           "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-o", LIB]
-    if os.environ.get("CCD_PIPE_PROFILE"):
-        cmd.append("-DCCD_PIPE_PROFILE")  # cycle counters in the entropy kernel (ccd_batch_slot_stats)
-    cmd += [os.path.join(_HERE, "csrc", s) for s in SOURCES]
+    from concurrent.futures import ThreadPoolExecutor
+
+    obj_dir = os.path.join(_HERE, "csrc", "_obj" + ("_prof" if os.environ.get("CCD_PIPE_PROFILE") else ""))
+    os.makedirs(obj_dir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(os.path.join(_HERE, "csrc", h)) for h in HEADERS + ["../_build.py"])
+
+    def compile_one(src):
+        path = os.path.join(_HERE, "csrc", src)
+        obj = os.path.join(obj_dir, src + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_t):
+            return obj
+        cmd = [_hipcc()] + _flags() + ["-c", path, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -41,4 +65,6 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build_lib(force=True, verbose=True))
+    import sys
+
+    print(build_lib(force="--force" in sys.argv, verbose=True))

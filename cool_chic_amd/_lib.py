@@ -104,6 +104,13 @@ SIGNATURES = {
     "ccd_range_encode": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(_u8p)]),
     "ccd_encode_stream": (C.c_int64, [C.POINTER(CCHeader), C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p), C.c_int,
                                       C.c_int, C.POINTER(_u8p)]),
+    "ccd_encode_coolchic": (C.c_int64, [C.POINTER(CCHeader), C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p),
+                                        C.POINTER(_u8p)]),
+    "ccd_network_layout": (C.c_int, [C.POINTER(CCHeader), C.POINTER(C.c_int64)]),
+    "ccd_encode_network": (C.c_int64, [C.POINTER(CCHeader), C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(_u8p)]),
+    "ccd_write_cc_header": (C.c_int, [C.POINTER(CCHeader), C.c_void_p, C.c_size_t]),
+    "ccd_write_frame_header": (C.c_int, [C.POINTER(FrameHeader), C.c_void_p, C.c_size_t]),
+    "ccd_write_video_header": (C.c_int, [C.POINTER(VideoHeader), C.c_void_p, C.c_size_t]),
     "ccd_free": (None, [C.c_void_p]),
     "ccd_debug_laplace_bounds": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_void_p]),

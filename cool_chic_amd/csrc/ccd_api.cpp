@@ -30,6 +30,11 @@ hipError_t launch_syn_fused(const SynthFused* d_frames, int n_frames, int c_in, 
                             hipStream_t stream);
 hipError_t launch_resize_nearest(const float* in, float* out, int c, int h_in, int w_in, int h_out, int w_out,
                                  hipStream_t stream);
+hipError_t launch_resize_interp(const float* in, float* out, int c, int h_in, int w_in, int h_out, int w_out, int cubic,
+                                float scale_y, float scale_x, hipStream_t stream);
+hipError_t launch_final_resize(const float* in, float* out, int c, int h_in, int w_in, int h_out, int w_out, int mode,
+                               hipStream_t stream);
+hipError_t launch_cr_noise(float* out, size_t n, hipStream_t stream);
 hipError_t launch_planes_to_444(const void* p0, const void* p1, const void* p2, float* out, int h, int w, int bitdepth,
                                 int frame_data_type, hipStream_t stream);
 hipError_t launch_inter_recon(int frame_type, int h, int w, int n_taps, const int* gflow, const float* residue, const float* motion,
@@ -77,6 +82,12 @@ struct Slot {
     std::vector<UpsampleLevel> levels;
     int dense_c = 0, dense_h = 0, dense_w = 0;
     float* d_dense = nullptr;
+    // common randomness (coolchic.py:179-183): noise pyramid + two ping-pong stacks for fixed_upsampling
+    bool cr = false;
+    float* d_noise = nullptr;
+    float* d_nstack[2] = {nullptr, nullptr};
+    std::vector<size_t> noise_off;        // per latent level, finest first
+    std::vector<int> lvl_h, lvl_w;        // latent level sizes, finest first
     // synthesis
     float* d_syn_params = nullptr;
     bool use_fused_syn = false;      // whole synthesis in one kernel (ccd_synth_fused.hip)
@@ -208,7 +219,6 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     if (rc < 0) return rc;
     const ccd_cc_header& h = s.hdr;
     if (n_lat % 4) return CCD_ERR_VALUE;  // np.frombuffer(dtype=uint32) raises (rangecoder.py:81)
-    if (h.flag_common_randomness) return CCD_ERR_UNSUPPORTED;
     rc = decode_network(h, bytes_nn, n_nn, s.net);
     if (rc < 0) return rc;
     s.bitdepth = bitdepth; s.frame_data_type = frame_data_type;
@@ -242,12 +252,14 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     std::vector<int> lat_grids;
     for (int g = 0; g < h.n_grids; ++g) if (!h.is_hyperlatent[g]) lat_grids.push_back(g);
     const int n_levels = static_cast<int>(lat_grids.size());
-    if (n_levels < 1 || n_levels != h.input_feature_synthesis) return CCD_ERR_VALUE;
+    s.cr = h.flag_common_randomness != 0;
+    if (n_levels < 1 || n_levels * (s.cr ? 2 : 1) != h.input_feature_synthesis) return CCD_ERR_VALUE;
     if (n_levels > 1 && net.n_ups < 1) return CCD_ERR_VALUE;
-    s.dense_c = n_levels; s.dense_h = h.grid_h[lat_grids[0]]; s.dense_w = h.grid_w[lat_grids[0]];
+    s.dense_c = h.input_feature_synthesis; s.dense_h = h.grid_h[lat_grids[0]]; s.dense_w = h.grid_w[lat_grids[0]];
     const int H = h.img_size[0], W = h.img_size[1];
     const bool need_resize = (s.dense_h != H || s.dense_w != W);
-    if (need_resize && h.final_upsampling_type != 0) return CCD_ERR_UNSUPPORTED;  // bilinear / bicubic resize
+    // the reference concatenates [.., dense_h, dense_w] with noise resized to img_size: torch.cat raises unless equal
+    if (s.cr && need_resize) return CCD_ERR_VALUE;
     if (bitdepth != 0 && h.out_channels < 3) return CCD_ERR_ARG;
 
     // ---- arena layout --------------------------------------------------------------------------------
@@ -267,8 +279,25 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     }
     const size_t o_feat = A.reserve(feat_px * std::max(h.output_feature_ifce, 1) * 4);
     const size_t o_status = A.reserve(512);
-    const size_t dense_elems = static_cast<size_t>(n_levels) * s.dense_h * s.dense_w;
+    const size_t dense_elems = static_cast<size_t>(s.dense_c) * s.dense_h * s.dense_w;
     const size_t o_stack_a = A.reserve(dense_elems * 4);
+    size_t o_noise = 0, o_nstack[2] = {0, 0};
+    if (s.cr) {
+        size_t n_noise = 0;
+        for (int i = 0; i < n_levels; ++i) {
+            s.lvl_h.push_back(h.grid_h[lat_grids[i]]); s.lvl_w.push_back(h.grid_w[lat_grids[i]]);
+            s.noise_off.push_back(n_noise);
+            n_noise += static_cast<size_t>(s.lvl_h[i]) * s.lvl_w[i];
+        }
+        s.noise_off.push_back(n_noise);
+        o_noise = A.reserve(n_noise * 4);
+        // intermediate stacks: level 1 holds n_levels-1 planes, level 2 n_levels-2 planes (the finest goes to dense)
+        for (int k = 0; k < 2; ++k) {
+            const int lv = k + 1;
+            const size_t elems = lv < n_levels ? static_cast<size_t>(n_levels - lv) * s.lvl_h[lv] * s.lvl_w[lv] : 1;
+            o_nstack[k] = A.reserve(elems * 4);
+        }
+    }
     size_t stack_b_elems = 1;
     if (n_levels >= 3) {
         const int g1 = lat_grids[1];
@@ -295,17 +324,17 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
             ok = L[l].c_in == h.out_channels && L[l].c_out == h.out_channels && (L[l].k & 1) && L[l].k <= 7;
             halo += (L[l].k - 1) / 2;
         }
-        ok = ok && syn_fused_supports(n_levels, h.out_channels, halo) && (!net.syn_stab.c_out || net.syn_stab.c_in <= n_levels);
+        ok = ok && syn_fused_supports(s.dense_c, h.out_channels, halo) && (!net.syn_stab.c_out || net.syn_stab.c_in <= s.dense_c);
         if (ok) {
-            const int cp = ((n_levels + 3) / 4) * 4, C = h.out_channels, N = L[0].c_out;
+            const int cp = ((s.dense_c + 3) / 4) * 4, C = h.out_channels, N = L[0].c_out;
             auto push_padded = [&](const std::vector<float>& w, int rows, int cols) {
                 const size_t off = syn_blob.size();
                 for (int r = 0; r < rows; ++r)
                     for (int c = 0; c < cp; ++c) syn_blob.push_back(c < cols ? w[static_cast<size_t>(r) * cols + c] : 0.0f);
                 return static_cast<int32_t>(off);
             };
-            F.c_in = n_levels; F.c = C; F.n_hidden = N; F.relu0 = L[0].relu; F.relu1 = L[1].relu;
-            F.w0_off = push_padded(L[0].w, N, n_levels); F.b0_off = static_cast<int32_t>(s.b_off[0]);
+            F.c_in = s.dense_c; F.c = C; F.n_hidden = N; F.relu0 = L[0].relu; F.relu1 = L[1].relu;
+            F.w0_off = push_padded(L[0].w, N, s.dense_c); F.b0_off = static_cast<int32_t>(s.b_off[0]);
             F.w1_off = static_cast<int32_t>(s.w_off[1]); F.b1_off = static_cast<int32_t>(s.b_off[1]);
             F.n_conv = static_cast<int32_t>(L.size()) - 2;
             for (int l = 0; l < F.n_conv; ++l) {
@@ -403,6 +432,10 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
         prev = L.out;
     }
     s.d_dense = stack_a;
+    if (s.cr) {
+        s.d_noise = A.at<float>(o_noise);
+        s.d_nstack[0] = A.at<float>(o_nstack[0]); s.d_nstack[1] = A.at<float>(o_nstack[1]);
+    }
     s.d_syn_params = A.at<float>(o_synp);
     s.d_tmp[0] = A.at<float>(o_tmp0); s.d_tmp[1] = A.at<float>(o_tmp1);
     s.d_stab = A.at<float>(o_stab);
@@ -500,7 +533,34 @@ static int upload_params(ccd_batch* b) {
     return CCD_OK;
 }
 
+// Common-randomness planes (coolchic.py:179-183): Gaussian grids at every latent level, then
+// fixed_upsampling(mode="bicubic") coarsest -> finest into channels [n_levels, 2 n_levels) of the dense stack.
+static int run_common_randomness(Slot& s, hipStream_t st) {
+    const int n = static_cast<int>(s.lvl_h.size());
+    HIP_TRY(launch_cr_noise(s.d_noise, s.noise_off[n], st));
+    const size_t plane0 = static_cast<size_t>(s.dense_h) * s.dense_w;
+    // stack at level lv: [target noise lv, upsampled planes of levels lv+1 .. n-1]
+    auto stack_at = [&](int lv) { return lv == 0 ? s.d_dense + static_cast<size_t>(n) * plane0 : s.d_nstack[(lv - 1) & 1]; };
+    const float* cur = s.d_noise + s.noise_off[n - 1];
+    int ch = s.lvl_h[n - 1], cw = s.lvl_w[n - 1], cc = 1;
+    if (n == 1) {
+        HIP_TRY(hipMemcpyAsync(stack_at(0), cur, plane0 * 4, hipMemcpyDeviceToDevice, st));
+        return CCD_OK;
+    }
+    for (int lv = n - 2; lv >= 0; --lv) {
+        const int th = s.lvl_h[lv], tw = s.lvl_w[lv];
+        const size_t tp = static_cast<size_t>(th) * tw;
+        float* dst = stack_at(lv);  // levels >= 3 fit in the alternating level-1 / level-2 stacks (sizes shrink with lv)
+        HIP_TRY(hipMemcpyAsync(dst, s.d_noise + s.noise_off[lv], tp * 4, hipMemcpyDeviceToDevice, st));
+        if (th != ch || tw != cw) HIP_TRY(launch_resize_interp(cur, dst + tp, cc, ch, cw, th, tw, 1, 0.5f, 0.5f, st));
+        else HIP_TRY(hipMemcpyAsync(dst + tp, cur, static_cast<size_t>(cc) * tp * 4, hipMemcpyDeviceToDevice, st));
+        cur = dst; ch = th; cw = tw; ++cc;
+    }
+    return CCD_OK;
+}
+
 static int run_upsampling(Slot& s, hipStream_t st) {
+    if (s.cr) { const int rc = run_common_randomness(s, st); if (rc < 0) return rc; }
     if (s.levels.empty()) {
         const int g = [&] { for (int i = 0; i < s.hdr.n_grids; ++i) if (!s.hdr.is_hyperlatent[i]) return i; return 0; }();
         HIP_TRY(launch_i8_to_f32(s.ep.latent[g], s.d_dense, static_cast<size_t>(s.dense_h) * s.dense_w, st));
@@ -514,7 +574,7 @@ static int run_synthesis(Slot& s, hipStream_t st) {
     const int h = s.dense_h, w = s.dense_w;
     if (s.use_fused_syn) {  // the fused kernel itself was launched for the whole group (ccd_batch_run_stage)
         const int H = s.hdr.img_size[0], W = s.hdr.img_size[1];
-        if (s.d_out != s.d_syn_out) HIP_TRY(launch_resize_nearest(s.d_syn_out, s.d_out, s.hdr.out_channels, h, w, H, W, st));
+        if (s.d_out != s.d_syn_out) HIP_TRY(launch_final_resize(s.d_syn_out, s.d_out, s.hdr.out_channels, h, w, H, W, s.hdr.final_upsampling_type, st));
         if (s.bitdepth && !s.fused.write_planes)
             HIP_TRY(launch_planes(s.d_out, s.d_plane[0], s.d_plane[1], s.d_plane[2], H, W, s.bitdepth, s.frame_data_type, st));
         return CCD_OK;
@@ -538,7 +598,7 @@ static int run_synthesis(Slot& s, hipStream_t st) {
                              net.syn_out.c_out, 1, 0, 0, h, w, st));
     const int H = s.hdr.img_size[0], W = s.hdr.img_size[1];
     if (s.d_out != s.d_syn_out)
-        HIP_TRY(launch_resize_nearest(s.d_syn_out, s.d_out, s.hdr.out_channels, h, w, H, W, st));
+        HIP_TRY(launch_final_resize(s.d_syn_out, s.d_out, s.hdr.out_channels, h, w, H, W, s.hdr.final_upsampling_type, st));
     if (s.bitdepth)
         HIP_TRY(launch_planes(s.d_out, s.d_plane[0], s.d_plane[1], s.d_plane[2], H, W, s.bitdepth, s.frame_data_type, st));
     return CCD_OK;

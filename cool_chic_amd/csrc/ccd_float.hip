@@ -278,6 +278,147 @@ hipError_t launch_resize_nearest(const float* in, float* out, int c, int h_in, i
 }
 
 // -------------------------------------------------------------------------------------------------
+// F.interpolate(mode = bilinear | bicubic, align_corners=False): the final resize when the finest latent
+// is coarser than the picture (coolchic.py:187-189; scale = in / out) and the x2 steps of
+// fixed_upsampling(mode="bicubic") for the common-randomness planes (upsampling.py:556-595; scale 0.5).
+// Same float sequence as the oracle (section 9b): plain ops for coordinates and coefficients,
+// t_j = w_x0 v_0, fmaf(v_i, w_xi, t_j); out = w_y0 t_0, fmaf(t_j, w_yj, out).
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int interp_taps(int dst, int in_size, float scale, int cubic, int idx[4], float wt[4]) {
+    float src = scale * (static_cast<float>(dst) + 0.5f) - 0.5f;
+    if (!cubic && src < 0.0f) src = 0.0f;
+    int i0 = static_cast<int>(floorf(src));
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    float t = src - static_cast<float>(i0);
+    t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+    if (!cubic) {
+        idx[0] = i0; idx[1] = i0 + (i0 < in_size - 1 ? 1 : 0);
+        wt[0] = 1.0f - t; wt[1] = t;
+        return 2;
+    }
+    const float A = -0.75f;
+    const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = (1.0f - t) + 1.0f;
+    wt[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    wt[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+    wt[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    wt[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int v = i0 - 1 + j; idx[j] = v < 0 ? 0 : (v > in_size - 1 ? in_size - 1 : v); }
+    return 4;
+}
+
+__global__ void resize_interp_kernel(const float* __restrict__ in, float* __restrict__ out, int c, int h_in, int w_in,
+                                     int h_out, int w_out, int cubic, float scale_y, float scale_x) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w_out || y >= h_out) return;
+    int iy[4], ix[4];
+    float wy[4], wx[4];
+    const int ny = interp_taps(y, h_in, scale_y, cubic, iy, wy);
+    const int nx = interp_taps(x, w_in, scale_x, cubic, ix, wx);
+    for (int ch = 0; ch < c; ++ch) {
+        const float* plane = in + static_cast<size_t>(ch) * h_in * w_in;
+        float acc = 0.0f;
+        for (int j = 0; j < ny; ++j) {
+            const float* row = plane + static_cast<size_t>(iy[j]) * w_in;
+            float t = row[ix[0]] * wx[0];
+            for (int i = 1; i < nx; ++i) t = __fmaf_rn(row[ix[i]], wx[i], t);
+            acc = j == 0 ? t * wy[0] : __fmaf_rn(t, wy[j], acc);
+        }
+        out[(static_cast<size_t>(ch) * h_out + y) * w_out + x] = acc;
+    }
+}
+
+hipError_t launch_resize_interp(const float* in, float* out, int c, int h_in, int w_in, int h_out, int w_out, int cubic,
+                                float scale_y, float scale_x, hipStream_t stream) {
+    dim3 grid((w_out + 63) / 64, (h_out + 3) / 4);
+    hipLaunchKernelGGL(resize_interp_kernel, grid, dim3(256), 0, stream, in, out, c, h_in, w_in, h_out, w_out, cubic,
+                       scale_y, scale_x);
+    return hipGetLastError();
+}
+
+// coolchic.py:187-189 for any final_upsampling_type (0 nearest, 1 bilinear, 2 bicubic)
+hipError_t launch_final_resize(const float* in, float* out, int c, int h_in, int w_in, int h_out, int w_out, int mode,
+                               hipStream_t stream) {
+    if (mode == 0) return launch_resize_nearest(in, out, c, h_in, w_in, h_out, w_out, stream);
+    return launch_resize_interp(in, out, c, h_in, w_in, h_out, w_out, mode == 2, static_cast<float>(h_in) / static_cast<float>(h_out),
+                                static_cast<float>(w_in) / static_cast<float>(w_out), stream);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Common randomness (component/core/noise.py:17-54): Park-Miller LCG + Box-Muller, evaluated in f64
+// exactly like the oracle (section 9c: fixed fma sequences for log and cos), one thread per sample with a
+// jump-ahead of the generator: sample i uses draws 2i+1 and 2i+2, seed_k = a^k seed_0 mod m.
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double cr_sin_core(double r) {
+    const double r2 = r * r;
+    double p = -7.6471637318198164759e-13;
+    p = fma(p, r2, 1.6059043836821614599e-10);
+    p = fma(p, r2, -2.5052108385441718775e-08);
+    p = fma(p, r2, 2.7557319223985890653e-06);
+    p = fma(p, r2, -1.9841269841269841270e-04);
+    p = fma(p, r2, 8.3333333333333333333e-03);
+    p = fma(p, r2, -1.6666666666666666667e-01);
+    return fma(p * r2, r, r);
+}
+__device__ __forceinline__ double cr_cos_core(double r) {
+    const double r2 = r * r;
+    double p = 4.7794773323873852974e-14;
+    p = fma(p, r2, -1.1470745597729724714e-11);
+    p = fma(p, r2, 2.0876756987868098979e-09);
+    p = fma(p, r2, -2.7557319223985890653e-07);
+    p = fma(p, r2, 2.4801587301587301587e-05);
+    p = fma(p, r2, -1.3888888888888888889e-03);
+    p = fma(p, r2, 4.1666666666666666667e-02);
+    p = fma(p, r2, -0.5);
+    return fma(p, r2, 1.0);
+}
+__device__ __forceinline__ double cr_log(double x) {
+    unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(x));
+    int e = static_cast<int>((bits >> 52) & 0x7ff) - 1022;
+    bits = (bits & 0x000fffffffffffffULL) | 0x3fe0000000000000ULL;
+    double f = __longlong_as_double(static_cast<long long>(bits));
+    if (f < 0.70710678118654752440) { f = f * 2.0; e -= 1; }
+    const double s = __ddiv_rn(f - 1.0, f + 1.0), s2 = s * s;
+    double p = 1.0 / 23.0;
+    p = fma(p, s2, 1.0 / 21.0); p = fma(p, s2, 1.0 / 19.0); p = fma(p, s2, 1.0 / 17.0); p = fma(p, s2, 1.0 / 15.0);
+    p = fma(p, s2, 1.0 / 13.0); p = fma(p, s2, 1.0 / 11.0); p = fma(p, s2, 1.0 / 9.0); p = fma(p, s2, 1.0 / 7.0);
+    p = fma(p, s2, 1.0 / 5.0); p = fma(p, s2, 1.0 / 3.0);
+    const double r = fma(p * s2, 2.0 * s, 2.0 * s);
+    const double ed = static_cast<double>(e);
+    return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, r));
+}
+__device__ __forceinline__ double cr_cos(double x) {
+    const double q = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-q, 1.57079632679489655800e+00, x);
+    r = fma(-q, 6.12323399573676603587e-17, r);
+    const int n = static_cast<int>(q) & 3;
+    const double v = (n & 1) ? cr_sin_core(r) : cr_cos_core(r);
+    return (n == 1 || n == 2) ? -v : v;
+}
+
+__global__ void cr_noise_kernel(float* __restrict__ out, size_t n) {
+    const size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long m = 2147483647ULL;
+    unsigned long long seed = 18101995ULL, pw = 16807ULL;  // seed * a^(2i) mod m by square-and-multiply
+    for (unsigned long long k = 2ULL * i; k; k >>= 1) {
+        if (k & 1ULL) seed = (seed * pw) % m;
+        pw = (pw * pw) % m;
+    }
+    seed = (16807ULL * seed) % m; const double u1 = __ddiv_rn(static_cast<double>(seed), static_cast<double>(m));
+    seed = (16807ULL * seed) % m; const double u2 = __ddiv_rn(static_cast<double>(seed), static_cast<double>(m));
+    const double g = __dsqrt_rn(-2.0 * cr_log(u1)) * cr_cos((2.0 * 3.14159265359) * u2);
+    out[i] = static_cast<float>(g);
+}
+
+hipError_t launch_cr_noise(float* out, size_t n, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(cr_noise_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, out, n);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------------
 // Integer planes of an intra frame (decode.py:191-206 + png.py:57-58 / yuv.py:152-160).
 // -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float round_to_grid(float x, float maxv) { return rintf(maxv * x) / maxv; }

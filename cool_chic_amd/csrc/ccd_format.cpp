@@ -304,7 +304,7 @@ void symmetric_kernel(const int64_t* params, int n_params, int k, float q_step, 
 
 }  // namespace
 
-int decode_network(const ccd_cc_header& h, const uint8_t* bytes_nn, size_t n_nn, Network& net) {
+int network_layout(const ccd_cc_header& h, size_t n_kind[8]) {
     const int dim = h.total_context_arm;
     const int n_arm_layers = h.n_hidden_layers_arm + 1;
     const int n_ifce_out = h.output_feature_ifce;
@@ -314,9 +314,7 @@ int decode_network(const ccd_cc_header& h, const uint8_t* bytes_nn, size_t n_nn,
     const int ups_np = (h.ups_k_size + 1) / 2, pre_np = (h.ups_preconcat_k_size + 1) / 2;
     const int syn_out = h.out_channels, syn_in = h.input_feature_synthesis;
     const int n_stab_in = h.flag_common_randomness ? syn_in / 2 : syn_in;
-
-    // ---- sizes per (module, weight|bias) in stream order --------------------------------------
-    size_t n_kind[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 8; ++k) n_kind[k] = 0;
     for (int l = 0; l < n_arm_layers; ++l) {
         const int out = (l == n_arm_layers - 1) ? 2 : dim;
         n_kind[0] += static_cast<size_t>(out) * dim; n_kind[1] += out;
@@ -328,16 +326,31 @@ int decode_network(const ccd_cc_header& h, const uint8_t* bytes_nn, size_t n_nn,
     n_kind[5] = 2 * static_cast<size_t>(n_ups);
     n_kind[6] = static_cast<size_t>(syn_out) * syn_out + (h.linear_stabiliser_synth ? static_cast<size_t>(syn_out) * n_stab_in : 0);
     n_kind[7] = syn_out + (h.linear_stabiliser_synth ? syn_out : 0);
+    int c_in = syn_in;
+    for (int l = 0; l < h.n_layer_synthesis; ++l) {
+        const ccd_syn_layer& s = h.syn_layer[l];
+        if (s.k_size < 1 || !(s.k_size & 1)) return CCD_ERR_UNSUPPORTED;
+        if (s.mode == 1 && s.out_ft != c_in) return CCD_ERR_VALUE;
+        n_kind[6] += static_cast<size_t>(s.out_ft) * c_in * s.k_size * s.k_size;
+        n_kind[7] += s.out_ft;
+        c_in = s.out_ft;
+    }
+    return CCD_OK;
+}
+
+int decode_network(const ccd_cc_header& h, const uint8_t* bytes_nn, size_t n_nn, Network& net) {
+    const int dim = h.total_context_arm;
+    const int n_arm_layers = h.n_hidden_layers_arm + 1;
+    const int n_ifce_out = h.output_feature_ifce;
+    const int n_ups = h.latent_resolution[1];
+    const int ups_np = (h.ups_k_size + 1) / 2, pre_np = (h.ups_preconcat_k_size + 1) / 2;
+    const int syn_out = h.out_channels, syn_in = h.input_feature_synthesis;
+    const int n_stab_in = h.flag_common_randomness ? syn_in / 2 : syn_in;
+    // ---- sizes per (module, weight|bias) in stream order --------------------------------------
+    size_t n_kind[8];
     {
-        int c_in = syn_in;
-        for (int l = 0; l < h.n_layer_synthesis; ++l) {
-            const ccd_syn_layer& s = h.syn_layer[l];
-            if (s.k_size < 1 || !(s.k_size & 1)) return CCD_ERR_UNSUPPORTED;
-            if (s.mode == 1 && s.out_ft != c_in) return CCD_ERR_VALUE;
-            n_kind[6] += static_cast<size_t>(s.out_ft) * c_in * s.k_size * s.k_size;
-            n_kind[7] += s.out_ft;
-            c_in = s.out_ft;
-        }
+        const int lrc = network_layout(h, n_kind);
+        if (lrc < 0) return lrc;
     }
     std::vector<int> count;
     for (int kind = 0; kind < 8; ++kind) count.insert(count.end(), n_kind[kind], h.nn_expgol_cnt[kind]);

@@ -74,6 +74,8 @@ struct Network {
 
 int decode_exp_golomb(const uint8_t* p, size_t n, int n_pad_bits, const std::vector<int>& count,
                       std::vector<int64_t>& out);
+// Number of transmitted integers per (module, weight|bias) group, stream order (types.py:18-19,98-101).
+int network_layout(const ccd_cc_header& h, size_t n_kind[8]);
 int decode_network(const ccd_cc_header& h, const uint8_t* bytes_nn, size_t n_nn, Network& net);
 
 // Context template: (dy, dx) of the n highest-priority causal neighbours, component/core/arm.py:493-562.

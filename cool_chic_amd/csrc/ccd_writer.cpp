@@ -133,19 +133,51 @@ std::vector<uint8_t> cc_header_bytes(const ccd_cc_header& h, int n_bytes_latent)
     return emit(static_cast<int>(n_bytes)).bytes();
 }
 
+std::vector<uint8_t> frame_header_bytes(const ccd_frame_header& f) {
+    auto emit = [&](int n_bytes_header) {
+        BitWriter w;
+        w.put(f.display_index, 12); w.put(f.frame_type, 2); w.put(f.frame_data_type, 2); w.put(f.bitdepth - 8, 4);
+        w.put(n_bytes_header, 16);
+        const int n_refs = f.frame_type;  // I 0, P 1, B 2 (header.py:189-218)
+        if (n_refs > 0) {
+            for (int r = 0; r < n_refs; ++r) w.put(f.index_references[r], 12);
+            for (int r = 0; r < 2 * n_refs; ++r) w.put_sign_magnitude(f.global_flow[r], 14);
+            w.put(f.warp_filter_size, 4);
+        }
+        return w;
+    };
+    const size_t n_bytes = (emit(0).n_bits() + 7) / 8;
+    return emit(static_cast<int>(n_bytes)).bytes();
+}
+
 std::vector<uint8_t> frame_header_bytes(int display_index, int bitdepth, int frame_data_type) {
-    BitWriter w;
-    w.put(display_index, 12); w.put(0 /* I */, 2); w.put(frame_data_type, 2); w.put(bitdepth - 8, 4);
-    w.put(5, 16);  // 36 bits -> 5 bytes; an intra frame has no variable part
-    return w.bytes();
+    ccd_frame_header f{};
+    f.display_index = display_index; f.frame_type = 0; f.frame_data_type = frame_data_type; f.bitdepth = bitdepth;
+    return frame_header_bytes(f);
+}
+
+std::vector<uint8_t> video_header_bytes(const ccd_video_header& v) {
+    auto emit = [&](int n_bytes_header) {
+        BitWriter w;
+        w.put(v.n_frames, 12); w.put(v.n_intras, 12); w.put(v.n_p_frames, 12); w.put(n_bytes_header, 16);
+        for (int i = 0; i < v.n_intras; ++i) w.put(v.intra_pos[i], 12);
+        for (int i = 0; i < v.n_p_frames; ++i) w.put(v.p_pos[i], 12);
+        return w;
+    };
+    const size_t n_bytes = (emit(0).n_bits() + 7) / 8;
+    return emit(static_cast<int>(n_bytes)).bytes();
 }
 
 std::vector<uint8_t> video_header_bytes_one_intra() {
-    BitWriter w;
-    w.put(1, 12); w.put(1, 12); w.put(0, 12);
-    w.put(8, 16);  // 52 + 12 bits -> 8 bytes
-    w.put(0, 12);  // intra_pos = [0]
-    return w.bytes();
+    static ccd_video_header v;  // 32 KB: keep it off the stack
+    v.n_frames = 1; v.n_intras = 1; v.n_p_frames = 0; v.intra_pos[0] = 0;
+    return video_header_bytes(v);
+}
+
+// Serialise / parse round trip: fills the derived geometry from the transmitted fields of `tmpl`.
+int rederive(const ccd_cc_header& tmpl, ccd_cc_header* h) {
+    const std::vector<uint8_t> hb = cc_header_bytes(tmpl, 0);
+    return read_cc_header(hb.data(), hb.size(), h);
 }
 
 // armint.py:180-203 on the host (writer side only).
@@ -196,16 +228,88 @@ int64_t ccd_range_encode(const int8_t* symbols, const int32_t* mu_idx, const int
     return *out ? n_bytes : CCD_ERR_NOMEM;
 }
 
-int64_t ccd_encode_stream(const ccd_cc_header* tmpl, const uint8_t* bytes_nn, size_t n_nn,
-                          const int8_t* const* latents, int bitdepth, int frame_data_type, uint8_t** out) {
-    if (!tmpl || !bytes_nn || !latents || !out || bitdepth < 8 || bitdepth > 16) return CCD_ERR_ARG;
+int ccd_network_layout(const ccd_cc_header* arch, int64_t n_values[8]) {
+    if (!arch || !n_values) return CCD_ERR_ARG;
+    ccd_cc_header h;
+    int rc = rederive(*arch, &h);
+    if (rc < 0) return rc;
+    size_t n_kind[8];
+    rc = network_layout(h, n_kind);
+    if (rc < 0) return rc;
+    for (int k = 0; k < 8; ++k) n_values[k] = static_cast<int64_t>(n_kind[k]);
+    return CCD_OK;
+}
+
+int64_t ccd_encode_network(const ccd_cc_header* arch, const int32_t* values, int64_t n_values, int32_t* n_bit_pad,
+                           uint8_t** out) {
+    if (!arch || !values || !n_bit_pad || !out) return CCD_ERR_ARG;
+    int64_t n_kind[8];
+    const int rc = ccd_network_layout(arch, n_kind);
+    if (rc < 0) return rc;
+    int64_t total = 0;
+    for (int k = 0; k < 8; ++k) { total += n_kind[k]; if (arch->nn_expgol_cnt[k] < 0 || arch->nn_expgol_cnt[k] > 15) return CCD_ERR_VALUE; }
+    if (total != n_values) return CCD_ERR_ARG;
+    // expgolomb.py:45-62: sign folded into the LSB, then x + 2^count in binary with (bit length - 1 - count) leading zeros
+    BitWriter w;
+    const int32_t* v = values;
+    for (int k = 0; k < 8; ++k) {
+        const int count = arch->nn_expgol_cnt[k];
+        for (int64_t i = 0; i < n_kind[k]; ++i, ++v) {
+            const uint64_t x = *v <= 0 ? static_cast<uint64_t>(-2 * static_cast<int64_t>(*v)) : static_cast<uint64_t>(2 * static_cast<int64_t>(*v) - 1);
+            const uint64_t y = x + (uint64_t{1} << count);
+            int len = 0;
+            while ((y >> len) > 1) ++len;  // floor(log2 y)
+            w.put(0, len - count);
+            w.put(y, len + 1);
+        }
+    }
+    const int pad = static_cast<int>((8 - w.n_bits() % 8) % 8);
+    BitWriter full;
+    full.put(0, pad);
+    const std::vector<uint8_t> body = w.bytes();  // re-emit behind the prefix padding (expgolomb.py:64-67)
+    for (size_t i = 0; i < w.n_bits(); ++i) full.put((body[i >> 3] >> (7 - (i & 7))) & 1, 1);
+    const std::vector<uint8_t> bytes = full.bytes();
+    uint8_t* p = static_cast<uint8_t*>(std::malloc(bytes.size() + 1));
+    if (!p) return CCD_ERR_NOMEM;
+    std::memcpy(p, bytes.data(), bytes.size());
+    *n_bit_pad = pad;
+    *out = p;
+    return static_cast<int64_t>(bytes.size());
+}
+
+int ccd_write_cc_header(const ccd_cc_header* h, uint8_t* out, size_t cap) {
+    if (!h || !out || h->n_layer_synthesis < 1 || h->n_layer_synthesis > CCD_MAX_SYN_LAYERS) return CCD_ERR_ARG;
+    const std::vector<uint8_t> b = cc_header_bytes(*h, h->n_bytes_latent);
+    if (b.size() > cap) return CCD_ERR_ARG;
+    std::memcpy(out, b.data(), b.size());
+    return static_cast<int>(b.size());
+}
+
+int ccd_write_frame_header(const ccd_frame_header* f, uint8_t* out, size_t cap) {
+    if (!f || !out || f->frame_type < 0 || f->frame_type > 2 || f->bitdepth < 8 || f->bitdepth > 16) return CCD_ERR_ARG;
+    const std::vector<uint8_t> b = frame_header_bytes(*f);
+    if (b.size() > cap) return CCD_ERR_ARG;
+    std::memcpy(out, b.data(), b.size());
+    return static_cast<int>(b.size());
+}
+
+int ccd_write_video_header(const ccd_video_header* v, uint8_t* out, size_t cap) {
+    if (!v || !out || v->n_intras < 0 || v->n_intras > 4096 || v->n_p_frames < 0 || v->n_p_frames > 4096) return CCD_ERR_ARG;
+    const std::vector<uint8_t> b = video_header_bytes(*v);
+    if (b.size() > cap) return CCD_ERR_ARG;
+    std::memcpy(out, b.data(), b.size());
+    return static_cast<int>(b.size());
+}
+
+int64_t ccd_encode_coolchic(const ccd_cc_header* tmpl, const uint8_t* bytes_nn, size_t n_nn, const int8_t* const* latents,
+                            uint8_t** out) {
+    if (!tmpl || !bytes_nn || !latents || !out) return CCD_ERR_ARG;
     // Re-derive the geometry from the transmitted fields by a serialise/parse round trip.
     ccd_cc_header h;
     {
         ccd_cc_header t = *tmpl;
         t.nn_n_bytes = static_cast<int32_t>(n_nn);
-        const std::vector<uint8_t> hb = cc_header_bytes(t, 0);
-        const int rc = read_cc_header(hb.data(), hb.size(), &h);
+        const int rc = rederive(t, &h);
         if (rc < 0) return rc;
     }
     Network net;
@@ -273,19 +377,34 @@ int64_t ccd_encode_stream(const ccd_cc_header* tmpl, const uint8_t* bytes_nn, si
     }
     const std::vector<uint32_t> words = enc.sealed();
     const int n_bytes_latent = static_cast<int>(words.size() * 4);
-    const std::vector<uint8_t> vh = video_header_bytes_one_intra();
-    const std::vector<uint8_t> fh = frame_header_bytes(0, bitdepth, frame_data_type);
     const std::vector<uint8_t> ch = cc_header_bytes(h, n_bytes_latent);
-    const size_t total = vh.size() + fh.size() + ch.size() + n_nn + static_cast<size_t>(n_bytes_latent);
+    const size_t total = ch.size() + n_nn + static_cast<size_t>(n_bytes_latent);
     uint8_t* p = static_cast<uint8_t*>(std::malloc(total + 4));
     if (!p) return CCD_ERR_NOMEM;
     size_t pos = 0;
-    std::memcpy(p + pos, vh.data(), vh.size()); pos += vh.size();
-    std::memcpy(p + pos, fh.data(), fh.size()); pos += fh.size();
     std::memcpy(p + pos, ch.data(), ch.size()); pos += ch.size();
     std::memcpy(p + pos, bytes_nn, n_nn); pos += n_nn;
     for (size_t i = 0; i < words.size(); ++i)
         for (int k = 0; k < 4; ++k) p[pos + 4 * i + k] = static_cast<uint8_t>(words[i] >> (8 * k));
+    *out = p;
+    return static_cast<int64_t>(total);
+}
+
+int64_t ccd_encode_stream(const ccd_cc_header* tmpl, const uint8_t* bytes_nn, size_t n_nn,
+                          const int8_t* const* latents, int bitdepth, int frame_data_type, uint8_t** out) {
+    if (!out || bitdepth < 8 || bitdepth > 16) return CCD_ERR_ARG;
+    uint8_t* cc = nullptr;
+    const int64_t n_cc = ccd_encode_coolchic(tmpl, bytes_nn, n_nn, latents, &cc);
+    if (n_cc < 0) return n_cc;
+    const std::vector<uint8_t> vh = video_header_bytes_one_intra();
+    const std::vector<uint8_t> fh = frame_header_bytes(0, bitdepth, frame_data_type);
+    const size_t total = vh.size() + fh.size() + static_cast<size_t>(n_cc);
+    uint8_t* p = static_cast<uint8_t*>(std::malloc(total + 4));
+    if (!p) { std::free(cc); return CCD_ERR_NOMEM; }
+    std::memcpy(p, vh.data(), vh.size());
+    std::memcpy(p + vh.size(), fh.data(), fh.size());
+    std::memcpy(p + vh.size() + fh.size(), cc, static_cast<size_t>(n_cc));
+    std::free(cc);
     *out = p;
     return static_cast<int64_t>(total);
 }

@@ -189,6 +189,23 @@ int64_t ccd_range_encode(const int8_t* symbols, const int32_t* mu_idx, const int
  * Kodak/CLIC/4K-shaped inputs; never used while decoding. */
 int64_t ccd_encode_stream(const ccd_cc_header* tmpl, const uint8_t* bytes_nn, size_t n_nn,
                           const int8_t* const* latents, int bitdepth, int frame_data_type, uint8_t** out);
+/* The cool-chic part alone (cool-chic header + NN payload + range-coded latents), for multi-frame /
+ * multi-cool-chic streams assembled by the caller (bitstream/encode.py:83-92). */
+int64_t ccd_encode_coolchic(const ccd_cc_header* tmpl, const uint8_t* bytes_nn, size_t n_nn,
+                            const int8_t* const* latents, uint8_t** out);
+/* Number of transmitted integers per (module, weight|bias) group for the architecture in `arch` (only the
+ * transmitted fields are read), order arm.w arm.b ifce.w ifce.b ups.w ups.b syn.w syn.b
+ * (component/core/types.py:18-19,98-101; neuralnet.py:46-71). */
+int ccd_network_layout(const ccd_cc_header* arch, int64_t n_values[8]);
+/* Exp-Golomb NN payload writer: encode_network + encode_exp_golomb (neuralnet.py:27-90, expgolomb.py:15-71).
+ * `values` = the quantised parameters in stream order, orders taken from arch->nn_expgol_cnt.  Returns the
+ * byte count (malloc'ed *out, free with ccd_free); *n_bit_pad = prefix padding bits for the header. */
+int64_t ccd_encode_network(const ccd_cc_header* arch, const int32_t* values, int64_t n_values, int32_t* n_bit_pad,
+                           uint8_t** out);
+/* Header writers, AbstractHeader.to_bytes (header.py:90-105); n_bytes_header is computed. Return bytes written. */
+int ccd_write_cc_header(const ccd_cc_header* h, uint8_t* out, size_t cap); /* transmitted fields only */
+int ccd_write_frame_header(const ccd_frame_header* f, uint8_t* out, size_t cap);
+int ccd_write_video_header(const ccd_video_header* v, uint8_t* out, size_t cap);
 void ccd_free(void* p);
 
 /* Leaky-quantised-Laplace boundaries computed ON THE GPU for a list of (mu_idx, scale_idx, s):

@@ -700,6 +700,109 @@ static void syn_conv(const float* in, int cin, int h, int w, const float* wt, co
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * 9b. F.interpolate(mode = "bilinear" | "bicubic", align_corners=False) as the decoder uses it: the final
+ *     resize (coolchic.py:187-189, scale = in / out) and the x2 steps of fixed_upsampling (upsampling.py:556-595,
+ *     scale_factor=2 -> scale 0.5).  Index / weight rules follow ATen's UpSample.h (area_pixel_compute_source_index,
+ *     guard_index_and_lambda, get_cubic_upsample_coefficients with A = -0.75), all in float32.
+ *     Canon of this build: plain float ops for the coordinates and coefficients (no contraction), then
+ *     row value t_j = w_x0 * v_0, t_j = fmaf(v_i, w_xi, t_j) (taps ascending) and out = w_y0 * t_0,
+ *     out = fmaf(t_j, w_yj, out).
+ * ---------------------------------------------------------------------------------------------- */
+static int interp_taps(int dst, int in_size, float scale, int cubic, int idx[4], float wt[4]) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (!cubic && src < 0.0f) src = 0.0f;
+    int i0 = (int)floorf(src);
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    float t = src - (float)i0;
+    t = t < 0.0f ? 0.0f : (t > 1.0f ? 1.0f : t);
+    if (!cubic) {
+        idx[0] = i0; idx[1] = i0 + (i0 < in_size - 1 ? 1 : 0);
+        wt[0] = 1.0f - t; wt[1] = t;
+        return 2;
+    }
+    const float A = -0.75f;
+    const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = (1.0f - t) + 1.0f;
+    wt[0] = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+    wt[1] = ((A + 2.0f) * x1 - (A + 3.0f)) * x1 * x1 + 1.0f;
+    wt[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+    wt[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+    for (int j = 0; j < 4; ++j) idx[j] = clip_i(i0 - 1 + j, 0, in_size - 1);
+    return 4;
+}
+
+/* in [c][h][w] -> out [c][H][W] (only the H x W top-left outputs of the virtual out_h x out_w result exist) */
+static void resize_interp(const float* in, int c, int h, int w, float* out, int H, int W, int cubic, float scale_y, float scale_x) {
+    for (int ch = 0; ch < c; ++ch)
+        for (int y = 0; y < H; ++y) {
+            int iy[4]; float wy[4];
+            const int ny = interp_taps(y, h, scale_y, cubic, iy, wy);
+            for (int x = 0; x < W; ++x) {
+                int ix[4]; float wx[4];
+                const int nx = interp_taps(x, w, scale_x, cubic, ix, wx);
+                float acc = 0.0f;
+                for (int j = 0; j < ny; ++j) {
+                    const float* row = in + ((size_t)ch * h + iy[j]) * w;
+                    float t = row[ix[0]] * wx[0];
+                    for (int i = 1; i < nx; ++i) t = fmaf(row[ix[i]], wx[i], t);
+                    acc = j == 0 ? t * wy[0] : fmaf(t, wy[j], acc);
+                }
+                out[((size_t)ch * H + y) * W + x] = acc;
+            }
+        }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * 9c. Common randomness (component/core/noise.py:17-54; coolchic.py:1058-1061; coolchic.py(bitstream):179-183)
+ *     Park-Miller LCG (seed 18101995, a = 7^5, m = 2^31 - 1), two draws per sample, Box-Muller in Python
+ *     floats (f64), rounded to f32; one grid per latent level, finest first, row-major.
+ *     Canon of this build: log and cos are restated with fixed fma sequences (< 2 ulp of f64, so the
+ *     f32-rounded sample equals CPython's in all but ~1e-8 of the cases); the HIP kernel runs the same sequences.
+ * ---------------------------------------------------------------------------------------------- */
+static double sin_core(double r);
+static double cos_core(double r);
+
+static double cr_log(double x) { /* x normal, positive */
+    uint64_t bits; memcpy(&bits, &x, 8);
+    int e = (int)((bits >> 52) & 0x7ff) - 1022;
+    bits = (bits & 0x000fffffffffffffULL) | 0x3fe0000000000000ULL;
+    double f; memcpy(&f, &bits, 8); /* [0.5, 1) */
+    if (f < 0.70710678118654752440) { f = f * 2.0; e -= 1; }
+    const double s = (f - 1.0) / (f + 1.0), s2 = s * s;
+    double p = 1.0 / 23.0;
+    p = fma(p, s2, 1.0 / 21.0); p = fma(p, s2, 1.0 / 19.0); p = fma(p, s2, 1.0 / 17.0); p = fma(p, s2, 1.0 / 15.0);
+    p = fma(p, s2, 1.0 / 13.0); p = fma(p, s2, 1.0 / 11.0); p = fma(p, s2, 1.0 / 9.0); p = fma(p, s2, 1.0 / 7.0);
+    p = fma(p, s2, 1.0 / 5.0); p = fma(p, s2, 1.0 / 3.0);
+    const double r = fma(p * s2, 2.0 * s, 2.0 * s); /* 2 atanh(s) */
+    const double ed = (double)e;
+    return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, r)); /* ln2 hi, lo (fdlibm) */
+}
+
+static double cr_cos(double x) { /* 0 <= x < 8 */
+    const double q = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-q, 1.57079632679489655800e+00, x);
+    r = fma(-q, 6.12323399573676603587e-17, r);
+    const int n = (int)q & 3;
+    const double v = (n & 1) ? sin_core(r) : cos_core(r);
+    return (n == 1 || n == 2) ? -v : v;
+}
+
+static void cr_noise(float* out, size_t n);
+void ora_debug_cr_noise(float* out, size_t n) { cr_noise(out, n); }
+void ora_debug_resize(const float* in, int c, int h, int w, float* out, int H, int W, int cubic, float scale_y, float scale_x) {
+    resize_interp(in, c, h, w, out, H, W, cubic, scale_y, scale_x);
+}
+static void cr_noise(float* out, size_t n) {
+    uint64_t seed = 18101995ULL;
+    const uint64_t a = 16807ULL, m = 2147483647ULL;
+    for (size_t i = 0; i < n; ++i) {
+        seed = (a * seed) % m; const double u1 = (double)seed / (double)m;
+        seed = (a * seed) % m; const double u2 = (double)seed / (double)m;
+        const double g = sqrt(-2.0 * cr_log(u1)) * cr_cos((2.0 * 3.14159265359) * u2);
+        out[i] = (float)g;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
  * 10. One cool-chic (bitstream/component/coolchic.py:29-207, decode mode)
  * ---------------------------------------------------------------------------------------------- */
 void ora_cc_result_free(ora_cc_result* r) {
@@ -851,7 +954,6 @@ int ora_decode_coolchic(const uint8_t* cc_header, size_t n_hdr, const uint8_t* b
     r->words_consumed = rc.pos;
     if (rcod < 0) return rcod;
     if (stop_after_entropy) return ORA_OK;
-    if (h->flag_common_randomness) return ORA_ERR_UNSUPPORTED; /* noise.py path: not restated yet */
 
     /* ---- Upsampling.forward on the non-hyper grids: coolchic.py:175-177 */
     int lat_idx[ORA_MAX_GRIDS], n_lat_lv = 0;
@@ -883,6 +985,34 @@ int ora_decode_coolchic(const uint8_t* cc_header, size_t n_hdr, const uint8_t* b
         preconv(tgt, th, tw, wbuf, h->ups_preconcat_k_size, nxt); /* channel 0 = high branch */
         free(tgt); free(cur);
         cur = nxt; ch = th; cw = tw; cc++;
+    }
+    if (h->flag_common_randomness) { /* coolchic.py:179-183 */
+        /* torch.cat of [.., H_lo, W_lo] with the noise resized to img_size fails unless the sizes agree */
+        if (ch != h->img_size[0] || cw != h->img_size[1]) { free(cur); return ORA_ERR_VALUE; }
+        size_t n_noise = 0;
+        for (int i = 0; i < n_lat_lv; ++i) n_noise += (size_t)g->grid_h[lat_idx[i]] * g->grid_w[lat_idx[i]];
+        float* noise = (float*)malloc(n_noise * sizeof(float));
+        cr_noise(noise, n_noise); /* size_per_latent_cr: finest level first (coolchic.py:187-191) */
+        size_t* off = (size_t*)calloc((size_t)n_lat_lv + 1, sizeof(size_t));
+        for (int i = 0, o = 0; i < n_lat_lv; ++i) { off[i] = (size_t)o; o += g->grid_h[lat_idx[i]] * g->grid_w[lat_idx[i]]; }
+        /* fixed_upsampling(mode="bicubic"): coarsest first, x2 + crop, cat((target, x)) */
+        int nh = g->grid_h[lat_idx[n_lat_lv - 1]], nw = g->grid_w[lat_idx[n_lat_lv - 1]], nc = 1;
+        float* ncur = (float*)malloc((size_t)nh * nw * sizeof(float));
+        memcpy(ncur, noise + off[n_lat_lv - 1], (size_t)nh * nw * sizeof(float));
+        for (int lv = n_lat_lv - 2; lv >= 0; --lv) {
+            const int th = g->grid_h[lat_idx[lv]], tw = g->grid_w[lat_idx[lv]];
+            float* nn = (float*)malloc((size_t)(nc + 1) * th * tw * sizeof(float));
+            memcpy(nn, noise + off[lv], (size_t)th * tw * sizeof(float));
+            if (th != nh || tw != nw) resize_interp(ncur, nc, nh, nw, nn + (size_t)th * tw, th, tw, 1, 0.5f, 0.5f);
+            else memcpy(nn + (size_t)th * tw, ncur, (size_t)nc * th * tw * sizeof(float));
+            free(ncur); ncur = nn; nh = th; nw = tw; nc++;
+        }
+        /* F.interpolate(size=img_size, "bicubic") at equal sizes is the identity (coefficients 0, 1, 0, 0) */
+        float* both = (float*)malloc((size_t)(cc + nc) * ch * cw * sizeof(float));
+        memcpy(both, cur, (size_t)cc * ch * cw * sizeof(float));
+        memcpy(both + (size_t)cc * ch * cw, ncur, (size_t)nc * ch * cw * sizeof(float));
+        free(cur); free(ncur); free(noise); free(off);
+        cur = both; cc += nc;
     }
     r->dense = cur; r->dense_c = cc; r->dense_h = ch; r->dense_w = cw;
     if (cc != g->input_feature_synthesis) return ORA_ERR_VALUE;
@@ -940,7 +1070,9 @@ int ora_decode_coolchic(const uint8_t* cc_header, size_t n_hdr, const uint8_t* b
             for (int yy = 0; yy < H; ++yy)
                 for (int xx = 0; xx < W; ++xx)
                     r->out[((size_t)c * H + yy) * W + xx] = x[c * plane + (size_t)nearest_src(yy, ch, H) * cw + nearest_src(xx, cw, W)];
-    } else return ORA_ERR_UNSUPPORTED;
+    } else { /* bilinear / bicubic, scale = in / out as float (UpSample.h: area_pixel_compute_scale) */
+        resize_interp(x, so, ch, cw, r->out, H, W, h->final_upsampling_type == 2, (float)ch / (float)H, (float)cw / (float)W);
+    }
     return ORA_OK;
 }
 

@@ -162,4 +162,8 @@ void ora_rc_encoder_free(ora_rc_encoder* e);
 #ifdef __cplusplus
 }
 #endif
+/* debug hooks for the unit tests of sections 9b / 9c */
+void ora_debug_cr_noise(float* out, size_t n);
+void ora_debug_resize(const float* in, int c, int h, int w, float* out, int H, int W, int cubic, float scale_y, float scale_x);
+
 #endif

@@ -10,8 +10,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-IMAGE_STREAMS = ["kodim14", "rgb192", "yuv420_8b", "yuv420_10b", "yuv444_10b"]
-SMALL_STREAMS = ["rgb192", "yuv420_8b", "yuv420_10b", "yuv444_10b"]
+IMAGE_STREAMS = ["kodim14", "rgb192", "yuv420_8b", "yuv420_10b", "yuv444_10b", "cr192", "bicubic190", "bilinear190"]
+SMALL_STREAMS = ["rgb192", "yuv420_8b", "yuv420_10b", "yuv444_10b", "cr192", "bicubic190", "bilinear190"]
 
 
 def pytest_configure(config):

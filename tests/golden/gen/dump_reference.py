@@ -131,6 +131,7 @@ def main():
 
     def hook_syn(self, x):
         r = orig_syn_fwd(self, x)
+        cur["dense"] = x.detach().numpy().astype(np.float32)[0]  # synthesis input (latent planes [+ noise planes])
         cur["syn_out"] = r.detach().numpy().astype(np.float32)[0]
         return r
 
