@@ -88,6 +88,7 @@ SIGNATURES = {
     "ccd_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ccd_batch_slot_status": (C.c_int, [C.c_void_p, C.c_int]),
     "ccd_batch_slot_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "ccd_batch_slot_kernels": (C.c_int, [C.c_void_p, C.c_int]),
     "ccd_batch_output": (C.c_void_p, [C.c_void_p, C.c_int]),
     "ccd_batch_dense": (C.c_void_p, [C.c_void_p, C.c_int]),
     "ccd_batch_latent": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),

@@ -72,6 +72,10 @@ class DecodeBatch:
         return lib().ccd_batch_slot_status(self._h, slot)
 
     # ---- results -------------------------------------------------------------------------------
+    def slot_kernels(self, slot: int) -> int:
+        """bit 0: pipelined entropy kernel, bit 1: fused synthesis kernel."""
+        return check(lib().ccd_batch_slot_kernels(self._h, slot), "ccd_batch_slot_kernels")
+
     def latent(self, slot: int, grid: int) -> np.ndarray:
         h = self.header(slot)
         out = np.empty((h.grid_h[grid], h.grid_w[grid]), dtype=np.int8)

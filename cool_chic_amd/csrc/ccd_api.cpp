@@ -660,6 +660,12 @@ int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64) {
     return CCD_OK;
 }
 
+int ccd_batch_slot_kernels(const ccd_batch* b, int slot) {
+    if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
+    const Slot& s = *b->slots[slot];
+    return (s.use_pipe ? 1 : 0) | (s.use_fused_syn ? 2 : 0);
+}
+
 const float* ccd_batch_output(const ccd_batch* b, int slot) {
     return (b && slot >= 0 && slot < static_cast<int>(b->slots.size())) ? b->slots[slot]->d_out : nullptr;
 }

@@ -154,7 +154,11 @@ def adapt_network(donor: CCHeader, donor_ints: np.ndarray, arch: CCHeader, noise
             fin_d = [f for f in donor.input_features_ifce[:donor.n_grids] if f > 0]
             w0 = d[k][:n_out * fin_d[0]].reshape(donor.output_feature_ifce, fin_d[0])
             w0 = w0[np.arange(n_out) % w0.shape[0]]
-            out.append(np.concatenate([_cycle_cols(w0, f).ravel() for f in arch.input_features_ifce[:arch.n_grids] if f > 0]))
+            def grown(f):  # inputs the donor never saw (more, coarser grids) get a quarter of the weight
+                w = _cycle_cols(w0, f).astype(np.float64)
+                w[:, w0.shape[1]:] *= 0.25
+                return np.round(w).astype(np.int64).ravel()
+            out.append(np.concatenate([grown(f) for f in arch.input_features_ifce[:arch.n_grids] if f > 0]))
         elif k == 4:  # ups.w: n_ups x (k/2) transposed-conv halves, then n_ups x ceil(k_pre/2)
             nd, na = donor.latent_resolution[1], arch.latent_resolution[1]
             if (donor.ups_k_size, donor.ups_preconcat_k_size) != (arch.ups_k_size, arch.ups_preconcat_k_size):

@@ -135,6 +135,9 @@ int ccd_batch_slot_status(const ccd_batch* b, int slot);
  * [2..3] symbols decoded (lo, hi); [4..63] profiling cycle counters when built with -DCCD_PIPE_PROFILE.
  * `out64` receives 64 words. */
 int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64);
+/* Which kernels serve this slot: bit 0 = pipelined entropy kernel (else the generic int64 one),
+ * bit 1 = fused synthesis kernel (else one launch per layer). */
+int ccd_batch_slot_kernels(const ccd_batch* b, int slot);
 
 /* Device pointers of a slot's results (valid until the batch is destroyed / re-run): */
 const float* ccd_batch_output(const ccd_batch* b, int slot);    /* [C][H][W] f32, synthesis output */

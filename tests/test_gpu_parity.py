@@ -264,3 +264,46 @@ def test_video_ipb_parity(gpu, oracle, tmp_path):
     raw = np.fromfile(out_yuv, dtype=np.uint8)
     expect = np.concatenate([np.concatenate([p.astype(np.uint8).ravel() for p in want[i]["planes"]]) for i in range(5)])
     assert np.array_equal(raw, expect)
+
+
+FULL_SIZE = {
+    # CLIC-2K picture, latent 0-7 + hyperlatent 4-7 (12 grids)
+    "clic2k": dict(img_size=(1365, 2048), latent_resolution=(0, 7), hyperlatent_resolution=(4, 7), n_latent_grids=12),
+    # 3840x2160, latent 0-8 + hyperlatent 4-8 (14 grids, 11.1 M symbols)
+    "uhd4k": dict(img_size=(2160, 3840), latent_resolution=(0, 8), hyperlatent_resolution=(4, 8), n_latent_grids=14),
+}
+
+
+@pytest.mark.parametrize("name", list(FULL_SIZE))
+def test_full_size_configs(gpu, oracle, name):
+    """BASELINE.json configs 2 and 4 at their full sizes: kodim14's trained networks grown to 12 / 14 grids,
+    tiled real latents, written with the bitstream writer.  Round trip (every decoded grid equals the encoded
+    one) plus integer planes bit-exact against the oracle."""
+    import time
+
+    from cool_chic_amd import writer
+
+    bs, z, _ = load_golden("kodim14")
+    hdr, _, _ = oracle.split_stream(bs)[1][0][1][0]
+    donor = writer.parse_cc_header(hdr)
+    arch = writer.derive_arch(donor, **FULL_SIZE[name])
+    nn = writer.encode_network(arch, writer.adapt_network(donor, z["cc0.nn_ints"], arch))
+    latents = writer.tile_latents([z[f"cc0.latent{g}"] for g in range(donor.n_grids)], donor, arch)
+    stream = writer.encode_stream(writer.cc_header_bytes(arch), nn, latents)
+    triple = oracle.split_stream(stream)[1][0][1][0]
+    b = _decode(gpu, [triple], 8, 0)
+    try:
+        assert b.slot_status(0) == 0
+        assert b.slot_kernels(0) == 3, "the reference configurations must run on the pipelined / fused kernels"
+        t0 = time.time()
+        b.run(); b.wait()
+        dt = time.time() - t0
+        print(f"\n{name}: {len(stream)} bytes, {arch.n_symbols} symbols, GPU decode {dt * 1e3:.1f} ms "
+              f"({arch.img_size[0] * arch.img_size[1] / dt / 1e6:.1f} Mpx/s single stream)")
+        for g, a in enumerate(latents):
+            assert np.array_equal(b.latent(0, g), a), f"grid {g}"
+        want = oracle.decode_video(stream)[0]["planes"]
+        for p, w in zip(b.planes(0), want):
+            assert np.array_equal(p.astype(np.uint16), w)
+    finally:
+        b.close()
