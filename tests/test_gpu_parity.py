@@ -307,3 +307,48 @@ def test_full_size_configs(gpu, oracle, name):
             assert np.array_equal(p.astype(np.uint16), w)
     finally:
         b.close()
+
+
+def test_video_1080p_gop(gpu, oracle):
+    """SURVEY 8d config 3 at full picture size (reduced GOP): the I/P/B/B/B structure, networks and headers of
+    the reference-encoded `vid5` stream with its latents tiled to 1920x1080 4:2:0, re-written frame by frame.
+    ccd_decode_video against the oracle, bit-exact, all five frames."""
+    import time
+
+    from cool_chic_amd import writer
+    from cool_chic_amd._lib import Video, check, lib
+
+    bs, z, _ = load_golden("vid5")
+    vh, frames = oracle.split_stream(bs)
+    H, W = 1080, 1920
+    out = [writer.video_header_bytes(vh.n_frames, list(vh.intra_pos[:vh.n_intras]), list(vh.p_pos[:vh.n_p_frames]))]
+    cc_idx = 0
+    for fh, ccs in frames:
+        out.append(writer.frame_header_bytes(fh.display_index, "IPB"[fh.frame_type], fh.frame_data_type, fh.bitdepth,
+                                             list(fh.index_references[:fh.n_refs]), list(fh.global_flow[:2 * fh.n_refs]),
+                                             fh.warp_filter_size))
+        for hdr, nn, _lat in ccs:
+            donor = writer.parse_cc_header(hdr)
+            arch = writer.derive_arch(donor, img_size=(H, W))
+            lat = [z[f"cc{cc_idx}.latent{g}"] for g in range(donor.n_grids)]
+            out.append(writer.encode_coolchic(arch, nn, writer.tile_latents(lat, donor, arch)))
+            cc_idx += 1
+    stream = b"".join(out)
+    t0 = time.time()
+    want = oracle.decode_video(stream)
+    t_cpu = time.time() - t0
+    v = Video()
+    t0 = time.time()
+    check(lib().ccd_decode_video(stream, len(stream), 0, C.byref(v)), "ccd_decode_video")
+    t_gpu = time.time() - t0
+    print(f"\n1080p x {vh.n_frames} frames: {len(stream)} bytes; oracle {t_cpu:.1f} s, ccd_decode_video {t_gpu * 1e3:.0f} ms (incl. parse/upload)")
+    try:
+        assert v.n_frames == vh.n_frames
+        for i in range(v.n_frames):
+            f = v.frames[i]
+            assert (f.h, f.w, f.ch, f.cw) == (H, W, H // 2, W // 2)
+            for p, shape in enumerate([(f.h, f.w), (f.ch, f.cw), (f.ch, f.cw)]):
+                got = np.ctypeslib.as_array(f.plane[p], shape=shape)
+                assert np.array_equal(got, want[i]["planes"][p]), f"frame {i} plane {p}"
+    finally:
+        lib().ccd_video_free(C.byref(v))
