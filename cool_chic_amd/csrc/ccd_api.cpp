@@ -17,7 +17,7 @@ size_t entropy_lds_bytes(int dim, int arm_len);
 hipError_t launch_entropy(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream);
 size_t entropy_pipe_lds_bytes(int dim, int n_layers);
 bool entropy_pipe_supports(int dim, int n_layers, int narrow, int max_grid_w);
-hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_laplace_bounds(const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* sym,
                                  const float* scale_table, int64_t n, uint32_t* left, uint32_t* right, hipStream_t stream);
 hipError_t launch_upsample_step(const UpsampleLevel* d_levels, const uint32_t* d_zmap, int n_z, int max_w, int max_h, hipStream_t stream);
@@ -115,6 +115,8 @@ struct ccd_batch {
     EntropyParams* d_params = nullptr;   // [pipe slots..., generic slots...]
     int n_params_uploaded = 0;
     int n_pipe = 0, n_generic = 0;
+    struct PipeGroup { int nv, first, n; };
+    std::vector<PipeGroup> pipe_groups;
     float* d_scale_table = nullptr;
     double* d_rcp_table = nullptr;
     size_t lds_generic = 0, lds_pipe = 0;
@@ -463,7 +465,13 @@ static int upload_params(ccd_batch* b) {
     if (b->n_params_uploaded == n) return CCD_OK;
     if (b->d_params) { (void)hipFree(b->d_params); b->d_params = nullptr; }
     std::vector<EntropyParams> host;
-    for (int i = 0; i < n; ++i) if (b->slots[i]->use_pipe) host.push_back(b->slots[i]->ep);
+    b->pipe_groups.clear();  // the pipelined kernel is instantiated per input width nv = ceil(dim / 4): one launch per width
+    for (int nv = 1; nv <= 8; ++nv) {
+        const int first = static_cast<int>(host.size());
+        for (int i = 0; i < n; ++i)
+            if (b->slots[i]->use_pipe && (b->slots[i]->ep.dim + 3) / 4 == nv) host.push_back(b->slots[i]->ep);
+        if (static_cast<int>(host.size()) > first) b->pipe_groups.push_back({nv, first, static_cast<int>(host.size()) - first});
+    }
     b->n_pipe = static_cast<int>(host.size());
     for (int i = 0; i < n; ++i) if (!b->slots[i]->use_pipe) host.push_back(b->slots[i]->ep);
     b->n_generic = n - b->n_pipe;
@@ -611,7 +619,7 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
     int rc = upload_params(b);
     if (rc < 0) return rc;
     if (stage == 0) {
-        HIP_TRY(launch_entropy_pipe(b->d_params, b->n_pipe, b->lds_pipe, st));
+        for (const auto& g : b->pipe_groups) HIP_TRY(launch_entropy_pipe(b->d_params + g.first, g.n, g.nv, b->lds_pipe, st));
         HIP_TRY(launch_entropy(b->d_params + b->n_pipe, b->n_generic, b->lds_generic, st));
         return CCD_OK;
     }

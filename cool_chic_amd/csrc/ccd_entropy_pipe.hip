@@ -105,6 +105,8 @@ struct PipeCtx {
     const EntropyParams* P;
     uint2* s_tab;          // [kSlots][kBatch][64] (L, P)
     BatchMeta* s_meta;     // [kSlots]
+    const double* s_rcp;   // [kNumScale] RN(1 / b): LDS copies of the two Laplace-scale tables (a global load per
+    const float* s_scale;  // [kNumScale] b        pixel would put an L2 round trip on every task's critical path)
     int32_t* s_w;          // transposed int32 weights Wt[out][in_pad]
     int64_t* s_b;          // biases: hidden layers, output (2), stabiliser (2)
     int32_t* s_act;        // [kProducers][kBatch][in_pad]
@@ -375,6 +377,19 @@ __device__ __forceinline__ int64_t dot4(int4 x, int4 w) {
            static_cast<int64_t>(x.w) * w.w;
 }
 
+// One v_mad_i64_i32 per multiply-add.  The empty asm pins every partial sum: without it the optimiser re-associates
+// the wrapping int64 sums into one long dependent chain per output and expands part of the products into 64 x 64
+// multiplies (an asm statement holding the instruction itself makes the hazard recogniser pad every one with s_nop).
+__device__ __forceinline__ void mad64(int64_t& acc, int32_t x, int32_t w) {
+    acc += static_cast<int64_t>(x) * static_cast<int64_t>(w);
+    asm("" : "+v"(acc));
+}
+#define CCD_MAD4(ACC, X, Wv, NCH)                                                   \
+    _Pragma("unroll") for (int g_ = 0; g_ < (NCH); ++g_) mad64(ACC[g_], (X).x, Wv[g_].x); \
+    _Pragma("unroll") for (int g_ = 0; g_ < (NCH); ++g_) mad64(ACC[g_], (X).y, Wv[g_].y); \
+    _Pragma("unroll") for (int g_ = 0; g_ < (NCH); ++g_) mad64(ACC[g_], (X).z, Wv[g_].z); \
+    _Pragma("unroll") for (int g_ = 0; g_ < (NCH); ++g_) mad64(ACC[g_], (X).w, Wv[g_].w);
+
 template <int NV, int kLpp>
 __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned long long* prof) {
     constexpr int in_pad = 4 * NV;
@@ -444,44 +459,68 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 int4 xv[NV];
 #pragma unroll
                 for (int v = 0; v < NV; ++v) xv[v] = act_row[v];
-                int64_t stab = 0;
-                if (q < 2) {  // stabiliser branch on the raw inputs
-                    const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + 2 * in_pad + q * in_pad);
-                    stab = C.s_b[(n_layers - 1) * dim + 2 + q];
+                // Lane q owns outputs q, q + kLpp, ...: their accumulators advance in lock-step (independent chains), one
+                // 16-byte weight vector per output and step; every multiply-add is a single v_mad_i64_i32.
+                PROF_ADD(prof[4], t_m);  // activation reload
+                const unsigned long long t_s = PROF_T();
+                int64_t so[2];  // [0]: stabiliser output (lanes q < 2), [1]: scratch second chain
+                {   // stabiliser branch on the raw inputs; lanes q >= 2 compute a discarded copy of row 1
+                    const int qs = q < 2 ? q : 1;
+                    const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + 2 * in_pad + qs * in_pad);
+                    so[0] = C.s_b[(n_layers - 1) * dim + 2 + qs];
+                    so[1] = 0;
 #pragma unroll
-                    for (int v = 0; v < NV; ++v) stab += dot4(xv[v], wr[v]);
+                    for (int v = 0; v < NV; ++v) {
+                        const int4 w = wr[v];
+                        int64_t& a = so[v & 1];
+                        mad64(a, xv[v].x, w.x); mad64(a, xv[v].y, w.y); mad64(a, xv[v].z, w.z); mad64(a, xv[v].w, w.w);
+                    }
                 }
+                const int64_t stab = so[0] + so[1];
+                PROF_ADD(prof[5], t_s);
+                const unsigned long long t_h = PROF_T();
                 for (int l = 0; l < n_layers - 1; ++l) {
                     const int32_t* wl = C.s_w + l * dim * in_pad;
                     const int64_t* bl = C.s_b + l * dim;
-                    int32_t outv[NOUT];
+                    int64_t acc[NOUT];
+                    const int4* wr[NOUT];
+#pragma unroll
+                    for (int t = 0; t < NOUT; ++t) {
+                        const int oc = min(q + kLpp * t, dim - 1);  // rows past the layer: a discarded copy of the last one
+                        wr[t] = reinterpret_cast<const int4*>(wl + oc * in_pad);
+                        acc[t] = bl[oc];
+                    }
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        int4 w[NOUT];
+#pragma unroll
+                        for (int t = 0; t < NOUT; ++t) w[t] = wr[t][v];
+                        CCD_MAD4(acc, xv[v], w, NOUT)
+                    }
 #pragma unroll
                     for (int t = 0; t < NOUT; ++t) {
                         const int o = q + kLpp * t;
-                        outv[t] = 0;
-                        if (o < dim) {
-                            const int4* wr = reinterpret_cast<const int4*>(wl + o * in_pad);
-                            int64_t acc = bl[o];
-#pragma unroll
-                            for (int v = 0; v < NV; ++v) acc += dot4(xv[v], wr[v]);
-                            acc = acc < 0 ? 0 : acc;
-                            outv[t] = static_cast<int32_t>(acc >> 16);
-                        }
+                        const int64_t a = acc[t] < 0 ? 0 : acc[t];
+                        if (o < in_pad) act[px * in_pad + o] = o < dim ? static_cast<int32_t>(a >> 16) : 0;
                     }
-#pragma unroll
-                    for (int t = 0; t < NOUT; ++t)
-                        if (q + kLpp * t < in_pad) act[px * in_pad + q + kLpp * t] = outv[t];
 #pragma unroll
                     for (int v = 0; v < NV; ++v) xv[v] = act_row[v];
                 }
+                PROF_ADD(prof[6], t_h);
+                const unsigned long long t_o = PROF_T();
                 // output layer (q = 0: mu, q = 1: log-scale) -> table indices -> per-pixel table parameters
                 BatchMeta& meta = C.s_meta[slot];
                 const int mpx = half * kTaskPix + px;  // pixel index inside the slot
                 if (q < 2) {
                     const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + q * in_pad);
-                    int64_t acc = C.s_b[(n_layers - 1) * dim + q] + stab;
+                    int64_t ao[2] = {C.s_b[(n_layers - 1) * dim + q] + stab, 0};
 #pragma unroll
-                    for (int v = 0; v < NV; ++v) acc += dot4(xv[v], wr[v]);
+                    for (int v = 0; v < NV; ++v) {
+                        const int4 w = wr[v];
+                        int64_t& a = ao[v & 1];
+                        mad64(a, xv[v].x, w.x); mad64(a, xv[v].y, w.y); mad64(a, xv[v].z, w.z); mad64(a, xv[v].w, w.w);
+                    }
+                    const int64_t acc = ao[0] + ao[1];
                     const int64_t q8 = acc >> 24;
                     const int64_t off = q8 + (q == 0 ? kMuOffset : kScaleOffset);
                     const int64_t hi = q == 0 ? kNumMu - 1 : kNumScale - 1;
@@ -490,13 +529,17 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         if (q == 0) {
                             meta.mu_idx[mpx] = idx;
                         } else {
-                            meta.b[mpx] = static_cast<double>(P.scale_table[idx]);
-                            meta.rcp[mpx] = P.rcp_table[idx];
+                            meta.b[mpx] = static_cast<double>(C.s_scale[idx]);
+                            meta.rcp[mpx] = C.s_rcp[idx];
                             meta.sc_idx[mpx] = idx;
                         }
                     }
                 }
                 PROF_ADD(prof[2], t_m);
+                PROF_ADD(prof[7], t_o);
+#ifdef CCD_PIPE_PROFILE
+                prof[8] += 1;
+#endif
                 const unsigned long long t_t = PROF_T();
                 // ---- window tables (lanes hold symbols in DESCENDING order; entry 0 = upper sentinel, trailing entries =
                 // lower sentinels, both with P = 0).  Narrow pixels (small scale): 14 real symbols, four pixels per pass.
@@ -578,20 +621,9 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     return seq;
 }
 
-template <int kLpp>
-__device__ __forceinline__ uint32_t producer_dispatch(const PipeCtx& C, int nv, unsigned long long* prof) {
-    switch (nv) {
-        case 1: return producer_grid<1, kLpp>(C, prof);
-        case 2: return producer_grid<2, kLpp>(C, prof);
-        case 3: return producer_grid<3, kLpp>(C, prof);
-        case 4: return producer_grid<4, kLpp>(C, prof);
-        case 5: return producer_grid<5, kLpp>(C, prof);
-        case 6: return producer_grid<6, kLpp>(C, prof);
-        case 7: return producer_grid<7, kLpp>(C, prof);
-        default: return producer_grid<8, kLpp>(C, prof);
-    }
-}
-
+// One kernel per input width NV = ceil(dim / 4): a single instantiation keeps the register file for the variant that runs
+// (all widths in one kernel cost 444 SGPR spills and VGPR scratch in every path).
+template <int NV>
 __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const EntropyParams* slots_desc) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const EntropyParams& P = slots_desc[blockIdx.x];
@@ -599,23 +631,28 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int dim = P.dim;
-    const int in_pad = (dim + 3) & ~3;
+    constexpr int in_pad = 4 * NV;
     const int n_layers = P.n_layers;
     const int n_if = P.has_ifce ? P.n_ifce_out : 0;
 
     // ---- LDS carve-up (all offsets multiples of 16) ----------------------------------------------
     PipeCtx C;
     C.P = &P;
-    C.s_tab = reinterpret_cast<uint2*>(smem);
-    C.s_meta = reinterpret_cast<BatchMeta*>(C.s_tab + kSlots * kBatch * 64);
-    C.s_w = reinterpret_cast<int32_t*>(C.s_meta + kSlots);
+    // network first: its addresses stay below 64 KB, so the per-vector offsets fold into the ds_read immediates
+    C.s_w = reinterpret_cast<int32_t*>(smem);
     C.n_w_hidden = (n_layers - 1) * dim * in_pad;
     const int n_w_total = C.n_w_hidden + 4 * in_pad;  // + output layer (2 rows) + stabiliser (2 rows)
     C.s_b = reinterpret_cast<int64_t*>(C.s_w + ((n_w_total + 3) & ~3));
     const int n_b_total = (n_layers - 1) * dim + 4;
     C.s_act = reinterpret_cast<int32_t*>(C.s_b + ((n_b_total + 1) & ~1));
-    C.s_ring = reinterpret_cast<int8_t*>(C.s_act + kProducers * kBatch * in_pad);
-    uint32_t* s_sync = reinterpret_cast<uint32_t*>(C.s_ring + kRingRows * 64);
+    C.s_tab = reinterpret_cast<uint2*>(C.s_act + kProducers * kBatch * in_pad);
+    C.s_meta = reinterpret_cast<BatchMeta*>(C.s_tab + kSlots * kBatch * 64);
+    C.s_ring = reinterpret_cast<int8_t*>(C.s_meta + kSlots);
+    double* s_rcp = reinterpret_cast<double*>(C.s_ring + kRingRows * 64);
+    float* s_scale = reinterpret_cast<float*>(s_rcp + kNumScale + 1);
+    C.s_rcp = s_rcp; C.s_scale = s_scale;
+    uint32_t* s_sync = reinterpret_cast<uint32_t*>(s_scale + ((kNumScale + 3) & ~3));
+    for (int i = tid; i < kNumScale; i += kPipeThreads) { s_rcp[i] = P.rcp_table[i]; s_scale[i] = P.scale_table[i]; }
     C.s_ready = s_sync;
     C.s_consumed = s_sync + kSlots * kMaxParts;
     C.s_abort = C.s_consumed + 1;
@@ -658,7 +695,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         S.dist = (static_cast<uint64_t>(w0) << 32) | w1;
         S.wbuf = (S.wbase + lane < P.n_words) ? P.words[S.wbase + lane] : 0u;
     }
-    unsigned long long prof[4] = {0, 0, 0, 0};
+    unsigned long long prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // [4..7]: MLP sub-phases, [8]: tasks
     const unsigned long long prof_total0 = PROF_T();
     C.seq_base = 0;
     __syncthreads();
@@ -744,7 +781,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
             }
 #endif
         } else {
-            seq_end = C.task_pix == 8 ? producer_dispatch<8>(C, in_pad / 4, prof) : producer_dispatch<16>(C, in_pad / 4, prof);
+            seq_end = C.task_pix == 8 ? producer_grid<NV, 8>(C, prof) : producer_grid<NV, 16>(C, prof);
         }
         const unsigned long long t_b = PROF_T();
         __syncthreads();  // also makes the decoder's global writes of this grid visible to every wave
@@ -769,7 +806,11 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         unsigned long long* o = reinterpret_cast<unsigned long long*>(P.status + 4) + wave * 5;
         o[0] = __builtin_amdgcn_s_memtime() - prof_total0;
         if (wave == 0) { o[1] = S.prof_wait; o[2] = S.prof_work; o[3] = prof_ifce; o[4] = prof_bar; }
-        else { o[1] = prof[0]; o[2] = prof[1]; o[3] = prof[2]; o[4] = prof[3]; }
+        else {
+            o[1] = prof[0]; o[2] = prof[1]; o[3] = prof[2]; o[4] = prof[3];
+            unsigned long long* e = reinterpret_cast<unsigned long long*>(P.status + 40);
+            for (int i = 0; i < 5; ++i) e[i] = prof[4 + i];
+        }
     }
 #else
     (void)prof_total0; (void)prof_ifce; (void)prof_bar;
@@ -786,6 +827,7 @@ size_t entropy_pipe_lds_bytes(int dim, int n_layers) {
     n += static_cast<size_t>((n_b_total + 1) & ~1) * 8;
     n += static_cast<size_t>(kProducers) * kBatch * in_pad * 4;
     n += static_cast<size_t>(kRingRows) * 64;
+    n += static_cast<size_t>(kNumScale + 1) * 8 + static_cast<size_t>((kNumScale + 3) & ~3) * 4;
     n += (kSlots * kMaxParts + 8) * 4;
     return (n + 15) & ~size_t{15};
 }
@@ -795,13 +837,29 @@ bool entropy_pipe_supports(int dim, int n_layers, int narrow, int max_grid_w) {
            entropy_pipe_lds_bytes(dim, n_layers) <= 160 * 1024;
 }
 
-hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream) {
-    if (n_slots <= 0) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(entropy_pipe_kernel),
+template <int NV>
+static hipError_t launch_pipe_nv(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(entropy_pipe_kernel<NV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(entropy_pipe_kernel, dim3(n_slots), dim3(kPipeThreads), lds_bytes, stream, d_slots);
+    hipLaunchKernelGGL(entropy_pipe_kernel<NV>, dim3(n_slots), dim3(kPipeThreads), lds_bytes, stream, d_slots);
     return hipGetLastError();
+}
+
+// All `n_slots` descriptors must share nv = ceil(dim / 4) (the host groups the slots of a batch by it).
+hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, size_t lds_bytes, hipStream_t stream) {
+    if (n_slots <= 0) return hipSuccess;
+    switch (nv) {
+        case 1: return launch_pipe_nv<1>(d_slots, n_slots, lds_bytes, stream);
+        case 2: return launch_pipe_nv<2>(d_slots, n_slots, lds_bytes, stream);
+        case 3: return launch_pipe_nv<3>(d_slots, n_slots, lds_bytes, stream);
+        case 4: return launch_pipe_nv<4>(d_slots, n_slots, lds_bytes, stream);
+        case 5: return launch_pipe_nv<5>(d_slots, n_slots, lds_bytes, stream);
+        case 6: return launch_pipe_nv<6>(d_slots, n_slots, lds_bytes, stream);
+        case 7: return launch_pipe_nv<7>(d_slots, n_slots, lds_bytes, stream);
+        case 8: return launch_pipe_nv<8>(d_slots, n_slots, lds_bytes, stream);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace ccd

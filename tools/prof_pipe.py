@@ -28,3 +28,7 @@ for g in range(4):
     print(' grid %d (%dx%d): wait %.1fM work %.1fM cycles -> %.0f cycles/symbol total, wait share %.2f'%(g,hw[g][0],hw[g][1],w/1e6,k/1e6,(w+k)/n,w/(w+k+1)))
 
 print(' grid0 steady-state decoder wait by batch position j (Mcycles):', [round(int(x)*1024/1e6,2) for x in st[32:38]])
+
+e=st[40:50].view(np.uint64)
+nt=max(int(e[4]),1)
+print(' producer1 tasks %d: per task gather %.0f mlp %.0f (reload %.0f stab %.0f hidden %.0f out+meta %.0f) table %.0f wait %.0f'%(nt,u[7]/nt,u[8]/nt,e[0]/nt,e[1]/nt,e[2]/nt,e[3]/nt,u[9]/nt,u[6]/nt))
