@@ -29,7 +29,8 @@ def _flags():
              # every fused multiply-add of the float stages is an explicit __fmaf_rn (bit parity with the oracle)
              "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
     if os.environ.get("CCD_PIPE_PROFILE"):
-        flags.append("-DCCD_PIPE_PROFILE")  # cycle counters in the entropy kernel (ccd_batch_slot_stats)
+        # cycle counters in the entropy kernel (ccd_batch_slot_stats): 1 = light (stalls, per-grid totals), 2 = every phase
+        flags.append("-DCCD_PIPE_PROFILE=" + os.environ["CCD_PIPE_PROFILE"])
     return flags
 
 

@@ -25,7 +25,9 @@
 
 namespace ccd {
 
-#ifdef CCD_PIPE_PROFILE
+// -DCCD_PIPE_PROFILE=1: light counters (per-grid totals, decoder stalls: nothing on the fast path);
+// -DCCD_PIPE_PROFILE=2: a time stamp around every phase (each costs an SMEM round trip: perturbs the pipeline).
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE >= 2
 #define PROF_T() __builtin_amdgcn_s_memtime()
 #define PROF_ADD(var, t0) var += __builtin_amdgcn_s_memtime() - (t0)
 #else
@@ -126,7 +128,7 @@ struct DecState {
     uint64_t dist, range;  // dist = point - lower (all the decoder ever uses)
     uint32_t word_pos, wbase, wbuf;
     uint64_t n_decoded;
-    unsigned long long prof_wait, prof_work;
+    unsigned long long prof_wait, prof_work, stall_ticks, stall_events;
     unsigned long long wait_by_j[6];  // grid 0, steps with n >= 64: decoder wait per batch position
 };
 
@@ -200,10 +202,11 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     uint32_t word_pos = uni(S.word_pos), wbase = uni(S.wbase), wbuf = S.wbuf;
     const uint32_t n_words = uni(P.n_words);
     const int task_pix = uni(C.task_pix);
+    const int bpx = task_pix == 2 ? 8 : kBatch;  // 2-pixel tasks (32 lanes per pixel) come with 8-pixel batches
     bool ok = true;
     while (ok && it.next()) {
-        for (int i0 = 0; i0 < it.n; i0 += kBatch, ++seq) {
-            const int cnt = uni(min(kBatch, it.n - i0));
+        for (int i0 = 0; i0 < it.n; i0 += bpx, ++seq) {
+            const int cnt = uni(min(bpx, it.n - i0));
             const int slot = uni(static_cast<int>(seq % kSlots));
             {
                 const unsigned long long t0 = PROF_T();
@@ -215,15 +218,23 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                     const uint32_t want = seq + 1;
                     bool ready = uni(f.x) == want && (n_parts < 2 || uni(f.y) == want) && (n_parts < 3 || uni(f.z) == want) &&
                                  (n_parts < 4 || uni(f.w) == want);
-                    if (!ready)
+                    if (!ready) {
+#ifdef CCD_PIPE_PROFILE
+                        const unsigned long long ts = __builtin_amdgcn_s_memtime();
+#endif
                         for (int part = 0; part < n_parts && ok; ++part)
                             if (!wait_ge(&C.s_ready[slot * kMaxParts + part], want, C.s_abort)) ok = false;
+#ifdef CCD_PIPE_PROFILE
+                        S.stall_ticks += __builtin_amdgcn_s_memtime() - ts;
+                        S.stall_events += 1;
+#endif
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 }
                 if (!ok) break;
                 PROF_ADD(S.prof_wait, t0);
-#ifdef CCD_PIPE_PROFILE
-                if (C.W == 768 && it.n >= 64) S.wait_by_j[min(i0 / kBatch, 5)] += __builtin_amdgcn_s_memtime() - t0;
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE >= 2
+                if (C.W == 768 && it.n >= 64) S.wait_by_j[min(i0 / bpx, 5)] += __builtin_amdgcn_s_memtime() - t0;
 #endif
             }
             const unsigned long long t_dec = PROF_T();
@@ -394,7 +405,8 @@ template <int NV, int kLpp>
 __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned long long* prof) {
     constexpr int in_pad = 4 * NV;
     constexpr int kTaskPix = 64 / kLpp;
-    constexpr int kHalves = kBatch / kTaskPix;
+    constexpr int kBpx = kLpp == 32 ? 8 : kBatch;  // pixels per decoder batch: 2-pixel tasks come with 8-pixel batches
+    constexpr int kHalves = kBpx / kTaskPix;
     constexpr int NOUT = (in_pad + kLpp - 1) / kLpp;  // outputs per lane in a hidden layer
     const int lane = threadIdx.x & 63;
     const int pw = (threadIdx.x >> 6) - 1;
@@ -409,11 +421,11 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     int prev_nb = 0, prev_n = 0;
     bool ok = true;
     while (ok && it.next()) {
-        const int nb = (it.n + kBatch - 1) / kBatch;
+        const int nb = (it.n + kBpx - 1) / kBpx;
         for (int j = 0; j < nb && ok; ++j, ++seq) {
             const int slot = seq % kSlots;
             for (int half = 0; half < kHalves; ++half) {
-                const int i0 = j * kBatch + half * kTaskPix;     // first pixel of the task within the step
+                const int i0 = j * kBpx + half * kTaskPix;     // first pixel of the task within the step
                 if (i0 >= it.n) break;
                 if (static_cast<int>((seq * kHalves + half) % kProducers) != pw) continue;
                 const int cnt = min(kTaskPix, it.n - i0);
@@ -430,7 +442,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // Slot free again?  Pixels this task reads decoded?  Its left neighbours sit in the previous step at pixel
                 // index <= i0 + cnt, i.e. in that step's batch (i0 + cnt) / kBatch (clamped to its last batch).
                 uint32_t need = seq >= static_cast<uint32_t>(kSlots) ? seq - kSlots + 1 : 0;
-                if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(i0 + cnt, prev_n - 1) / kBatch) + 1);
+                if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(i0 + cnt, prev_n - 1) / kBpx) + 1);
                 need = max(need, C.seq_base);
                 {
                     const unsigned long long t0 = PROF_T();
@@ -511,6 +523,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // output layer (q = 0: mu, q = 1: log-scale) -> table indices -> per-pixel table parameters
                 BatchMeta& meta = C.s_meta[slot];
                 const int mpx = half * kTaskPix + px;  // pixel index inside the slot
+                int32_t idx = 0;
                 if (q < 2) {
                     const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + q * in_pad);
                     int64_t ao[2] = {C.s_b[(n_layers - 1) * dim + q] + stab, 0};
@@ -524,7 +537,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     const int64_t q8 = acc >> 24;
                     const int64_t off = q8 + (q == 0 ? kMuOffset : kScaleOffset);
                     const int64_t hi = q == 0 ? kNumMu - 1 : kNumScale - 1;
-                    const int32_t idx = static_cast<int32_t>(off < 0 ? 0 : (off > hi ? hi : off));
+                    idx = static_cast<int32_t>(off < 0 ? 0 : (off > hi ? hi : off));
                     if (px < cnt) {
                         if (q == 0) {
                             meta.mu_idx[mpx] = idx;
@@ -535,6 +548,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         }
                     }
                 }
+                // bit (px * kLpp + 1) of the ballot: pixel px of the task takes a narrow window (wave-uniform, no LDS trip)
+                const unsigned long long narrow_lanes = __ballot(q == 1 && px < cnt && idx <= kNarrowMaxScale);
                 PROF_ADD(prof[2], t_m);
                 PROF_ADD(prof[7], t_o);
 #ifdef CCD_PIPE_PROFILE
@@ -547,7 +562,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 uint2* tab = C.s_tab + (static_cast<size_t>(slot) * kBatch + half * kTaskPix) * 64;
                 const int base = half * kTaskPix;
                 unsigned narrow_mask = 0;  // bit i: pixel i of the task is narrow (wave-uniform)
-                for (int i = 0; i < cnt; ++i) narrow_mask |= (uni(meta.sc_idx[base + i]) <= kNarrowMaxScale ? 1u : 0u) << i;
+#pragma unroll
+                for (int i = 0; i < kTaskPix; ++i) narrow_mask |= static_cast<unsigned>((narrow_lanes >> (i * kLpp + 1)) & 1ull) << i;
                 unsigned rest = narrow_mask;
                 while (rest) {
                     // up to four narrow pixels: sub-wave u = lane >> 4 handles pixel pix[u], entry e = lane & 15
@@ -568,7 +584,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     const int ssym = top - (e - 1);  // e = 0 -> top + 1: its left bound is the window's upper edge
                     uint32_t left = min(window_left(mu, meta.b[mi], meta.rcp[mi], ssym), (1u << kRcPrecision) - 1u);
                     left = e == 15 ? 0u : left;
-                    const uint32_t right = __shfl_up(left, 1);
+                    // entry e - 1 of the same 16-lane row (DPP row_shr:1; entry 0 does not use it)
+                    const uint32_t right = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(left), 0x111, 0xf, 0xf, false));
                     uint2 ent;
                     ent.x = left;
                     ent.y = (e == 0 || e == 15) ? 0u : ((e == 1 && ssym == kAcLo + kAlphabet - 1) ? (1u << kRcPrecision) - left : right - left);
@@ -576,14 +593,17 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         tab[mine * 64 + e] = ent;
                         if (e == 0) meta.top[mi] = top;
                     }
-                    // entries 16..63 of the (up to) four rows: lower sentinels
-                    const uint2 zero = make_uint2(0u, 0u);
+                    // entries 16..63 of the (up to) four rows: lower sentinels (4 rows x 24 16-byte stores)
+                    {
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const int t = lane + 64 * j;  // 0..191 = 4 rows x 48 entries
-                        const int ru = t / 48;
-                        const int rp = ru == 0 ? pix[0] : (ru == 1 ? pix[1] : (ru == 2 ? pix[2] : pix[3]));
-                        if (rp >= 0) tab[rp * 64 + 16 + t % 48] = zero;
+                        for (int j = 0; j < 2; ++j) {
+                            const int t = lane + 64 * j;          // 0..95 (lanes 32..63 idle in the second round)
+                            const int ru = t >= 72 ? 3 : (t >= 48 ? 2 : (t >= 24 ? 1 : 0));
+                            const int rp = ru == 0 ? pix[0] : (ru == 1 ? pix[1] : (ru == 2 ? pix[2] : pix[3]));
+                            if (t < 96 && rp >= 0) *reinterpret_cast<u32x4*>(&tab[rp * 64 + 16 + 2 * (t - 24 * ru)]) = z4;
+                        }
                     }
                     (void)n_here;
                 }
@@ -685,7 +705,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
 
     DecState S;
     S.range = ~uint64_t{0}; S.dist = 0; S.word_pos = 2; S.wbase = 2; S.wbuf = 0; S.n_decoded = 0;
-    S.prof_wait = 0; S.prof_work = 0;
+    S.prof_wait = 0; S.prof_work = 0; S.stall_ticks = 0; S.stall_events = 0;
     for (int i = 0; i < 6; ++i) S.wait_by_j[i] = 0;
     if (wave == 0) {
         // loads through pointers stored in the parameter block are FLAT loads, which the compiler treats as
@@ -710,7 +730,8 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         C.fw = (g == P.n_grids - 1) ? C.W : P.grid_w[g + 1];
         {   // widest wavefront step of the grid decides the task shape
             const int n_max = C.W <= 9 ? 1 : min(C.H, (C.W - 1) / 10 + 1);
-            C.task_pix = n_max >= 48 ? 8 : 4;
+            // wide steps: 8-pixel tasks (throughput); short steps: the fewer pixels a task holds, the sooner its batch is ready
+            C.task_pix = n_max >= 48 ? 8 : (n_max >= 24 ? 4 : 2);
         }
         // ---- IFCE features at the previously decoded grid's size (coolchic.py:94-146) -------------
         // Per-channel source descriptors and the (tiny) linear layer are staged in LDS first: read through the
@@ -769,6 +790,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
             __builtin_amdgcn_s_setprio(3);
 #ifdef CCD_PIPE_PROFILE
             const unsigned long long w0 = S.prof_wait, k0 = S.prof_work;
+            const unsigned long long g_t0 = __builtin_amdgcn_s_memtime(), st0 = S.stall_ticks, se0 = S.stall_events;
 #endif
             seq_end = decoder_grid(C, S);
             __builtin_amdgcn_s_setprio(0);
@@ -778,10 +800,14 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
             if (lane == 0 && g < 4) {  // per-grid decoder counters for the four finest grids: status[24 + 2 g ..]
                 P.status[24 + 2 * g] = static_cast<int32_t>((S.prof_wait - w0) >> 10);
                 P.status[25 + 2 * g] = static_cast<int32_t>((S.prof_work - k0) >> 10);
+                // light counters: total ticks of the grid, ticks stalled on producers, number of stalls
+                P.status[50 + 3 * g] = static_cast<int32_t>((__builtin_amdgcn_s_memtime() - g_t0) >> 10);
+                P.status[51 + 3 * g] = static_cast<int32_t>((S.stall_ticks - st0) >> 10);
+                P.status[52 + 3 * g] = static_cast<int32_t>(S.stall_events - se0);
             }
 #endif
         } else {
-            seq_end = C.task_pix == 8 ? producer_grid<NV, 8>(C, prof) : producer_grid<NV, 16>(C, prof);
+            seq_end = C.task_pix == 8 ? producer_grid<NV, 8>(C, prof) : (C.task_pix == 4 ? producer_grid<NV, 16>(C, prof) : producer_grid<NV, 32>(C, prof));
         }
         const unsigned long long t_b = PROF_T();
         __syncthreads();  // also makes the decoder's global writes of this grid visible to every wave

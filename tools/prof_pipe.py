@@ -32,3 +32,7 @@ print(' grid0 steady-state decoder wait by batch position j (Mcycles):', [round(
 e=st[40:50].view(np.uint64)
 nt=max(int(e[4]),1)
 print(' producer1 tasks %d: per task gather %.0f mlp %.0f (reload %.0f stab %.0f hidden %.0f out+meta %.0f) table %.0f wait %.0f'%(nt,u[7]/nt,u[8]/nt,e[0]/nt,e[1]/nt,e[2]/nt,e[3]/nt,u[9]/nt,u[6]/nt))
+
+print(' light counters (decoder, per grid): total Mticks, stalled Mticks, stall events')
+for g in range(4):
+    print('  grid %d: total %.1fM stalled %.1fM (%.0f%%) in %d stalls'%(g,int(st[50+3*g])*1024/1e6,int(st[51+3*g])*1024/1e6,100.0*int(st[51+3*g])/max(int(st[50+3*g]),1),int(st[52+3*g])))
