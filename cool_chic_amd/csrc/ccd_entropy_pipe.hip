@@ -113,7 +113,7 @@ struct PipeCtx {
     int64_t* s_b;          // biases: hidden layers, output (2), stabiliser (2)
     int32_t* s_act;        // [kProducers][kBatch][in_pad]
     int8_t* s_ring;        // [kRingRows][64]
-    uint32_t* s_ready;     // [kSlots][kMaxParts]
+    uint32_t* s_ready;     // [kSlots] parts of the slot's batch finished by the producers (cleared by the decoder)
     uint32_t* s_consumed;
     uint32_t* s_abort;
     int dim, n_layers, n_sp, n_if, n_w_hidden;
@@ -210,20 +210,13 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
             const int slot = uni(static_cast<int>(seq % kSlots));
             {
                 const unsigned long long t0 = PROF_T();
-                {   // all part flags of the slot with one 16-byte LDS read; fall back to per-flag spinning if any lags
-                    const int n_parts = (cnt + task_pix - 1) / task_pix;
-                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-                    asm volatile("" ::: "memory");  // re-read the flags every time
-                    const u32x4 f = *reinterpret_cast<const u32x4*>(&C.s_ready[slot * kMaxParts]);
-                    const uint32_t want = seq + 1;
-                    bool ready = uni(f.x) == want && (n_parts < 2 || uni(f.y) == want) && (n_parts < 3 || uni(f.z) == want) &&
-                                 (n_parts < 4 || uni(f.w) == want);
-                    if (!ready) {
+                {   // one counter per slot: every finished part adds 1, the decoder clears it when the batch is consumed
+                    const uint32_t n_parts = static_cast<uint32_t>((cnt + task_pix - 1) / task_pix);
+                    if (uni(lds_load_acquire(&C.s_ready[slot])) != n_parts) {
 #ifdef CCD_PIPE_PROFILE
                         const unsigned long long ts = __builtin_amdgcn_s_memtime();
 #endif
-                        for (int part = 0; part < n_parts && ok; ++part)
-                            if (!wait_ge(&C.s_ready[slot * kMaxParts + part], want, C.s_abort)) ok = false;
+                        if (!wait_ge(&C.s_ready[slot], n_parts, C.s_abort)) ok = false;
 #ifdef CCD_PIPE_PROFILE
                         S.stall_ticks += __builtin_amdgcn_s_memtime() - ts;
                         S.stall_events += 1;
@@ -241,6 +234,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
             const uint2* tab = C.s_tab + static_cast<size_t>(slot) * kBatch * 64 + lane;
             const BatchMeta& meta = C.s_meta[slot];
             int raw = 0;  // lane i: window lane chosen for pixel i
+            const int top_l = meta.top[lane & (kBatch - 1)];  // needed after the loop: the read overlaps it
             // ---- symbol loop: hand-scheduled recurrence (see the file header).  The asm block walks symbols
             // i .. cnt-1 and stops early (status 1) at the first symbol whose new range has a zero high word:
             // renormalisation, window miss or invalid data - all handled in C++ below, then the loop resumes.
@@ -392,10 +386,11 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
             // ---- vector epilogue of the batch: symbols -> ring + global grid ------------------------
             if (lane < cnt) {
                 const int y = it.y0 + i0 + lane, x = it.x0 - 10 * (i0 + lane);
-                const int sym = meta.top[lane] - (raw - 1);
+                const int sym = top_l - (raw - 1);
                 C.s_ring[(y & (kRingRows - 1)) * 64 + ((x + 10 * y) & 63)] = static_cast<int8_t>(sym);
                 C.lat[y * C.W + x] = static_cast<int8_t>(sym);
             }
+            lds_store_ordered(&C.s_ready[slot], 0u);  // before `consumed`: the slot's next producers wait for that
             lds_store_ordered(C.s_consumed, seq + 1);
             PROF_ADD(S.prof_work, t_dec);
         }
@@ -653,7 +648,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     tab[i * 64 + lane] = ent;
                     if (lane == 0) meta.top[mi] = top;
                 }
-                if (lane == 0) lds_store_release(&C.s_ready[slot * kMaxParts + half], seq + 1);
+                if (lane == 0) __hip_atomic_fetch_add(&C.s_ready[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 PROF_ADD(prof[3], t_t);
             }
         }
