@@ -38,11 +38,11 @@ namespace ccd {
 constexpr int kPipeThreads = 512;           // 8 waves: 1 decoder + 7 producers
 constexpr int kPipeWaves = kPipeThreads / 64;
 constexpr int kProducers = kPipeWaves - 1;
-constexpr int kBatch = 16;                  // pixels per decoder batch (one slot)
+constexpr int kBatch = 16;                  // most pixels per decoder batch; 8 with 2-pixel tasks
+constexpr int kRows = 128;                  // table rows in LDS = slots x pixels per batch (4 x 32, 8 x 16 or 16 x 8)
 // Producer task = a part of a batch: 8 pixels x 8 lanes on wide wavefronts, 4 pixels x 16 lanes on short ones
 // (small grids are bound by the producers' latency, not their throughput).
-constexpr int kMaxParts = 4;
-constexpr int kSlots = 8;                   // ring of batch slots (power of two: cheap modulo on the decoder's path)
+constexpr int kSlots = 16;                  // most batch slots in flight (power of two)
 constexpr int kMaxNV = 8;                   // MLP width <= 32 (in 4-wide vectors)
 constexpr int kRingRows = 512;              // rows of the decoded-symbol ring (>= live rows + 4; 4K: 384 + 4)
 // Scale index up to which a 14-symbol window [round(mu) - 7, round(mu) + 6] is used (b <= 1: 99.3 % of the symbols of
@@ -95,23 +95,22 @@ __device__ __forceinline__ uint32_t window_left(double mu, double b, double rcp,
     return s <= kAcLo ? 0u : (s > kAcLo + kAlphabet - 1 ? (1u << kRcPrecision) : v);
 }
 
-struct alignas(16) BatchMeta {
-    double b[kBatch];       // Laplace scale (float32 table value widened)
-    double rcp[kBatch];     // RN(1 / b)
-    int32_t mu_idx[kBatch];
-    int32_t top[kBatch];    // symbol of window lane 1
-    int32_t sc_idx[kBatch]; // scale index (narrow windows when <= kNarrowMaxScale)
+struct alignas(16) RowMeta {  // per table row (= pixel of a batch in flight)
+    double b[kRows];        // Laplace scale (float32 table value widened)
+    double rcp[kRows];      // RN(1 / b)
+    int32_t mu_idx[kRows];
+    int32_t top[kRows];     // symbol of window lane 1
 };
 
 struct PipeCtx {
     const EntropyParams* P;
-    uint2* s_tab;          // [kSlots][kBatch][64] (L, P)
-    BatchMeta* s_meta;     // [kSlots]
+    uint2* s_tab;          // [kRows][64] (L, P)
+    RowMeta* s_meta;
     const double* s_rcp;   // [kNumScale] RN(1 / b): LDS copies of the two Laplace-scale tables (a global load per
     const float* s_scale;  // [kNumScale] b        pixel would put an L2 round trip on every task's critical path)
     int32_t* s_w;          // transposed int32 weights Wt[out][in_pad]
     int64_t* s_b;          // biases: hidden layers, output (2), stabiliser (2)
-    int32_t* s_act;        // [kProducers][kBatch][in_pad]
+    int32_t* s_act;        // [kProducers][8][in_pad] (a task holds at most 8 pixels)
     int8_t* s_ring;        // [kRingRows][64]
     uint32_t* s_ready;     // [kSlots] parts of the slot's batch finished by the producers (cleared by the decoder)
     uint32_t* s_consumed;
@@ -202,12 +201,17 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     uint32_t word_pos = uni(S.word_pos), wbase = uni(S.wbase), wbuf = S.wbuf;
     const uint32_t n_words = uni(P.n_words);
     const int task_pix = uni(C.task_pix);
-    const int bpx = task_pix == 2 ? 8 : kBatch;  // 2-pixel tasks (32 lanes per pixel) come with 8-pixel batches
+    // pixels per batch: 16 (two 8-pixel or four 4-pixel tasks) or 8 (four 2-pixel tasks).  32-pixel batches were tried:
+    // the decoder saves ~20 ticks / symbol of per-batch overhead, but progress is published (and the producers of the next
+    // step released) only half as often, which costs more in stalls than it saves.
+    const int bpx = task_pix == 2 ? 8 : 16;
+    const int slot_mask = kRows / bpx - 1;       // 8 / 16 slots share the 128 table rows
     bool ok = true;
     while (ok && it.next()) {
         for (int i0 = 0; i0 < it.n; i0 += bpx, ++seq) {
             const int cnt = uni(min(bpx, it.n - i0));
-            const int slot = uni(static_cast<int>(seq % kSlots));
+            const int slot = uni(static_cast<int>(seq) & slot_mask);
+            const int row0 = slot * bpx;
             {
                 const unsigned long long t0 = PROF_T();
                 {   // one counter per slot: every finished part adds 1, the decoder clears it when the batch is consumed
@@ -231,10 +235,10 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
 #endif
             }
             const unsigned long long t_dec = PROF_T();
-            const uint2* tab = C.s_tab + static_cast<size_t>(slot) * kBatch * 64 + lane;
-            const BatchMeta& meta = C.s_meta[slot];
+            const uint2* tab = C.s_tab + static_cast<size_t>(row0) * 64 + lane;
+            const RowMeta& meta = *C.s_meta;
             int raw = 0;  // lane i: window lane chosen for pixel i
-            const int top_l = meta.top[lane & (kBatch - 1)];  // needed after the loop: the read overlaps it
+            const int top_l = meta.top[row0 + (lane & (kBatch - 1))];  // needed after the loop: the read overlaps it
             // ---- symbol loop: hand-scheduled recurrence (see the file header).  The asm block walks symbols
             // i .. cnt-1 and stops early (status 1) at the first symbol whose new range has a zero high word:
             // renormalisation, window miss or invalid data - all handled in C++ below, then the loop resumes.
@@ -359,8 +363,8 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                         ok = false;
                         break;
                     }
-                    const double mu = -64.0 + static_cast<double>(meta.mu_idx[i]) * (1.0 / 256.0);
-                    const double b = meta.b[i], rcp = meta.rcp[i];
+                    const double mu = -64.0 + static_cast<double>(meta.mu_idx[row0 + i]) * (1.0 / 256.0);
+                    const double b = meta.b[row0 + i], rcp = meta.rcp[row0 + i];
                     const uint32_t f0 = window_left(mu, b, rcp, kAcLo + lane);
                     const uint32_t f1 = window_left(mu, b, rcp, kAcLo + 64 + lane);
                     const unsigned long long m0 = __ballot(scale * f0 <= rc_dist), m1 = __ballot(scale * f1 <= rc_dist);
@@ -370,7 +374,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                     if (sidx == kAlphabet - 1) right = 1u << kRcPrecision;
                     nd = rc_dist - scale * left;
                     nr = scale * static_cast<uint64_t>(right - left);
-                    k = uni(1 - ((sidx + kAcLo) - meta.top[i]));  // top - (k - 1) == symbol
+                    k = uni(1 - ((sidx + kAcLo) - meta.top[row0 + i]));  // top - (k - 1) == symbol
                 }
                 if (static_cast<uint32_t>(nr >> 32) == 0) {
                     nr <<= 32;
@@ -424,14 +428,15 @@ template <int NV, int kLpp>
 __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned long long* prof) {
     constexpr int in_pad = 4 * NV;
     constexpr int kTaskPix = 64 / kLpp;
-    constexpr int kBpx = kLpp == 32 ? 8 : kBatch;  // pixels per decoder batch: 2-pixel tasks come with 8-pixel batches
+    constexpr int kBpx = kTaskPix == 2 ? 8 : 16;   // pixels per decoder batch (see decoder_grid)
     constexpr int kHalves = kBpx / kTaskPix;
+    constexpr int kNSlots = kRows / kBpx;
     constexpr int NOUT = (in_pad + kLpp - 1) / kLpp;  // outputs per lane in a hidden layer
     const int lane = threadIdx.x & 63;
     const int pw = (threadIdx.x >> 6) - 1;
     const EntropyParams& P = *C.P;
     const int dim = C.dim, n_layers = C.n_layers, n_sp = C.n_sp, W = C.W;
-    int32_t* act = C.s_act + pw * kBatch * in_pad;   // this wave's activation tile [kTaskPix][in_pad] (kBatch rows reserved)
+    int32_t* act = C.s_act + pw * 8 * in_pad;        // this wave's activation tile [kTaskPix][in_pad]
     const int px = lane / kLpp, q = lane % kLpp;     // pixel of the task, lane within its group
     const int4* act_row = reinterpret_cast<const int4*>(act + px * in_pad);
     StepIter it;
@@ -442,7 +447,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     while (ok && it.next()) {
         const int nb = (it.n + kBpx - 1) / kBpx;
         for (int j = 0; j < nb && ok; ++j, ++seq) {
-            const int slot = seq % kSlots;
+            const int slot = seq % kNSlots;
             for (int half = 0; half < kHalves; ++half) {
                 const int i0 = j * kBpx + half * kTaskPix;     // first pixel of the task within the step
                 if (i0 >= it.n) break;
@@ -460,7 +465,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 }
                 // Slot free again?  Pixels this task reads decoded?  Its left neighbours sit in the previous step at pixel
                 // index <= i0 + cnt, i.e. in that step's batch (i0 + cnt) / kBatch (clamped to its last batch).
-                uint32_t need = seq >= static_cast<uint32_t>(kSlots) ? seq - kSlots + 1 : 0;
+                uint32_t need = seq >= static_cast<uint32_t>(kNSlots) ? seq - kNSlots + 1 : 0;
                 if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(i0 + cnt, prev_n - 1) / kBpx) + 1);
                 need = max(need, C.seq_base);
                 {
@@ -540,8 +545,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 PROF_ADD(prof[6], t_h);
                 const unsigned long long t_o = PROF_T();
                 // output layer (q = 0: mu, q = 1: log-scale) -> table indices -> per-pixel table parameters
-                BatchMeta& meta = C.s_meta[slot];
-                const int mpx = half * kTaskPix + px;  // pixel index inside the slot
+                RowMeta& meta = *C.s_meta;
+                const int mpx = slot * kBpx + half * kTaskPix + px;  // table row of the pixel
                 int32_t idx = 0;
                 if (q < 2) {
                     const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + q * in_pad);
@@ -563,7 +568,6 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         } else {
                             meta.b[mpx] = static_cast<double>(C.s_scale[idx]);
                             meta.rcp[mpx] = C.s_rcp[idx];
-                            meta.sc_idx[mpx] = idx;
                         }
                     }
                 }
@@ -578,8 +582,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // ---- window tables (lanes hold symbols in DESCENDING order; entry 0 = upper sentinel, trailing entries =
                 // lower sentinels, both with P = 0).  Narrow pixels (small scale): 14 real symbols, four pixels per pass.
                 // Wide pixels: 62 real symbols, one pixel per pass.
-                uint2* tab = C.s_tab + (static_cast<size_t>(slot) * kBatch + half * kTaskPix) * 64;
-                const int base = half * kTaskPix;
+                const int base = slot * kBpx + half * kTaskPix;  // first table row of the task
+                uint2* tab = C.s_tab + static_cast<size_t>(base) * 64;
                 unsigned narrow_mask = 0;  // bit i: pixel i of the task is narrow (wave-uniform)
 #pragma unroll
                 for (int i = 0; i < kTaskPix; ++i) narrow_mask |= static_cast<unsigned>((narrow_lanes >> (i * kLpp + 1)) & 1ull) << i;
@@ -684,16 +688,16 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     C.s_b = reinterpret_cast<int64_t*>(C.s_w + ((n_w_total + 3) & ~3));
     const int n_b_total = (n_layers - 1) * dim + 4;
     C.s_act = reinterpret_cast<int32_t*>(C.s_b + ((n_b_total + 1) & ~1));
-    C.s_tab = reinterpret_cast<uint2*>(C.s_act + kProducers * kBatch * in_pad);
-    C.s_meta = reinterpret_cast<BatchMeta*>(C.s_tab + kSlots * kBatch * 64);
-    C.s_ring = reinterpret_cast<int8_t*>(C.s_meta + kSlots);
+    C.s_tab = reinterpret_cast<uint2*>(C.s_act + kProducers * 8 * in_pad);
+    C.s_meta = reinterpret_cast<RowMeta*>(C.s_tab + kRows * 64);
+    C.s_ring = reinterpret_cast<int8_t*>(C.s_meta + 1);
     double* s_rcp = reinterpret_cast<double*>(C.s_ring + kRingRows * 64);
     float* s_scale = reinterpret_cast<float*>(s_rcp + kNumScale + 1);
     C.s_rcp = s_rcp; C.s_scale = s_scale;
     uint32_t* s_sync = reinterpret_cast<uint32_t*>(s_scale + ((kNumScale + 3) & ~3));
     for (int i = tid; i < kNumScale; i += kPipeThreads) { s_rcp[i] = P.rcp_table[i]; s_scale[i] = P.scale_table[i]; }
     C.s_ready = s_sync;
-    C.s_consumed = s_sync + kSlots * kMaxParts;
+    C.s_consumed = s_sync + kSlots;
     C.s_abort = C.s_consumed + 1;
     C.dim = dim; C.n_layers = n_layers; C.n_sp = P.n_spatial; C.n_if = n_if;
 
@@ -718,8 +722,8 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         }
         if (tid < 2) C.s_b[(n_layers - 1) * dim + 2 + tid] = src[dim * 2 + tid];
     }
-    for (int i = tid; i < kProducers * kBatch * in_pad; i += kPipeThreads) C.s_act[i] = 0;
-    if (tid < kSlots * kMaxParts) C.s_ready[tid] = 0;
+    for (int i = tid; i < kProducers * 8 * in_pad; i += kPipeThreads) C.s_act[i] = 0;
+    if (tid < kSlots) C.s_ready[tid] = 0;
     if (tid == 0) { *C.s_consumed = 0; *C.s_abort = 0; }
 
     DecState S;
@@ -866,14 +870,14 @@ size_t entropy_pipe_lds_bytes(int dim, int n_layers) {
     const int in_pad = (dim + 3) & ~3;
     const int n_w_total = (n_layers - 1) * dim * in_pad + 4 * in_pad;
     const int n_b_total = (n_layers - 1) * dim + 4;
-    size_t n = static_cast<size_t>(kSlots) * kBatch * 64 * sizeof(uint2);
-    n += static_cast<size_t>(kSlots) * sizeof(BatchMeta);
+    size_t n = static_cast<size_t>(kRows) * 64 * sizeof(uint2);
+    n += sizeof(RowMeta);
     n += static_cast<size_t>((n_w_total + 3) & ~3) * 4;
     n += static_cast<size_t>((n_b_total + 1) & ~1) * 8;
-    n += static_cast<size_t>(kProducers) * kBatch * in_pad * 4;
+    n += static_cast<size_t>(kProducers) * 8 * in_pad * 4;
     n += static_cast<size_t>(kRingRows) * 64;
     n += static_cast<size_t>(kNumScale + 1) * 8 + static_cast<size_t>((kNumScale + 3) & ~3) * 4;
-    n += (kSlots * kMaxParts + 8) * 4;
+    n += (kSlots + 8) * 4;
     return (n + 15) & ~size_t{15};
 }
 

@@ -1,0 +1,24 @@
+"""Light-profile counters (CCD_PIPE_PROFILE=1 build) of one kodak24 stream decoded alone: python tools/prof_stream.py IDX"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from cool_chic_amd import DecodeBatch
+from cool_chic_amd._lib import lib
+
+items, _ = bench.build_kodak24(0)
+for idx in [int(a) for a in sys.argv[1:]] or [0]:
+    hdr, nn, lat, (h, w) = items[idx]
+    b = DecodeBatch(0)
+    b.add(hdr, nn, lat, 8, 0)
+    for _ in range(2):
+        torch.cuda.synchronize(); t = time.time(); b.run(stage=0); b.wait(); dt = time.time() - t
+    st = np.zeros(64, np.int32); lib().ccd_batch_slot_stats(b._h, 0, st.ctypes.data)
+    hh = b.header(0)
+    print("stream %d %dx%d: entropy %.1f ms" % (idx, h, w, dt * 1e3))
+    for g in range(4):
+        n = hh.grid_h[g] * hh.grid_w[g]
+        tot, stl, ev = int(st[50 + 3 * g]) * 1024, int(st[51 + 3 * g]) * 1024, int(st[52 + 3 * g])
+        print("  grid %d (%dx%d): total %.1fM ticks = %.0f / symbol, stalled %.1fM (%.0f%%) in %d stalls" % (g, hh.grid_h[g], hh.grid_w[g], tot / 1e6, tot / n, stl / 1e6, 100.0 * stl / max(tot, 1), ev))
+    b.close()
