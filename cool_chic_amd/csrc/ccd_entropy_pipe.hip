@@ -442,7 +442,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     StepIter it;
     it.init(C.H, C.W);
     uint32_t seq = C.seq_base, prev_first = C.seq_base;
-    int prev_nb = 0, prev_n = 0;
+    int prev_nb = 0, prev_n = 0, prev_y0 = 0;
     bool ok = true;
     while (ok && it.next()) {
         const int nb = (it.n + kBpx - 1) / kBpx;
@@ -466,7 +466,9 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // Slot free again?  Pixels this task reads decoded?  Its left neighbours sit in the previous step at pixel
                 // index <= i0 + cnt, i.e. in that step's batch (i0 + cnt) / kBatch (clamped to its last batch).
                 uint32_t need = seq >= static_cast<uint32_t>(kNSlots) ? seq - kNSlots + 1 : 0;
-                if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(i0 + cnt, prev_n - 1) / kBpx) + 1);
+                // The only context in the previous step is the left neighbour (y, x - 1): pixel i of this step reads pixel i of
+                // the previous one - pixel i + 1 when the previous step started one row higher (once in ten steps).
+                if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 != prev_y0 ? 1 : 0), prev_n - 1) / kBpx) + 1);
                 need = max(need, C.seq_base);
                 {
                     const unsigned long long t0 = PROF_T();
@@ -660,6 +662,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
         prev_first = seq - nb;
         prev_nb = nb;
         prev_n = it.n;
+        prev_y0 = it.y0;
     }
     return seq;
 }
