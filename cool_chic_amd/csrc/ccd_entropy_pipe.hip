@@ -757,7 +757,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         {   // widest wavefront step of the grid decides the task shape
             const int n_max = C.W <= 9 ? 1 : min(C.H, (C.W - 1) / 10 + 1);
             // wide steps: 8-pixel tasks (throughput); short steps: the fewer pixels a task holds, the sooner its batch is ready
-            C.task_pix = n_max >= 48 ? 8 : (n_max >= 24 ? 4 : 2);
+            C.task_pix = n_max >= 29 ? 8 : (n_max >= 15 ? 4 : 2);  // at most ~7 tasks per step: one round of the producers
         }
         // ---- IFCE features at the previously decoded grid's size (coolchic.py:94-146) -------------
         // Per-channel source descriptors and the (tiny) linear layer are staged in LDS first: read through the
