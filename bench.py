@@ -178,13 +178,38 @@ def main():
     if rank == 0:
         hdr0 = batch.header(0)
         n_sym = sum(batch.header(s).n_symbols for s in range(n_frames))
+        n_payload = sum(len(lat) for _, _, lat, _ in items)
         L = hdr0.input_feature_synthesis
         c_out = hdr0.out_channels
-        # synthesis, unfused: read 4*L B/px of dense planes, write 4*C_out B/px
-        # (+ the uint8 planes: C_out B/px)
-        syn_bytes_per_px = 4 * L + 4 * c_out + c_out
-        syn_s = stage_ms["synthesis"] / 1e3
-        achieved = px_per_step * syn_bytes_per_px / syn_s / 1e9
+        # PMC traffic of the same command, collected under rocprofv3 (tools/collect_profiles.sh: one run per counter)
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "kodak24_pmc_traffic.json")) as f:
+                pmc = json.load(f)["kernels"]
+        except (OSError, ValueError, KeyError):
+            pmc = {}
+
+        def traffic(name, suffix=""):
+            k = pmc.get(name, {})
+            if "fetch_bytes" + suffix in k and "write_bytes" + suffix in k:
+                return k["fetch_bytes" + suffix] + k["write_bytes" + suffix]
+            return None
+
+        def line(kernel, algo_bytes, ms, tr, note):
+            ach = algo_bytes / (ms / 1e3) / 1e9
+            return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": tr, "algorithmic_bytes": algo_bytes, "ms_per_launch": ms, "note": note}
+
+        # ALGORITHMIC bytes per launch:
+        #   entropy: payload in + one byte per symbol out; upsampling: S + 4 L B/px; synthesis: 4 L + 4 C + C B/px
+        ent_bytes = n_payload + n_sym
+        syn_bytes = (4 * L + 4 * c_out + c_out) * px_per_step
+        # latent planes only (hyperlatents do not reach the upsampling): S = sum of the latent grids of every frame
+        n_lat_px = 0
+        for s_ in range(n_frames):
+            h_ = batch.header(s_)
+            n_lat_px += sum(h_.grid_h[g] * h_.grid_w[g] for g in range(h_.n_grids) if not h_.is_hyperlatent[g])
+        ups_bytes = n_lat_px + 4 * L * px_per_step
         res = {
             "metric": "decoded Mpixel/s", "value": world * px_per_step * args.steps / dt / 1e6, "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -195,9 +220,19 @@ def main():
             "parity": "bit-exact vs CPU oracle (tests/test_gpu_parity.py); <=1 LSB on <=2e-5 of samples vs reference fixture",
             "stage_ms_per_step": stage_ms,
             "entropy_msym_per_s": n_sym / (stage_ms["entropy"] / 1e3) / 1e6,
-            "roofline": {"bound": "hbm", "kernel": "synthesis stage (all layers + integer planes), 24 frames",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_px": syn_bytes_per_px},
+            # the dominant kernel (98 % of the step) is the serial range-decoder chain: one workgroup per stream, bound by
+            # dependent-instruction latency, not by HBM or MFMA - its HBM fraction only shows how far from that roof it sits
+            "roofline": line("entropy_pipe_kernel<5> (24 streams, one workgroup each)", ent_bytes, stage_ms["entropy"],
+                             traffic("entropy_pipe_kernel"),
+                             "latency-bound serial chain (one range decoder per stream): see entropy_msym_per_s and DESIGN.md 4.1"),
+            "roofline_float_stages": [
+                line("upsample_step_kernel x6 (whole pyramid, 24 frames)", ups_bytes, stage_ms["upsampling"],
+                     traffic("upsample_step_kernel", "_per_step"), "HBM-bound; traffic includes the intermediate stacks"),
+                line("syn_fused_kernel<8,3> (all layers + integer planes, 24 frames)", syn_bytes, stage_ms["synthesis"],
+                     traffic("syn_fused_kernel"), "above the fp32 ridge for the HOP network: 1344 flop/px over 43 B/px"),
+            ],
+            "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, raw KiB counters summed "
+                              "(profiles/r01/kodak24_pmc_traffic.json; FETCH_SIZE uncalibrated for 4-byte accesses on gfx950)",
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(streams)
