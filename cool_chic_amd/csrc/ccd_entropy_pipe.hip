@@ -131,26 +131,20 @@ struct DecState {
     unsigned long long wait_by_j[6];  // grid 0, steps with n >= 64: decoder wait per batch position
 };
 
-// Pointers into LDS come in two flavours: generic (`T*`, fine wherever the compiler can trace them back to the shared
-// array, i.e. in code inlined into the kernel) and explicit `lds_ptr<T>` (address space 3) for the decoder, which is
-// a real function with its own register allocation and would otherwise fall back to flat instructions.
-template <typename T> using lds_ptr = T __attribute__((address_space(3)))*;
-template <typename T> __device__ __forceinline__ lds_ptr<T> to_lds(T* p) { return (lds_ptr<T>)p; }
-
-template <typename P> __device__ __forceinline__ void lds_store_release(P p, uint32_t v) {
+__device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // LDS requests of one wave are performed in order, so a relaxed flag store issued after the payload
 // stores is enough for hand-over inside the workgroup; unlike a release it does not also wait for the
 // wave's outstanding GLOBAL stores (the decoder's writes to the latent grid).
-template <typename P> __device__ __forceinline__ void lds_store_ordered(P p, uint32_t v) {
+__device__ __forceinline__ void lds_store_ordered(uint32_t* p, uint32_t v) {
     asm volatile("" ::: "memory");
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     asm volatile("" ::: "memory");
 }
 // All lanes read the same word; readfirstlane tells the compiler the result is wave-uniform so that the
 // control flow hanging off it (and every value defined inside) stays scalar.
-template <typename P> __device__ __forceinline__ uint32_t lds_load_acquire(P p) {
+__device__ __forceinline__ uint32_t lds_load_acquire(const uint32_t* p) {
     return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
 
@@ -161,7 +155,7 @@ __device__ __forceinline__ uint64_t uni(uint64_t v) {
 }
 
 // Spin until *p >= want (sequence numbers only grow). Returns false on abort / timeout.
-template <typename P, typename Q> __device__ __forceinline__ bool wait_ge(P p, uint32_t want, Q s_abort) {
+__device__ __forceinline__ bool wait_ge(const uint32_t* p, uint32_t want, uint32_t* s_abort) {
     if (static_cast<int32_t>(lds_load_acquire(p) - want) >= 0) return true;
     unsigned spins = 0;
     while (static_cast<int32_t>(lds_load_acquire(p) - want) < 0) {
@@ -194,18 +188,9 @@ struct StepIter {
 // =================================================================================================
 // DECODER (wave 0): one grid.  Returns the batch sequence number after the grid.
 // =================================================================================================
-// A real function (not inlined): the serial chain gets its own register allocation instead of competing with the
-// producers' code for the kernel's 104 SGPRs; called once per grid, so the call and the by-reference state cost nothing.
-__device__ __attribute__((noinline)) uint32_t decoder_grid(const PipeCtx& C, DecState& S) {
+__device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) {
     const int lane = threadIdx.x & 63;
     const EntropyParams& P = *C.P;
-    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));  // a (L, P) table entry as a plain vector (uint2 is a class)
-    const lds_ptr<uint32_t> s_ready = to_lds(C.s_ready), s_consumed = to_lds(C.s_consumed), s_abort = to_lds(C.s_abort);
-    const lds_ptr<u32x2> s_tab = (lds_ptr<u32x2>)C.s_tab;
-    const lds_ptr<RowMeta> s_meta = to_lds(C.s_meta);
-    const lds_ptr<int8_t> s_ring = to_lds(C.s_ring);
-    int8_t* const lat = C.lat;
-    const int grid_w = uni(C.W);
     // Everything that steers the decoder is wave-uniform; `uni` (readfirstlane) states it to the compiler,
     // which otherwise treats values loaded through the parameter block as divergent and moves the whole
     // recurrence to VGPRs with exec-mask control flow.
@@ -231,11 +216,11 @@ __device__ __attribute__((noinline)) uint32_t decoder_grid(const PipeCtx& C, Dec
                 const unsigned long long t0 = PROF_T();
                 {   // one counter per slot: every finished part adds 1, the decoder clears it when the batch is consumed
                     const uint32_t n_parts = static_cast<uint32_t>((cnt + task_pix - 1) / task_pix);
-                    if (uni(lds_load_acquire(&s_ready[slot])) != n_parts) {
+                    if (uni(lds_load_acquire(&C.s_ready[slot])) != n_parts) {
 #ifdef CCD_PIPE_PROFILE
                         const unsigned long long ts = __builtin_amdgcn_s_memtime();
 #endif
-                        if (!wait_ge(&s_ready[slot], n_parts, s_abort)) ok = false;
+                        if (!wait_ge(&C.s_ready[slot], n_parts, C.s_abort)) ok = false;
 #ifdef CCD_PIPE_PROFILE
                         S.stall_ticks += __builtin_amdgcn_s_memtime() - ts;
                         S.stall_events += 1;
@@ -250,10 +235,10 @@ __device__ __attribute__((noinline)) uint32_t decoder_grid(const PipeCtx& C, Dec
 #endif
             }
             const unsigned long long t_dec = PROF_T();
-            const lds_ptr<u32x2> tab = s_tab + row0 * 64 + lane;
-            const lds_ptr<RowMeta> meta = s_meta;
+            const uint2* tab = C.s_tab + static_cast<size_t>(row0) * 64 + lane;
+            const RowMeta& meta = *C.s_meta;
             int raw = 0;  // lane i: window lane chosen for pixel i
-            const int top_l = meta->top[row0 + (lane & (kBatch - 1))];  // needed after the loop: the read overlaps it
+            const int top_l = meta.top[row0 + (lane & (kBatch - 1))];  // needed after the loop: the read overlaps it
             // ---- symbol loop: hand-scheduled recurrence (see the file header).  The asm block walks symbols
             // i .. cnt-1 and stops early (status 1) at the first symbol whose new range has a zero high word:
             // renormalisation, window miss or invalid data - all handled in C++ below, then the loop resumes.
@@ -358,7 +343,7 @@ __device__ __attribute__((noinline)) uint32_t decoder_grid(const PipeCtx& C, Dec
                       "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49");
                 if (status == 0) break;
                 // ---- rare path for symbol i (state untouched by the asm block) -----------------------------------
-                const u32x2 cur = tab[i * 64];
+                const uint2 cur = tab[i * 64];
                 const uint32_t sc_lo = static_cast<uint32_t>(rc_range >> 24);
                 const uint32_t sc_hi = static_cast<uint32_t>(rc_range >> 56);
                 const uint64_t p0 = static_cast<uint64_t>(sc_lo) * cur.x;
@@ -374,12 +359,12 @@ __device__ __attribute__((noinline)) uint32_t decoder_grid(const PipeCtx& C, Dec
                     // symbol outside the window (or invalid data): full 128-way search
                     const uint64_t scale = rc_range >> kRcPrecision;
                     if ((rc_dist >> kRcPrecision) >= scale) {
-                        lds_store_release(s_abort, static_cast<uint32_t>(-CCD_ERR_INVALID_DATA));
+                        lds_store_release(C.s_abort, static_cast<uint32_t>(-CCD_ERR_INVALID_DATA));
                         ok = false;
                         break;
                     }
-                    const double mu = -64.0 + static_cast<double>(meta->mu_idx[row0 + i]) * (1.0 / 256.0);
-                    const double b = meta->b[row0 + i], rcp = meta->rcp[row0 + i];
+                    const double mu = -64.0 + static_cast<double>(meta.mu_idx[row0 + i]) * (1.0 / 256.0);
+                    const double b = meta.b[row0 + i], rcp = meta.rcp[row0 + i];
                     const uint32_t f0 = window_left(mu, b, rcp, kAcLo + lane);
                     const uint32_t f1 = window_left(mu, b, rcp, kAcLo + 64 + lane);
                     const unsigned long long m0 = __ballot(scale * f0 <= rc_dist), m1 = __ballot(scale * f1 <= rc_dist);
@@ -389,7 +374,7 @@ __device__ __attribute__((noinline)) uint32_t decoder_grid(const PipeCtx& C, Dec
                     if (sidx == kAlphabet - 1) right = 1u << kRcPrecision;
                     nd = rc_dist - scale * left;
                     nr = scale * static_cast<uint64_t>(right - left);
-                    k = uni(1 - ((sidx + kAcLo) - meta->top[row0 + i]));  // top - (k - 1) == symbol
+                    k = uni(1 - ((sidx + kAcLo) - meta.top[row0 + i]));  // top - (k - 1) == symbol
                 }
                 if (static_cast<uint32_t>(nr >> 32) == 0) {
                     nr <<= 32;
@@ -406,11 +391,11 @@ __device__ __attribute__((noinline)) uint32_t decoder_grid(const PipeCtx& C, Dec
             if (lane < cnt) {
                 const int y = it.y0 + i0 + lane, x = it.x0 - 10 * (i0 + lane);
                 const int sym = top_l - (raw - 1);
-                s_ring[(y & (kRingRows - 1)) * 64 + ((x + 10 * y) & 63)] = static_cast<int8_t>(sym);
-                lat[y * grid_w + x] = static_cast<int8_t>(sym);
+                C.s_ring[(y & (kRingRows - 1)) * 64 + ((x + 10 * y) & 63)] = static_cast<int8_t>(sym);
+                C.lat[y * C.W + x] = static_cast<int8_t>(sym);
             }
-            lds_store_ordered(&s_ready[slot], 0u);  // before `consumed`: the slot's next producers wait for that
-            lds_store_ordered(s_consumed, seq + 1);
+            lds_store_ordered(&C.s_ready[slot], 0u);  // before `consumed`: the slot's next producers wait for that
+            lds_store_ordered(C.s_consumed, seq + 1);
             PROF_ADD(S.prof_work, t_dec);
         }
     }
