@@ -352,3 +352,47 @@ def test_video_1080p_gop(gpu, oracle):
                 assert np.array_equal(got, want[i]["planes"][p]), f"frame {i} plane {p}"
     finally:
         lib().ccd_video_free(C.byref(v))
+
+
+@pytest.mark.parametrize("donor_name,sizes", [
+    ("rgb192", [(1, 1), (1, 13), (13, 1), (7, 9), (9, 10), (10, 9), (17, 33), (64, 65), (100, 37), (129, 257)]),
+    ("yuv420_8b", [(2, 2), (10, 18), (34, 66), (130, 94)]),
+    ("cr192", [(5, 11), (63, 130)]),
+])
+def test_ragged_picture_sizes(gpu, oracle, donor_name, sizes):
+    """Edge geometry: 1-pixel pictures, grids narrower than ten columns (raster coding order instead of the wavefront,
+    latent.py:113-122), odd sizes (ceil at every pyramid level, crop after every x2 upsampling), tile borders of the
+    float kernels, 4:2:0 chroma of small pictures.  Streams: the donor's trained networks, seeded random latents,
+    written with the bitstream writer; latents and integer planes bit-exact against the oracle."""
+    from cool_chic_amd import writer
+
+    bs, z, j = load_golden(donor_name)
+    (fh, ccs), = oracle.split_stream(bs)[1]
+    hdr, nn, _ = ccs[0]
+    donor = writer.parse_cc_header(hdr)
+    rng = np.random.default_rng(20240926)
+    streams, lat_in = [], []
+    for (h, w) in sizes:
+        arch = writer.derive_arch(donor, img_size=(h, w))
+        nn_i = nn
+        if writer.network_layout(arch) != writer.network_layout(donor):
+            # the reference derives a grid's level from the HEIGHT ratio (component/core/coolchic.py:209-211): on 1-pixel-high
+            # pictures every grid counts as level 0 and takes IFCE inputs - the network grows
+            nn_i = writer.encode_network(arch, writer.adapt_network(donor, z["cc0.nn_ints"], arch))
+        lat = [np.clip(np.rint(rng.laplace(0.0, 1.2, size=(arch.grid_h[g], arch.grid_w[g]))), -20, 20).astype(np.int8)
+               for g in range(arch.n_grids)]
+        streams.append(writer.encode_stream(writer.cc_header_bytes(arch), nn_i, lat, bitdepth=fh.bitdepth,
+                                            frame_data_type=fh.frame_data_type))
+        lat_in.append(lat)
+    triples = [oracle.split_stream(s)[1][0][1][0] for s in streams]
+    b = _decode(gpu, triples, fh.bitdepth, fh.frame_data_type)
+    try:
+        for i, (s, lat) in enumerate(zip(streams, lat_in)):
+            assert b.slot_status(i) == 0
+            for g, a in enumerate(lat):
+                assert np.array_equal(b.latent(i, g), a), f"size {sizes[i]} grid {g}"
+            want = oracle.decode_video(s)[0]["planes"]
+            for p, (got, w_) in enumerate(zip(b.planes(i), want)):
+                assert got.shape == w_.shape and np.array_equal(got.astype(np.uint16), w_), f"size {sizes[i]} plane {p}"
+    finally:
+        b.close()
