@@ -131,6 +131,19 @@ def _np(ptr, shape, dtype):
     return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype).reshape(shape).copy()
 
 
+def read_cc_header(raw: bytes):
+    """(CCHeader, Geometry) of one cool-chic header: sections 2 and 3 of cc_oracle.c."""
+    L = lib()
+    h, g = CCHeader(), Geometry()
+    used = L.ora_read_cc_header(raw, len(raw), C.byref(h))
+    if used < 0:
+        raise OracleError(f"cc header: {used}")
+    rc = L.ora_geometry_from_header(C.byref(h), C.byref(g))
+    if rc < 0:
+        raise OracleError(f"geometry: {rc}")
+    return h, g
+
+
 def split_stream(bitstream: bytes):
     """Walk a .cool file: returns (video_header, [(frame_header, [(hdr_bytes, nn_bytes, lat_bytes), ...])])."""
     L = lib()

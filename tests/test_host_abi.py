@@ -136,3 +136,92 @@ def test_writer_reproduces_reference_streams(oracle):
                 out.append(writer.encode_coolchic(arch, nn, lat))
                 cc_idx += 1
         assert b"".join(out) == bs, name
+
+
+def test_random_headers_round_trip_and_agree_with_the_oracle(oracle):
+    """Seeded sweep over the header space: every transmitted cool-chic field drawn at random (architectures, picture
+    sizes, latent / hyperlatent / IFCE ranges, quantisation-step and Exp-Golomb indices, synthesis layers), frame
+    headers of all three types with signed global flows, video headers with intra / P position lists.  Written with the
+    C ABI writers, parsed back by the C ABI readers (all fields equal) and by the oracle (same fields, same derived
+    geometry: grid sizes, hyperlatent flags, IFCE inputs, synthesis inputs)."""
+    import ctypes as C
+
+    from cool_chic_amd import writer
+    from cool_chic_amd._lib import CCHeader, FrameHeader, VideoHeader, check, lib
+
+    rng = np.random.default_rng(7)
+    q_first = [-8, -16, -8, -16, -12, 0, -12, -24]
+    q_count = [9, 17, 9, 17, 13, 1, 13, 25]
+    for _ in range(300):
+        a = CCHeader()
+        a.linear_stabiliser_synth = int(rng.integers(0, 2)); a.n_layer_synthesis = int(rng.integers(1, 6))
+        a.ups_k_size = int(rng.choice([4, 6, 8])); a.ups_preconcat_k_size = int(rng.choice([3, 5, 7]))
+        a.spatial_context_arm = int(rng.integers(1, 25)); a.output_feature_ifce = int(rng.integers(0, 8))
+        a.linear_stabiliser_arm = int(rng.integers(0, 2)); a.n_hidden_layers_arm = int(rng.integers(0, 4))
+        a.img_size[0], a.img_size[1] = int(rng.integers(1, 4000)), int(rng.integers(1, 4000))
+        lo = int(rng.integers(0, 4)); hi = int(rng.integers(lo, 9))
+        a.latent_resolution[0], a.latent_resolution[1] = lo, hi
+        a.flag_hyperlatent = int(rng.integers(0, 2))
+        if a.flag_hyperlatent:
+            hl = int(rng.integers(0, 9)); a.hyperlatent_resolution[0], a.hyperlatent_resolution[1] = hl, int(rng.integers(hl, 9))
+        a.n_latent_grids = (hi - lo + 1) + ((a.hyperlatent_resolution[1] - a.hyperlatent_resolution[0] + 1) if a.flag_hyperlatent else 0)
+        a.flag_common_randomness = int(rng.integers(0, 2)); a.final_upsampling_type = int(rng.integers(0, 3))
+        for i in range(8):
+            a.nn_q_step_log2[i] = q_first[i] + int(rng.integers(0, q_count[i]))
+            a.nn_expgol_cnt[i] = int(rng.integers(0, 13))  # POSSIBLE_EXP_GOL_COUNT: 0..12 (nnquant/expgolomb.py:20-37)
+        a.nn_n_bytes, a.nn_n_bit_pad, a.n_bytes_latent = int(rng.integers(0, 16384)), int(rng.integers(0, 8)), 4 * int(rng.integers(0, 1 << 20))
+        if a.output_feature_ifce > 0:
+            il = int(rng.integers(0, 9)); a.ifce_resolution[0], a.ifce_resolution[1] = il, int(rng.integers(il, 9))
+        c_in = (hi - lo + 1) * (2 if a.flag_common_randomness else 1)
+        for l in range(a.n_layer_synthesis):
+            mode = int(rng.integers(0, 2))
+            a.syn_layer[l].out_ft = c_in if mode else int(rng.integers(1, 64))
+            a.syn_layer[l].k_size = int(rng.choice([1, 3, 5])); a.syn_layer[l].mode = mode
+            a.syn_layer[l].non_linearity = int(rng.integers(0, 2))
+            c_in = a.syn_layer[l].out_ft
+        raw = writer.cc_header_bytes(a)
+        b = writer.parse_cc_header(raw)
+        assert b.n_bytes_header == len(raw)
+        for name, ctype in CCHeader._fields_:
+            if name in ("n_bytes_header", "has_ifce_resolution") or name in ("n_grids", "grid_h", "grid_w", "is_hyperlatent",
+                                                                               "input_features_ifce", "input_feature_synthesis",
+                                                                               "total_context_arm", "out_channels", "n_symbols"):
+                continue
+            va, vb = getattr(a, name), getattr(b, name)
+            if name == "syn_layer":
+                for l in range(a.n_layer_synthesis):
+                    assert (va[l].out_ft, va[l].k_size, va[l].mode, va[l].non_linearity) == (vb[l].out_ft, vb[l].k_size, vb[l].mode, vb[l].non_linearity)
+            elif name in ("ifce_resolution", "hyperlatent_resolution") and not (a.output_feature_ifce if name[0] == "i" else a.flag_hyperlatent):
+                continue
+            elif hasattr(va, "__len__"):
+                assert list(va) == list(vb), name
+            else:
+                assert va == vb, name
+        oh, og = oracle.read_cc_header(raw)
+        assert (oh.img_size[0], oh.img_size[1], oh.n_bytes_header, oh.n_bytes_latent) == (a.img_size[0], a.img_size[1], len(raw), a.n_bytes_latent)
+        assert og.n_grids == b.n_grids
+        assert list(og.grid_h[: og.n_grids]) == list(b.grid_h[: b.n_grids]) and list(og.grid_w[: og.n_grids]) == list(b.grid_w[: b.n_grids])
+        assert list(og.is_hyper[: og.n_grids]) == list(b.is_hyperlatent[: b.n_grids])
+        assert list(og.input_features_ifce[: og.n_grids]) == list(b.input_features_ifce[: b.n_grids])
+        assert og.input_feature_synthesis == b.input_feature_synthesis and og.total_context_arm == b.total_context_arm
+    # out-of-table indices raise like the reference (element.py:289-292)
+    from cool_chic_amd import CcdError
+    a.nn_expgol_cnt[3] = 13
+    with pytest.raises(CcdError):
+        writer.parse_cc_header(writer.cc_header_bytes(a))
+    for _ in range(200):
+        ft = int(rng.integers(0, 3))
+        refs = [int(x) for x in rng.integers(0, 4096, size=ft)]
+        flows = [int(x) for x in rng.integers(-8191, 8192, size=2 * ft)]
+        raw = writer.frame_header_bytes(int(rng.integers(0, 4096)), "IPB"[ft], int(rng.integers(0, 4)), int(rng.integers(8, 17)), refs,
+                                        flows, int(rng.integers(0, 16)))
+        f = FrameHeader()
+        assert check(lib().ccd_read_frame_header(raw, len(raw), C.byref(f)), "read") == len(raw)
+        assert f.frame_type == ft and list(f.index_references[:ft]) == refs and list(f.global_flow[: 2 * ft]) == flows
+    for _ in range(50):
+        n_i, n_p = int(rng.integers(0, 40)), int(rng.integers(0, 40))
+        ip, pp = [int(x) for x in rng.integers(0, 4096, size=n_i)], [int(x) for x in rng.integers(0, 4096, size=n_p)]
+        raw = writer.video_header_bytes(int(rng.integers(1, 4096)), ip, pp)
+        v = VideoHeader()
+        assert check(lib().ccd_read_video_header(raw, len(raw), C.byref(v)), "read") == len(raw)
+        assert list(v.intra_pos[:n_i]) == ip and list(v.p_pos[:n_p]) == pp
