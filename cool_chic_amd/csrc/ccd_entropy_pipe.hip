@@ -34,6 +34,12 @@ namespace ccd {
 #define PROF_T() 0ull
 #define PROF_ADD(var, t0) (void)(t0)
 #endif
+// level 1 only: four stamps per task of producer 0 (idle before the early wait, early work, late wait, late work)
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 1
+#define LPROF_T(cond) ((cond) ? __builtin_amdgcn_s_memtime() : 0ull)
+#else
+#define LPROF_T(cond) 0ull
+#endif
 
 constexpr int kPipeThreads = 512;           // 8 waves: 1 decoder + 7 producers
 constexpr int kPipeWaves = kPipeThreads / 64;
@@ -118,7 +124,8 @@ struct PipeCtx {
     int dim, n_layers, n_sp, n_if, n_w_hidden;
     // per grid
     int H, W, fin, fh, fw;
-    int task_pix;          // pixels per producer task in this grid (8 or 4)
+    int task_pix;          // pixels per producer task in this grid (8, 4 or 2)
+    int k_left;            // index of the context (y, x - 1) among the spatial contexts, -1 if the mask has none
     int8_t* lat;
     uint32_t seq_base;
 };
@@ -127,7 +134,7 @@ struct DecState {
     uint64_t dist, range;  // dist = point - lower (all the decoder ever uses)
     uint32_t word_pos, wbase, wbuf;
     uint64_t n_decoded;
-    unsigned long long prof_wait, prof_work, stall_ticks, stall_events;
+    unsigned long long prof_wait, prof_work, stall_ticks, stall_events, n_rare, n_search;
     unsigned long long wait_by_j[6];  // grid 0, steps with n >= 64: decoder wait per batch position
 };
 
@@ -222,8 +229,10 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
 #endif
                         if (!wait_ge(&C.s_ready[slot], n_parts, C.s_abort)) ok = false;
 #ifdef CCD_PIPE_PROFILE
-                        S.stall_ticks += __builtin_amdgcn_s_memtime() - ts;
+                        const unsigned long long dts = __builtin_amdgcn_s_memtime() - ts;
+                        S.stall_ticks += dts;
                         S.stall_events += 1;
+                        if (it.n >= 48) S.wait_by_j[min(i0 / bpx, 5)] += dts;  // finest grid: stall ticks by batch position
 #endif
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -342,6 +351,9 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                     : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "v40", "v41",
                       "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49");
                 if (status == 0) break;
+#ifdef CCD_PIPE_PROFILE
+                S.n_rare += 1;
+#endif
                 // ---- rare path for symbol i (state untouched by the asm block) -----------------------------------
                 const uint2 cur = tab[i * 64];
                 const uint32_t sc_lo = static_cast<uint32_t>(rc_range >> 24);
@@ -356,6 +368,9 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 uint64_t nd = rc_dist - ((static_cast<uint64_t>(l_hi) << 32) | l_lo);
                 uint64_t nr = static_cast<uint64_t>(sc_lo) * psel + (static_cast<uint64_t>(sc_hi * psel) << 32);
                 if (nr == 0) {
+#ifdef CCD_PIPE_PROFILE
+                    S.n_search += 1;
+#endif
                     // symbol outside the window (or invalid data): full 128-way search
                     const uint64_t scale = rc_range >> kRcPrecision;
                     if ((rc_dist >> kRcPrecision) >= scale) {
@@ -439,10 +454,23 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     int32_t* act = C.s_act + pw * 8 * in_pad;        // this wave's activation tile [kTaskPix][in_pad]
     const int px = lane / kLpp, q = lane % kLpp;     // pixel of the task, lane within its group
     const int4* act_row = reinterpret_cast<const int4*>(act + px * in_pad);
+    // Per-lane constants of the gather: the lane always fetches inputs k = q + kLpp t.  Read through the parameter block
+    // inside the task loop they were global loads on every task's path.
+    int ctx_dy_l[NOUT], ctx_dx_l[NOUT];
+#pragma unroll
+    for (int t = 0; t < NOUT; ++t) {
+        const int k = q + kLpp * t;
+        ctx_dy_l[t] = k < n_sp ? P.ctx_dy[k] : 0;
+        ctx_dx_l[t] = k < n_sp ? P.ctx_dx[k] : 0;
+    }
+    const int32_t* const ifce_feat = P.ifce_feat;
+    const int feat_plane = C.fh * C.fw;
     StepIter it;
     it.init(C.H, C.W);
     uint32_t seq = C.seq_base, prev_first = C.seq_base;
     int prev_nb = 0, prev_n = 0, prev_y0 = 0;
+    uint32_t prev2_first = C.seq_base;
+    int prev2_nb = 0, prev2_n = 0, prev2_y0 = 0;
     bool ok = true;
     while (ok && it.next()) {
         const int nb = (it.n + kBpx - 1) / kBpx;
@@ -461,20 +489,26 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     const int k = q + kLpp * t;
                     fv[t] = 0;
                     if (px < cnt && k >= n_sp && k < dim && C.fin > 0)
-                        fv[t] = P.ifce_feat[(k - n_sp) * C.fh * C.fw + (y >> 1) * C.fw + (x >> 1)];
+                        fv[t] = ifce_feat[(k - n_sp) * feat_plane + (y >> 1) * C.fw + (x >> 1)];
                 }
-                // Slot free again?  Pixels this task reads decoded?  Its left neighbours sit in the previous step at pixel
-                // index <= i0 + cnt, i.e. in that step's batch (i0 + cnt) / kBatch (clamped to its last batch).
-                uint32_t need = seq >= static_cast<uint32_t>(kNSlots) ? seq - kNSlots + 1 : 0;
-                // The only context in the previous step is the left neighbour (y, x - 1): pixel i of this step reads pixel i of
-                // the previous one - pixel i + 1 when the previous step started one row higher (once in ten steps).
-                if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 != prev_y0 ? 1 : 0), prev_n - 1) / kBpx) + 1);
+                // ---- Two waits.  Of all contexts only the left neighbour (y, x - 1) lies in the previous step (pixel i of this
+                // step reads pixel i of that one, pixel i + 1 when the step start moved down a row in between); (y, x - 2) lies
+                // two steps back, everything else at least five.  So the task gathers every other input, runs the stabiliser and
+                // the first layer on them BEFORE the left neighbour is decoded, and only adds that one term afterwards: the
+                // critical path from "symbol decoded" to "table ready" loses the gather and a third of the MLP.
+                const bool split = C.k_left >= 0 && !it.raster && n_layers >= 2;
+                uint32_t need = seq >= static_cast<uint32_t>(kNSlots) ? seq - kNSlots + 1 : 0;  // slot free again (table / meta rows)
+                if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev_y0), prev_n - 1) / kBpx) + 1);
                 need = max(need, C.seq_base);
+                uint32_t need_early = C.seq_base;
+                if (prev2_nb > 0) need_early = max(need_early, prev2_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev2_y0), prev2_n - 1) / kBpx) + 1);
+                const unsigned long long lt_a = LPROF_T(pw == 0);
                 {
                     const unsigned long long t0 = PROF_T();
-                    if (!wait_ge(C.s_consumed, need, C.s_abort)) { ok = false; break; }
+                    if (!wait_ge(C.s_consumed, split ? need_early : need, C.s_abort)) { ok = false; break; }
                     PROF_ADD(prof[0], t0);
                 }
+                const unsigned long long lt_b = LPROF_T(pw == 0);
                 const unsigned long long t_g = PROF_T();
                 // ---- gather: lane q of the pixel's group fetches inputs k = q, q + 8, ... --------------------------
                 if (px < cnt) {
@@ -484,8 +518,9 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         if (k < in_pad) {
                             int32_t v = fv[t];
                             if (k < n_sp) {
-                                const int yy = y - P.ctx_dy[k], xx = x + P.ctx_dx[k];
-                                v = (yy >= 0 && xx >= 0 && xx < W) ? C.s_ring[(yy & (kRingRows - 1)) * 64 + ((xx + 10 * yy) & 63)] : 0;
+                                const int yy = y - ctx_dy_l[t], xx = x + ctx_dx_l[t];
+                                v = (yy >= 0 && xx >= 0 && xx < W && !(split && k == C.k_left))
+                                        ? C.s_ring[(yy & (kRingRows - 1)) * 64 + ((xx + 10 * yy) & 63)] : 0;
                             }
                             act[px * in_pad + k] = v << 16;  // armint.py:193
                         }
@@ -502,8 +537,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 PROF_ADD(prof[4], t_m);  // activation reload
                 const unsigned long long t_s = PROF_T();
                 int64_t so[2];  // [0]: stabiliser output (lanes q < 2), [1]: scratch second chain
-                {   // stabiliser branch on the raw inputs; lanes q >= 2 compute a discarded copy of row 1
-                    const int qs = q < 2 ? q : 1;
+                const int qs = q < 2 ? q : 1;  // lanes q >= 2 compute a discarded copy of row 1
+                {   // stabiliser branch on the raw inputs
                     const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + 2 * in_pad + qs * in_pad);
                     so[0] = C.s_b[(n_layers - 1) * dim + 2 + qs];
                     so[1] = 0;
@@ -514,10 +549,57 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         mad64(a, xv[v].x, w.x); mad64(a, xv[v].y, w.y); mad64(a, xv[v].z, w.z); mad64(a, xv[v].w, w.w);
                     }
                 }
-                const int64_t stab = so[0] + so[1];
                 PROF_ADD(prof[5], t_s);
                 const unsigned long long t_h = PROF_T();
-                for (int l = 0; l < n_layers - 1; ++l) {
+                // first hidden layer on the early inputs (the only layer when the late wait does not apply is handled alike:
+                // the left term is then simply zero and the gather above already took the neighbour)
+                int64_t acc0[NOUT];
+                int32_t wleft[NOUT], wleft_stab = 0;
+                if (n_layers >= 2) {
+                    const int32_t* wl = C.s_w;
+                    const int64_t* bl = C.s_b;
+                    const int4* wr[NOUT];
+                    const int kl = split ? C.k_left : 0;
+#pragma unroll
+                    for (int t = 0; t < NOUT; ++t) {
+                        const int oc = min(q + kLpp * t, dim - 1);  // rows past the layer: a discarded copy of the last one
+                        wr[t] = reinterpret_cast<const int4*>(wl + oc * in_pad);
+                        acc0[t] = bl[oc];
+                        wleft[t] = wl[oc * in_pad + kl];
+                    }
+                    wleft_stab = C.s_w[C.n_w_hidden + 2 * in_pad + qs * in_pad + kl];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        int4 w[NOUT];
+#pragma unroll
+                        for (int t = 0; t < NOUT; ++t) w[t] = wr[t][v];
+                        CCD_MAD4(acc0, xv[v], w, NOUT)
+                    }
+                }
+                // ---- the left neighbour: wait for it (and for the slot), add its term to the first layer and the stabiliser
+                int32_t xleft = 0;
+                const unsigned long long lt_c = LPROF_T(pw == 0);
+                if (split) {
+                    const unsigned long long t0 = PROF_T();
+                    if (!wait_ge(C.s_consumed, need, C.s_abort)) { ok = false; break; }
+                    PROF_ADD(prof[0], t0);
+                    if (px < cnt && x >= 1) xleft = static_cast<int32_t>(C.s_ring[(y & (kRingRows - 1)) * 64 + ((x - 1 + 10 * y) & 63)]) << 16;
+                }
+                const unsigned long long lt_d = LPROF_T(pw == 0);
+                mad64(so[0], xleft, wleft_stab);
+                const int64_t stab = so[0] + so[1];
+                if (n_layers >= 2) {
+#pragma unroll
+                    for (int t = 0; t < NOUT; ++t) {
+                        mad64(acc0[t], xleft, wleft[t]);
+                        const int o = q + kLpp * t;
+                        const int64_t a = acc0[t] < 0 ? 0 : acc0[t];
+                        if (o < in_pad) act[px * in_pad + o] = o < dim ? static_cast<int32_t>(a >> 16) : 0;
+                    }
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) xv[v] = act_row[v];
+                }
+                for (int l = 1; l < n_layers - 1; ++l) {
                     const int32_t* wl = C.s_w + l * dim * in_pad;
                     const int64_t* bl = C.s_b + l * dim;
                     int64_t acc[NOUT];
@@ -656,9 +738,16 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 }
                 if (lane == 0) __hip_atomic_fetch_add(&C.s_ready[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 PROF_ADD(prof[3], t_t);
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 1
+                if (pw == 0) {
+                    const unsigned long long lt_e = __builtin_amdgcn_s_memtime();
+                    prof[0] += lt_b - lt_a; prof[1] += lt_c - lt_b; prof[2] += lt_d - lt_c; prof[3] += lt_e - lt_d; prof[8] += 1;
+                }
+#endif
             }
         }
         if (!ok) break;
+        prev2_first = prev_first; prev2_nb = prev_nb; prev2_n = prev_n; prev2_y0 = prev_y0;
         prev_first = seq - nb;
         prev_nb = nb;
         prev_n = it.n;
@@ -703,6 +792,8 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     C.s_consumed = s_sync + kSlots;
     C.s_abort = C.s_consumed + 1;
     C.dim = dim; C.n_layers = n_layers; C.n_sp = P.n_spatial; C.n_if = n_if;
+    C.k_left = -1;
+    for (int k = 0; k < P.n_spatial; ++k) if (P.ctx_dy[k] == 0 && P.ctx_dx[k] == -1) C.k_left = k;
 
     // ---- stage the network: int64 blob (w[in][out], b[out] per layer; ws[dim][2], bs[2]) -> int32 Wt[out][in_pad]
     {
@@ -731,7 +822,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
 
     DecState S;
     S.range = ~uint64_t{0}; S.dist = 0; S.word_pos = 2; S.wbase = 2; S.wbuf = 0; S.n_decoded = 0;
-    S.prof_wait = 0; S.prof_work = 0; S.stall_ticks = 0; S.stall_events = 0;
+    S.prof_wait = 0; S.prof_work = 0; S.stall_ticks = 0; S.stall_events = 0; S.n_rare = 0; S.n_search = 0;
     for (int i = 0; i < 6; ++i) S.wait_by_j[i] = 0;
     if (wave == 0) {
         // loads through pointers stored in the parameter block are FLAT loads, which the compiler treats as
@@ -857,7 +948,10 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     if (lane == 0 && wave < 2) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(P.status + 4) + wave * 5;
         o[0] = __builtin_amdgcn_s_memtime() - prof_total0;
-        if (wave == 0) { o[1] = S.prof_wait; o[2] = S.prof_work; o[3] = prof_ifce; o[4] = prof_bar; }
+        if (wave == 0) {
+            o[1] = S.prof_wait; o[2] = S.prof_work; o[3] = prof_ifce; o[4] = prof_bar;
+            P.status[62] = static_cast<int32_t>(S.n_rare); P.status[63] = static_cast<int32_t>(S.n_search);  // leaves of the asm loop, full searches
+        }
         else {
             o[1] = prof[0]; o[2] = prof[1]; o[3] = prof[2]; o[4] = prof[3];
             unsigned long long* e = reinterpret_cast<unsigned long long*>(P.status + 40);
