@@ -155,6 +155,11 @@ __device__ __forceinline__ uint32_t lds_load_acquire(const uint32_t* p) {
     return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
 }
 
+// Pointers read from the parameter block are generic: their loads / stores compile to FLAT instructions, which count on
+// lgkmcnt as well as vmcnt - so every later LDS wait (the hand-over flags!) also waited for the global access to
+// complete.  An explicit global address space gives global_load / global_store (vmcnt only).
+template <typename T> using glb_ptr = T __attribute__((address_space(1)))*;
+
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint64_t uni(uint64_t v) {
@@ -207,6 +212,8 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     uint64_t rc_dist = uni(S.dist), rc_range = uni(S.range);
     uint32_t word_pos = uni(S.word_pos), wbase = uni(S.wbase), wbuf = S.wbuf;
     const uint32_t n_words = uni(P.n_words);
+    const glb_ptr<const uint32_t> words_g = (glb_ptr<const uint32_t>)P.words;
+    const glb_ptr<int8_t> lat_g = (glb_ptr<int8_t>)C.lat;
     const int task_pix = uni(C.task_pix);
     // pixels per batch: 16 (two 8-pixel or four 4-pixel tasks) or 8 (four 2-pixel tasks).  32-pixel batches were tried:
     // the decoder saves ~20 ticks / symbol of per-batch overhead, but progress is published (and the producers of the next
@@ -395,7 +402,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                     nr <<= 32;
                     nd = (nd << 32) | static_cast<uint32_t>(__builtin_amdgcn_readlane(wbuf, (word_pos - wbase) & 63));
                     ++word_pos;
-                    if (word_pos - wbase == 64) { wbase = word_pos; wbuf = (wbase + lane < n_words) ? P.words[wbase + lane] : 0u; }
+                    if (word_pos - wbase == 64) { wbase = word_pos; wbuf = (wbase + lane < n_words) ? words_g[wbase + lane] : 0u; }
                 }
                 rc_dist = uni(nd); rc_range = uni(nr);
                 asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(raw) : "s"(k), "s"(i));
@@ -407,7 +414,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 const int y = it.y0 + i0 + lane, x = it.x0 - 10 * (i0 + lane);
                 const int sym = top_l - (raw - 1);
                 C.s_ring[(y & (kRingRows - 1)) * 64 + ((x + 10 * y) & 63)] = static_cast<int8_t>(sym);
-                C.lat[y * C.W + x] = static_cast<int8_t>(sym);
+                lat_g[y * C.W + x] = static_cast<int8_t>(sym);
             }
             lds_store_ordered(&C.s_ready[slot], 0u);  // before `consumed`: the slot's next producers wait for that
             lds_store_ordered(C.s_consumed, seq + 1);
@@ -456,6 +463,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     const int4* act_row = reinterpret_cast<const int4*>(act + px * in_pad);
     // Per-lane constants of the gather: the lane always fetches inputs k = q + kLpp t.  Read through the parameter block
     // inside the task loop they were global loads on every task's path.
+    unsigned long long lt_prev_end = 0;  // level-1 profile: end of producer 0's previous task
+    (void)lt_prev_end;
     int ctx_dy_l[NOUT], ctx_dx_l[NOUT];
 #pragma unroll
     for (int t = 0; t < NOUT; ++t) {
@@ -463,7 +472,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
         ctx_dy_l[t] = k < n_sp ? P.ctx_dy[k] : 0;
         ctx_dx_l[t] = k < n_sp ? P.ctx_dx[k] : 0;
     }
-    const int32_t* const ifce_feat = P.ifce_feat;
+    const glb_ptr<const int32_t> ifce_feat = (glb_ptr<const int32_t>)P.ifce_feat;
     const int feat_plane = C.fh * C.fw;
     StepIter it;
     it.init(C.H, C.W);
@@ -503,6 +512,9 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 uint32_t need_early = C.seq_base;
                 if (prev2_nb > 0) need_early = max(need_early, prev2_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev2_y0), prev2_n - 1) / kBpx) + 1);
                 const unsigned long long lt_a = LPROF_T(pw == 0);
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 1
+                if (pw == 0 && lt_prev_end) prof[4] += lt_a - lt_prev_end;
+#endif
                 {
                     const unsigned long long t0 = PROF_T();
                     if (!wait_ge(C.s_consumed, split ? need_early : need, C.s_abort)) { ok = false; break; }
@@ -742,6 +754,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 if (pw == 0) {
                     const unsigned long long lt_e = __builtin_amdgcn_s_memtime();
                     prof[0] += lt_b - lt_a; prof[1] += lt_c - lt_b; prof[2] += lt_d - lt_c; prof[3] += lt_e - lt_d; prof[8] += 1;
+                    lt_prev_end = lt_e;
                 }
 #endif
             }
