@@ -455,9 +455,13 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     constexpr int kNSlots = kRows / kBpx;
     constexpr int NOUT = (in_pad + kLpp - 1) / kLpp;  // outputs per lane in a hidden layer
     const int lane = threadIdx.x & 63;
-    const int pw = (threadIdx.x >> 6) - 1;
+    // Everything that steers the task loop is wave-uniform; stated with readfirstlane, the loop control, the dependency
+    // arithmetic and the task filter run on the scalar unit instead of as exec-masked vector code.
+    const int pw = uni(static_cast<int>(threadIdx.x >> 6) - 1);
     const EntropyParams& P = *C.P;
-    const int dim = C.dim, n_layers = C.n_layers, n_sp = C.n_sp, W = C.W;
+    const int dim = uni(C.dim), n_layers = uni(C.n_layers), n_sp = uni(C.n_sp), W = uni(C.W);
+    const int k_left = uni(C.k_left), fin = uni(C.fin), fw = uni(C.fw);
+    const uint32_t seq_base = uni(C.seq_base);
     int32_t* act = C.s_act + pw * 8 * in_pad;        // this wave's activation tile [kTaskPix][in_pad]
     const int px = lane / kLpp, q = lane % kLpp;     // pixel of the task, lane within its group
     const int4* act_row = reinterpret_cast<const int4*>(act + px * in_pad);
@@ -473,12 +477,12 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
         ctx_dx_l[t] = k < n_sp ? P.ctx_dx[k] : 0;
     }
     const glb_ptr<const int32_t> ifce_feat = (glb_ptr<const int32_t>)P.ifce_feat;
-    const int feat_plane = C.fh * C.fw;
+    const int feat_plane = uni(C.fh) * fw;
     StepIter it;
-    it.init(C.H, C.W);
-    uint32_t seq = C.seq_base, prev_first = C.seq_base;
+    it.init(uni(C.H), W);
+    uint32_t seq = seq_base, prev_first = seq_base;
     int prev_nb = 0, prev_n = 0, prev_y0 = 0;
-    uint32_t prev2_first = C.seq_base;
+    uint32_t prev2_first = seq_base;
     int prev2_nb = 0, prev2_n = 0, prev2_y0 = 0;
     bool ok = true;
     while (ok && it.next()) {
@@ -497,19 +501,19 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 for (int t = 0; t < NOUT; ++t) {
                     const int k = q + kLpp * t;
                     fv[t] = 0;
-                    if (px < cnt && k >= n_sp && k < dim && C.fin > 0)
-                        fv[t] = ifce_feat[(k - n_sp) * feat_plane + (y >> 1) * C.fw + (x >> 1)];
+                    if (px < cnt && k >= n_sp && k < dim && fin > 0)
+                        fv[t] = ifce_feat[(k - n_sp) * feat_plane + (y >> 1) * fw + (x >> 1)];
                 }
                 // ---- Two waits.  Of all contexts only the left neighbour (y, x - 1) lies in the previous step (pixel i of this
                 // step reads pixel i of that one, pixel i + 1 when the step start moved down a row in between); (y, x - 2) lies
                 // two steps back, everything else at least five.  So the task gathers every other input, runs the stabiliser and
                 // the first layer on them BEFORE the left neighbour is decoded, and only adds that one term afterwards: the
                 // critical path from "symbol decoded" to "table ready" loses the gather and a third of the MLP.
-                const bool split = C.k_left >= 0 && !it.raster && n_layers >= 2;
+                const bool split = k_left >= 0 && !it.raster && n_layers >= 2;
                 uint32_t need = seq >= static_cast<uint32_t>(kNSlots) ? seq - kNSlots + 1 : 0;  // slot free again (table / meta rows)
                 if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev_y0), prev_n - 1) / kBpx) + 1);
-                need = max(need, C.seq_base);
-                uint32_t need_early = C.seq_base;
+                need = max(need, seq_base);
+                uint32_t need_early = seq_base;
                 if (prev2_nb > 0) need_early = max(need_early, prev2_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev2_y0), prev2_n - 1) / kBpx) + 1);
                 const unsigned long long lt_a = LPROF_T(pw == 0);
 #if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 1
@@ -531,7 +535,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                             int32_t v = fv[t];
                             if (k < n_sp) {
                                 const int yy = y - ctx_dy_l[t], xx = x + ctx_dx_l[t];
-                                v = (yy >= 0 && xx >= 0 && xx < W && !(split && k == C.k_left))
+                                v = (yy >= 0 && xx >= 0 && xx < W && !(split && k == k_left))
                                         ? C.s_ring[(yy & (kRingRows - 1)) * 64 + ((xx + 10 * yy) & 63)] : 0;
                             }
                             act[px * in_pad + k] = v << 16;  // armint.py:193
@@ -571,7 +575,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     const int32_t* wl = C.s_w;
                     const int64_t* bl = C.s_b;
                     const int4* wr[NOUT];
-                    const int kl = split ? C.k_left : 0;
+                    const int kl = split ? k_left : 0;
 #pragma unroll
                     for (int t = 0; t < NOUT; ++t) {
                         const int oc = min(q + kLpp * t, dim - 1);  // rows past the layer: a discarded copy of the last one
