@@ -31,6 +31,7 @@ def _flags():
     if os.environ.get("CCD_PIPE_PROFILE"):
         # cycle counters in the entropy kernel (ccd_batch_slot_stats): 1 = light (stalls, per-grid totals), 2 = every phase
         flags.append("-DCCD_PIPE_PROFILE=" + os.environ["CCD_PIPE_PROFILE"])
+    flags += os.environ.get("CCD_EXTRA_FLAGS", "").split()  # e.g. -DCCD_T8=48 for tuning experiments
     return flags
 
 

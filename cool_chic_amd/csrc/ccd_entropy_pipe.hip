@@ -41,6 +41,13 @@ namespace ccd {
 #define LPROF_T(cond) 0ull
 #endif
 
+// widest step of a grid >= CCD_T8 pixels: 8-pixel tasks; >= CCD_T4: 4-pixel tasks; else 2-pixel tasks (tunable at build time)
+#ifndef CCD_T8
+#define CCD_T8 29
+#endif
+#ifndef CCD_T4
+#define CCD_T4 15
+#endif
 constexpr int kPipeThreads = 512;           // 8 waves: 1 decoder + 7 producers
 constexpr int kPipeWaves = kPipeThreads / 64;
 constexpr int kProducers = kPipeWaves - 1;
@@ -865,7 +872,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         {   // widest wavefront step of the grid decides the task shape
             const int n_max = C.W <= 9 ? 1 : min(C.H, (C.W - 1) / 10 + 1);
             // wide steps: 8-pixel tasks (throughput); short steps: the fewer pixels a task holds, the sooner its batch is ready
-            C.task_pix = n_max >= 29 ? 8 : (n_max >= 15 ? 4 : 2);  // at most ~7 tasks per step: one round of the producers
+            C.task_pix = n_max >= CCD_T8 ? 8 : (n_max >= CCD_T4 ? 4 : 2);  // at most ~7 tasks per step: one round of the producers
         }
         // ---- IFCE features at the previously decoded grid's size (coolchic.py:94-146) -------------
         // Per-channel source descriptors and the (tiny) linear layer are staged in LDS first: read through the
