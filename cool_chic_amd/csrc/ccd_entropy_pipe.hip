@@ -492,14 +492,21 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     uint32_t prev2_first = seq_base;
     int prev2_nb = 0, prev2_n = 0, prev2_y0 = 0;
     bool ok = true;
+    // Task t of a step (pixels t kTaskPix ..) has the global index seq0 kHalves + t and belongs to producer index % kProducers:
+    // a producer visits only its own tasks (first owned one of the step, then every kProducers-th).
+    int phase = static_cast<int>((static_cast<unsigned long long>(seq_base) * kHalves) % kProducers);  // (seq0 kHalves) mod kProducers
     while (ok && it.next()) {
         const int nb = (it.n + kBpx - 1) / kBpx;
-        for (int j = 0; j < nb && ok; ++j, ++seq) {
-            const int slot = seq % kNSlots;
-            for (int half = 0; half < kHalves; ++half) {
-                const int i0 = j * kBpx + half * kTaskPix;     // first pixel of the task within the step
-                if (i0 >= it.n) break;
-                if (static_cast<int>((seq * kHalves + half) % kProducers) != pw) continue;
+        const int n_tasks = (it.n + kTaskPix - 1) / kTaskPix;
+        const uint32_t seq0 = seq;
+        int t_first = pw - phase;
+        t_first += t_first < 0 ? kProducers : 0;
+        {
+            for (int task = t_first; task < n_tasks; task += kProducers) {
+                const int j = task / kHalves, half = task % kHalves;
+                seq = seq0 + static_cast<uint32_t>(j);
+                const int slot = seq % kNSlots;
+                const int i0 = task * kTaskPix;                // first pixel of the task within the step
                 const int cnt = min(kTaskPix, it.n - i0);
                 const int y = it.y0 + i0 + px, x = it.x0 - 10 * (i0 + px);
                 // ---- IFCE features do not depend on this grid: fetch them before waiting on the decoder -------
@@ -771,6 +778,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
             }
         }
         if (!ok) break;
+        seq = seq0 + static_cast<uint32_t>(nb);
+        phase = (phase + nb * kHalves) % kProducers;
         prev2_first = prev_first; prev2_nb = prev_nb; prev2_n = prev_n; prev2_y0 = prev_y0;
         prev_first = seq - nb;
         prev_nb = nb;
