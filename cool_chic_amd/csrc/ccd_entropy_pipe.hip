@@ -20,6 +20,7 @@
 // Reference behaviour restated: bitstream/component/latent.py:18-187, armint.py:180-203,
 // coolchic.py:89-169, rangecoder.py:80-94 (constriction RangeDecoder + QuantizedLaplace(-64,63)).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "ccd_device.hpp"
 
@@ -115,19 +116,33 @@ struct alignas(16) RowMeta {  // per table row (= pixel of a batch in flight)
     int32_t top[kRows];     // symbol of window lane 1
 };
 
+// The workgroup's dynamic LDS.  Regions are referred to by 32-bit byte offsets (LdsRef): a generic 64-bit pointer per
+// region would pin two SGPRs each for the whole kernel (eleven regions), and the compiler could no longer see that the
+// accesses are LDS accesses once a pointer travelled through a struct.
+extern __shared__ __attribute__((aligned(16))) unsigned char ccd_pipe_smem[];
+template <typename T>
+struct LdsRef {
+    uint32_t off;
+    __device__ __forceinline__ operator T*() const { return reinterpret_cast<T*>(ccd_pipe_smem + off); }
+    __device__ __forceinline__ LdsRef& operator=(T* p) {
+        off = static_cast<uint32_t>(reinterpret_cast<unsigned char*>(const_cast<typename std::remove_const<T>::type*>(p)) - ccd_pipe_smem);
+        return *this;
+    }
+};
+
 struct PipeCtx {
     const EntropyParams* P;
-    uint2* s_tab;          // [kRows][64] (L, P)
-    RowMeta* s_meta;
-    const double* s_rcp;   // [kNumScale] RN(1 / b): LDS copies of the two Laplace-scale tables (a global load per
-    const float* s_scale;  // [kNumScale] b        pixel would put an L2 round trip on every task's critical path)
-    int32_t* s_w;          // transposed int32 weights Wt[out][in_pad]
-    int64_t* s_b;          // biases: hidden layers, output (2), stabiliser (2)
-    int32_t* s_act;        // [kProducers][8][in_pad] (a task holds at most 8 pixels)
-    int8_t* s_ring;        // [kRingRows][64]
-    uint32_t* s_ready;     // [kSlots] parts of the slot's batch finished by the producers (cleared by the decoder)
-    uint32_t* s_consumed;
-    uint32_t* s_abort;
+    LdsRef<uint2> s_tab;          // [kRows][64] (L, P)
+    LdsRef<RowMeta> s_meta;
+    LdsRef<const double> s_rcp;   // [kNumScale] RN(1 / b): LDS copies of the two Laplace-scale tables (a global load per
+    LdsRef<const float> s_scale;  // [kNumScale] b        pixel would put an L2 round trip on every task's critical path)
+    LdsRef<int32_t> s_w;          // transposed int32 weights Wt[out][in_pad]
+    LdsRef<int64_t> s_b;          // biases: hidden layers, output (2), stabiliser (2)
+    LdsRef<int32_t> s_act;        // [kProducers][8][in_pad] (a task holds at most 8 pixels)
+    LdsRef<int8_t> s_ring;        // [kRingRows][64]
+    LdsRef<uint32_t> s_ready;     // [kSlots] parts of the slot's batch finished by the producers (cleared by the decoder)
+    LdsRef<uint32_t> s_consumed;
+    LdsRef<uint32_t> s_abort;
     int dim, n_layers, n_sp, n_if, n_w_hidden;
     // per grid
     int H, W, fin, fh, fw;
@@ -793,7 +808,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 // (all widths in one kernel cost 444 SGPR spills and VGPR scratch in every path).
 template <int NV>
 __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const EntropyParams* slots_desc) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const smem = ccd_pipe_smem;
     const EntropyParams& P = slots_desc[blockIdx.x];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -888,7 +903,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         // parameter block inside the loops they would cost a dependent HBM round trip per multiply.
         if (C.fin > 0) {
             const int fin = C.fin, fh = C.fh, fw = C.fw;
-            int64_t* s_fw = reinterpret_cast<int64_t*>(C.s_tab);                 // [fin][n_if] then bias [n_if] (tables are idle here)
+            int64_t* s_fw = reinterpret_cast<int64_t*>(static_cast<uint2*>(C.s_tab));                 // [fin][n_if] then bias [n_if] (tables are idle here)
             const int8_t** s_src = reinterpret_cast<const int8_t**>(s_fw + fin * n_if + n_if);  // [fin]
             int32_t* s_gw = reinterpret_cast<int32_t*>(s_src + fin);            // [fin]
             int32_t* s_sh = s_gw + fin;                                          // [fin]
