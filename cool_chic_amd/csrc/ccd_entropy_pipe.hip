@@ -27,16 +27,17 @@
 namespace ccd {
 
 // -DCCD_PIPE_PROFILE=1: light counters (per-grid totals, decoder stalls: nothing on the fast path);
-// -DCCD_PIPE_PROFILE=2: a time stamp around every phase (each costs an SMEM round trip: perturbs the pipeline).
-#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE >= 2
+// -DCCD_PIPE_PROFILE=2: + five stamps per task of producer 0 (idle / early work / late wait / late work / between tasks);
+// -DCCD_PIPE_PROFILE=3: a time stamp around every phase (each costs an SMEM round trip: perturbs the pipeline).
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE >= 3
 #define PROF_T() __builtin_amdgcn_s_memtime()
 #define PROF_ADD(var, t0) var += __builtin_amdgcn_s_memtime() - (t0)
 #else
 #define PROF_T() 0ull
 #define PROF_ADD(var, t0) (void)(t0)
 #endif
-// level 1 only: four stamps per task of producer 0 (idle before the early wait, early work, late wait, late work)
-#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 1
+// level 2 only: stamps per task of producer 0 (idle before the early wait, early work, late wait, late work)
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
 #define LPROF_T(cond) ((cond) ? __builtin_amdgcn_s_memtime() : 0ull)
 #else
 #define LPROF_T(cond) 0ull
@@ -268,7 +269,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 }
                 if (!ok) break;
                 PROF_ADD(S.prof_wait, t0);
-#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE >= 2
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE >= 3
                 if (C.W == 768 && it.n >= 64) S.wait_by_j[min(i0 / bpx, 5)] += __builtin_amdgcn_s_memtime() - t0;
 #endif
             }
@@ -545,7 +546,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 uint32_t need_early = seq_base;
                 if (prev2_nb > 0) need_early = max(need_early, prev2_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev2_y0), prev2_n - 1) / kBpx) + 1);
                 const unsigned long long lt_a = LPROF_T(pw == 0);
-#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 1
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
                 if (pw == 0 && lt_prev_end) prof[4] += lt_a - lt_prev_end;
 #endif
                 {
@@ -704,7 +705,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 const unsigned long long narrow_lanes = __ballot(q == 1 && px < cnt && idx <= kNarrowMaxScale);
                 PROF_ADD(prof[2], t_m);
                 PROF_ADD(prof[7], t_o);
-#ifdef CCD_PIPE_PROFILE
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE >= 3
                 prof[8] += 1;
 #endif
                 const unsigned long long t_t = PROF_T();
@@ -783,7 +784,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 }
                 if (lane == 0) __hip_atomic_fetch_add(&C.s_ready[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 PROF_ADD(prof[3], t_t);
-#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 1
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
                 if (pw == 0) {
                     const unsigned long long lt_e = __builtin_amdgcn_s_memtime();
                     prof[0] += lt_b - lt_a; prof[1] += lt_c - lt_b; prof[2] += lt_d - lt_c; prof[3] += lt_e - lt_d; prof[8] += 1;

@@ -1,4 +1,4 @@
-"""Heavy-profile (CCD_PIPE_PROFILE=2 build) phase times of the producers on a kodim14-architecture stream cropped to
+"""Heavy-profile (CCD_PIPE_PROFILE=3 build) phase times of the producers on a kodim14-architecture stream cropped to
 H x W (default 128 x 192: every grid runs 2-pixel tasks; 256 x 384: the top grid runs 4-pixel tasks)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
