@@ -243,6 +243,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     // step released) only half as often, which costs more in stalls than it saves.
     const int bpx = task_pix == 2 ? 8 : 16;
     const int slot_mask = kRows / bpx - 1;       // 8 / 16 slots share the 128 table rows
+    const int task_shift = task_pix == 8 ? 3 : (task_pix == 4 ? 2 : 1);
     bool ok = true;
     while (ok && it.next()) {
         for (int i0 = 0; i0 < it.n; i0 += bpx, ++seq) {
@@ -252,7 +253,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
             {
                 const unsigned long long t0 = PROF_T();
                 {   // one counter per slot: every finished part adds 1, the decoder clears it when the batch is consumed
-                    const uint32_t n_parts = static_cast<uint32_t>((cnt + task_pix - 1) / task_pix);
+                    const uint32_t n_parts = static_cast<uint32_t>((cnt + task_pix - 1) >> task_shift);
                     if (uni(lds_load_acquire(&C.s_ready[slot])) != n_parts) {
 #ifdef CCD_PIPE_PROFILE
                         const unsigned long long ts = __builtin_amdgcn_s_memtime();
@@ -291,6 +292,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                     "s_mov_b64 s[52:53], %[rng]\n\t"
                     "ds_read_b64 v[40:41], %[ta]\n\t"
                     "ds_read_b64 v[42:43], %[ta] offset:512\n\t"
+                    ".p2align 6\n\t"  // the loop head on an instruction-fetch boundary: timing no longer moves with unrelated code
                     "1:\n\t"
                     // ---- copy 0: (L, P) of the current symbol in v[40:41], two rows ahead in flight
                     "ds_read_b64 v[46:47], %[ta] offset:1024\n\t"
