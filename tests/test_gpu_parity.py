@@ -396,3 +396,31 @@ def test_ragged_picture_sizes(gpu, oracle, donor_name, sizes):
                 assert got.shape == w_.shape and np.array_equal(got.astype(np.uint16), w_), f"size {sizes[i]} plane {p}"
     finally:
         b.close()
+
+
+def test_repeated_runs_are_identical(gpu, oracle):
+    """The pipelined entropy kernel hands work between waves through LDS flags; a lost or early hand-over would show as a
+    run-to-run difference.  One batch (kodim14 twice + the small fixtures), twenty runs, every latent and plane equal."""
+    import hashlib
+
+    triples = []
+    for name in ["kodim14", "rgb192", "yuv444_10b", "kodim14", "cr192", "bicubic190"]:
+        bs, _, _ = load_golden(name)
+        triples.append(oracle.split_stream(bs)[1][0][1][0])
+    b = gpu(0)
+    for t in triples:
+        b.add(*t, 8, 0)
+    try:
+        ref = None
+        for it in range(20):
+            b.run(); b.wait()
+            h = hashlib.sha256()
+            for s in range(len(triples)):
+                for g in range(b.header(s).n_grids):
+                    h.update(np.ascontiguousarray(b.latent(s, g)).tobytes())
+                for p in b.planes(s):
+                    h.update(np.ascontiguousarray(p).tobytes())
+            ref = ref or h.hexdigest()
+            assert h.hexdigest() == ref, f"run {it} differs from run 0"
+    finally:
+        b.close()
