@@ -27,13 +27,18 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 // Each thread produces a 2x2 output quad.  For the x2 transposed conv the four outputs of a quad read one
 // shared (k/2+1)^2 window of the input (5x5 for k = 8) and the k x k kron products are formed once per
 // thread and reused by every channel; accumulation order per output is unchanged (ky ascending, kx ascending).
+// Global address space stated explicitly: through the level descriptor the pointers are generic and would be accessed with
+// FLAT instructions (slower address path, and they count on lgkmcnt as well as vmcnt).
+typedef const float __attribute__((address_space(1)))* gcf_t;
+typedef const int8_t __attribute__((address_space(1)))* gci8_t;
+typedef float __attribute__((address_space(1)))* gf_t;
 constexpr int kUpsMaxK = 8;   // fast path for ups_k <= 8 / pre_k <= 7; larger kernels use the generic body
 
 __device__ __forceinline__ void upsample_generic_one(const UpsampleLevel& L, int ch, int ox, int oy) {
     float acc = 0.0f;
     if (ch == 0) {
         const int k = L.pre_k, pad = k / 2;
-        const int8_t* t = L.target;
+        const gci8_t t = (gci8_t)L.target;
         for (int ky = 0; ky < k; ++ky) {
             const int sy = oy + ky - pad;
             if (sy < 0 || sy >= L.h_out) continue;
@@ -49,7 +54,7 @@ __device__ __forceinline__ void upsample_generic_one(const UpsampleLevel& L, int
         const int k = L.ups_k, p0 = k / 2, crop = 2 * p0 - 1 + k / 2;
         const int h = L.h_in, w = L.w_in;
         const int py = oy + crop, px = ox + crop;
-        const float* inf = L.in_f32 ? L.in_f32 + static_cast<size_t>(ch - 1) * h * w : nullptr;
+        const gcf_t inf = L.in_f32 ? (gcf_t)L.in_f32 + static_cast<size_t>(ch - 1) * h * w : (gcf_t) nullptr;
         for (int ky = py & 1; ky < k; ky += 2) {
             const int iy = (py - ky) / 2;
             if (py - ky < 0 || iy >= h + 2 * p0) continue;
@@ -59,12 +64,12 @@ __device__ __forceinline__ void upsample_generic_one(const UpsampleLevel& L, int
                 if (px - kx < 0 || ix >= w + 2 * p0) continue;
                 const int sx = clampi(ix - p0, 0, w - 1);
                 const float k2 = L.ups_w[ky] * L.ups_w[kx];
-                const float v = inf ? inf[sy * w + sx] : static_cast<float>(L.in_i8[sy * w + sx]);
+                const float v = inf ? inf[sy * w + sx] : static_cast<float>(((gci8_t)L.in_i8)[sy * w + sx]);
                 acc = __fmaf_rn(v, k2, acc);
             }
         }
     }
-    L.out[(static_cast<size_t>(ch) * L.h_out + oy) * L.w_out + ox] = acc;
+    ((gf_t)L.out)[(static_cast<size_t>(ch) * L.h_out + oy) * L.w_out + ox] = acc;
 }
 
 // x2 transposed conv, k == 8 (the value every preset uses): quad (qy, qx) -> outputs (2qy + dy, 2qx + dx).
@@ -85,7 +90,7 @@ __device__ __forceinline__ void tconv8_quad(const UpsampleLevel& L, int qx, int 
     for (int ch = ch_first; ch <= ch_last; ++ch) {
         float v[5][5];
         if (L.in_f32) {
-            const float* src = L.in_f32 + static_cast<size_t>(ch - 1) * h * w;
+            const gcf_t src = (gcf_t)L.in_f32 + static_cast<size_t>(ch - 1) * h * w;
 #pragma unroll
             for (int a = 0; a < 5; ++a)
 #pragma unroll
@@ -94,7 +99,7 @@ __device__ __forceinline__ void tconv8_quad(const UpsampleLevel& L, int qx, int 
 #pragma unroll
             for (int a = 0; a < 5; ++a)
 #pragma unroll
-                for (int b = 0; b < 5; ++b) v[a][b] = static_cast<float>(L.in_i8[sy[a] + sx[b]]);
+                for (int b = 0; b < 5; ++b) v[a][b] = static_cast<float>(((gci8_t)L.in_i8)[sy[a] + sx[b]]);
         }
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
@@ -113,7 +118,7 @@ __device__ __forceinline__ void tconv8_quad(const UpsampleLevel& L, int qx, int 
                     }
                 }
                 const int oy = oy0 + dy, ox = ox0 + dx;
-                if (oy < L.h_out && ox < L.w_out) L.out[(static_cast<size_t>(ch) * L.h_out + oy) * L.w_out + ox] = acc;
+                if (oy < L.h_out && ox < L.w_out) ((gf_t)L.out)[(static_cast<size_t>(ch) * L.h_out + oy) * L.w_out + ox] = acc;
             }
         }
     }
@@ -124,7 +129,7 @@ __device__ __forceinline__ void tconv8_quad(const UpsampleLevel& L, int qx, int 
 // (acc is never -0), which equals the oracle's skipping of those taps.
 __device__ __forceinline__ void preconv7_quad(const UpsampleLevel& L, int qx, int qy) {
     const int h = L.h_out, w = L.w_out;
-    const int8_t* __restrict__ t = L.target;
+    const gci8_t t = (gci8_t)L.target;
     float wv[7];
 #pragma unroll
     for (int i = 0; i < 7; ++i) wv[i] = L.pre_w[i];
@@ -151,7 +156,7 @@ __device__ __forceinline__ void preconv7_quad(const UpsampleLevel& L, int qx, in
                 for (int kx = 0; kx < 7; ++kx) acc = __fmaf_rn(v[dy + ky][dx + kx], wv[ky] * wv[kx], acc);
             acc = acc + v[dy + 3][dx + 3];
             const int oy = 2 * qy + dy, ox = 2 * qx + dx;
-            if (oy < h && ox < w) L.out[static_cast<size_t>(oy) * w + ox] = acc;
+            if (oy < h && ox < w) ((gf_t)L.out)[static_cast<size_t>(oy) * w + ox] = acc;
         }
     }
 }

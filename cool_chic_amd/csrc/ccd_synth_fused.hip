@@ -58,15 +58,18 @@ __global__ __launch_bounds__(kSfThreads) void syn_fused_kernel(const SynthFused*
     const int tx0 = blockIdx.x * iw - R, ty0 = blockIdx.y * ih - R;  // image coordinate of extended (0, 0)
     const int H = p.h, W = p.w;
     const size_t plane = static_cast<size_t>(H) * W;
-    const float* __restrict__ prm = p.params;
-    const float* __restrict__ dense = p.dense;
+    // explicit global address space: through the descriptor these are generic pointers, whose FLAT loads / stores also
+    // count on lgkmcnt - every wait for an LDS tile would wait for the HBM traffic as well
+    typedef const float __attribute__((address_space(1)))* gcf_t;
+    const gcf_t dense = (gcf_t)p.dense;
+    const gcf_t prm = (gcf_t)p.params;
 
     // ---- phase 1: the two 1x1 layers, per pixel, evaluated at clamped image coordinates -------------
     {
-        const float* __restrict__ w0 = prm + p.w0_off;  // [N][CP]
-        const float* __restrict__ b0 = prm + p.b0_off;
-        const float* __restrict__ w1 = prm + p.w1_off;  // [C][N]
-        const float* __restrict__ b1 = prm + p.b1_off;
+        const gcf_t w0 = prm + p.w0_off;  // [N][CP]
+        const gcf_t b0 = prm + p.b0_off;
+        const gcf_t w1 = prm + p.w1_off;  // [C][N]
+        const gcf_t b1 = prm + p.b1_off;
         const int N = p.n_hidden;
 #pragma unroll 1
         for (int g = 0; g < kSfPerThread / kSfGroup; ++g) {
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(kSfThreads) void syn_fused_kernel(const SynthFused*
                 const int pos = tid + kSfThreads * (g * kSfGroup + u);
                 const int ey = pos / kSfEW, ex = pos % kSfEW;
                 const int gy = sf_clamp(ty0 + ey, 0, H - 1), gx = sf_clamp(tx0 + ex, 0, W - 1);
-                const float* src = dense + static_cast<size_t>(gy) * W + gx;
+                const gcf_t src = dense + static_cast<size_t>(gy) * W + gx;
 #pragma unroll
                 for (int c = 0; c < CP; ++c) x[u][c] = c < p.c_in ? src[c * plane] : 0.0f;
 #pragma unroll
@@ -124,8 +127,8 @@ __global__ __launch_bounds__(kSfThreads) void syn_fused_kernel(const SynthFused*
     float* nxt = bufB;
     for (int l = 0; l < p.n_conv; ++l) {
         const int k = p.conv_k[l], pad = (k - 1) / 2;
-        const float* __restrict__ wl = prm + p.conv_w_off[l];  // [C][C][k][k]
-        const float* __restrict__ bl = prm + p.conv_b_off[l];
+        const gcf_t wl = prm + p.conv_w_off[l];  // [C][C][k][k]
+        const gcf_t bl = prm + p.conv_b_off[l];
         const int residual = p.conv_residual[l], relu = p.conv_relu[l];
 #pragma unroll 1
         for (int m = 0; m < kSfPerThread; ++m) {
@@ -186,10 +189,10 @@ __global__ __launch_bounds__(kSfThreads) void syn_fused_kernel(const SynthFused*
     }
 
     // ---- epilogue: + stabiliser, output transform, stores ------------------------------------------------
-    const float* __restrict__ ws = prm + p.stab_w_off;  // [C][c_in]
-    const float* __restrict__ bs = prm + p.stab_b_off;
-    const float* __restrict__ wo = prm + p.out_w_off;   // [C][C]
-    const float* __restrict__ bo = prm + p.out_b_off;
+    const gcf_t ws = prm + p.stab_w_off;  // [C][c_in]
+    const gcf_t bs = prm + p.stab_b_off;
+    const gcf_t wo = prm + p.out_w_off;   // [C][C]
+    const gcf_t bo = prm + p.out_b_off;
     const float maxv = static_cast<float>((1 << p.bitdepth) - 1);
 #pragma unroll 1
     for (int m = 0; m < kSfPerThread; ++m) {
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(kSfThreads) void syn_fused_kernel(const SynthFused*
 #pragma unroll
         for (int j = 0; j < C; ++j) y[j] = cur[j * kSfPos + pos];
         if (p.has_stab) {
-            const float* src = dense + static_cast<size_t>(gy) * W + gx;
+            const gcf_t src = dense + static_cast<size_t>(gy) * W + gx;
             float xs[CP];
 #pragma unroll
             for (int c = 0; c < CP; ++c) xs[c] = c < p.stab_c_in ? src[c * plane] : 0.0f;
@@ -224,14 +227,14 @@ __global__ __launch_bounds__(kSfThreads) void syn_fused_kernel(const SynthFused*
         const size_t idx = static_cast<size_t>(gy) * W + gx;
         if (p.out) {
 #pragma unroll
-            for (int j = 0; j < C; ++j) p.out[j * plane + idx] = out[j];
+            for (int j = 0; j < C; ++j) ((float __attribute__((address_space(1)))*)p.out)[j * plane + idx] = out[j];
         }
         if (p.write_planes) {  // rgb / yuv444 integer samples (decode.py:191-206); yuv420 goes through planes_kernel
 #pragma unroll
             for (int j = 0; j < (C < 3 ? C : 3); ++j) {
                 const unsigned q = sf_quantise(out[j], maxv);
-                if (p.bitdepth == 8) static_cast<uint8_t*>(p.plane[j])[idx] = static_cast<uint8_t>(q);
-                else static_cast<uint16_t*>(p.plane[j])[idx] = static_cast<uint16_t>(q);
+                if (p.bitdepth == 8) ((uint8_t __attribute__((address_space(1)))*)p.plane[j])[idx] = static_cast<uint8_t>(q);
+                else ((uint16_t __attribute__((address_space(1)))*)p.plane[j])[idx] = static_cast<uint16_t>(q);
             }
         }
     }
