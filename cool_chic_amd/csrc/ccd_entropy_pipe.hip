@@ -292,76 +292,79 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                     "s_mov_b64 s[52:53], %[rng]\n\t"
                     "ds_read_b64 v[40:41], %[ta]\n\t"
                     "ds_read_b64 v[42:43], %[ta] offset:512\n\t"
-                    ".p2align 6\n\t"  // the loop head on an instruction-fetch boundary: timing no longer moves with unrelated code
+                    ".p2align 6\n\t"
                     "1:\n\t"
-                    // ---- copy 0: (L, P) of the current symbol in v[40:41], two rows ahead in flight
-                    "ds_read_b64 v[46:47], %[ta] offset:1024\n\t"
+                    // ---- copy 0: (L, P) of the current symbol in v[40:41], two rows ahead in flight.  Order found by sweeping
+                    // orderings in tools/ubench/dloop_variants.hip: compare before the scale * P products, range before dist.
                     "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                    "ds_read_b64 v[46:47], %[ta] offset:1024\n\t"
                     "s_waitcnt lgkmcnt(2)\n\t"
                     "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
-                    "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
                     "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                    "v_mad_u32_u24 v49, v41, s41, v49\n\t"
                     "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                    "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
+                    "v_mad_u32_u24 v49, v41, s41, v49\n\t"
+                    "s_mov_b32 m0, %[i]\n\t"
                     "s_ff1_i32_b64 s44, vcc\n\t"
-                    "v_readlane_b32 s46, v44, s44\n\t"
-                    "v_readlane_b32 s47, v45, s44\n\t"
                     "v_readlane_b32 s48, v48, s44\n\t"
                     "v_readlane_b32 s49, v49, s44\n\t"
+                    "v_readlane_b32 s46, v44, s44\n\t"
+                    "v_readlane_b32 s47, v45, s44\n\t"
                     "s_cmp_eq_u32 s49, 0\n\t"
                     "s_cbranch_scc1 3f\n\t"
+                    "s_mov_b64 s[52:53], s[48:49]\n\t"
                     "s_sub_u32 s50, s50, s46\n\t"
                     "s_subb_u32 s51, s51, s47\n\t"
-                    "s_mov_b64 s[52:53], s[48:49]\n\t"
-                    "s_mov_b32 m0, %[i]\n\t"
                     "v_writelane_b32 %[raw], s44, m0\n\t"
                     "s_add_u32 %[i], %[i], 1\n\t"
                     "s_cmp_lt_u32 %[i], %[cnt]\n\t"
                     "s_cbranch_scc0 2f\n\t"
-                    // ---- copy 1: (L, P) of the current symbol in v[42:43], two rows ahead in flight
-                    "ds_read_b64 v[40:41], %[ta] offset:1536\n\t"
+                    // ---- copy 1: (L, P) of the current symbol in v[42:43], two rows ahead in flight.  Order found by sweeping
+                    // orderings in tools/ubench/dloop_variants.hip: compare before the scale * P products, range before dist.
                     "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                    "ds_read_b64 v[40:41], %[ta] offset:1536\n\t"
                     "s_waitcnt lgkmcnt(2)\n\t"
                     "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
-                    "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
                     "v_mad_u32_u24 v45, v42, s41, v45\n\t"
-                    "v_mad_u32_u24 v49, v43, s41, v49\n\t"
                     "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                    "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
+                    "v_mad_u32_u24 v49, v43, s41, v49\n\t"
+                    "s_mov_b32 m0, %[i]\n\t"
                     "s_ff1_i32_b64 s44, vcc\n\t"
-                    "v_readlane_b32 s46, v44, s44\n\t"
-                    "v_readlane_b32 s47, v45, s44\n\t"
                     "v_readlane_b32 s48, v48, s44\n\t"
                     "v_readlane_b32 s49, v49, s44\n\t"
+                    "v_readlane_b32 s46, v44, s44\n\t"
+                    "v_readlane_b32 s47, v45, s44\n\t"
                     "s_cmp_eq_u32 s49, 0\n\t"
                     "s_cbranch_scc1 3f\n\t"
+                    "s_mov_b64 s[52:53], s[48:49]\n\t"
                     "s_sub_u32 s50, s50, s46\n\t"
                     "s_subb_u32 s51, s51, s47\n\t"
-                    "s_mov_b64 s[52:53], s[48:49]\n\t"
-                    "s_mov_b32 m0, %[i]\n\t"
                     "v_writelane_b32 %[raw], s44, m0\n\t"
                     "s_add_u32 %[i], %[i], 1\n\t"
                     "s_cmp_lt_u32 %[i], %[cnt]\n\t"
                     "s_cbranch_scc0 2f\n\t"
-                    // ---- copy 2: (L, P) of the current symbol in v[46:47], two rows ahead in flight
-                    "ds_read_b64 v[42:43], %[ta] offset:2048\n\t"
+                    // ---- copy 2: (L, P) of the current symbol in v[46:47], two rows ahead in flight.  Order found by sweeping
+                    // orderings in tools/ubench/dloop_variants.hip: compare before the scale * P products, range before dist.
                     "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                    "ds_read_b64 v[42:43], %[ta] offset:2048\n\t"
                     "s_waitcnt lgkmcnt(2)\n\t"
                     "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
-                    "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
                     "v_mad_u32_u24 v45, v46, s41, v45\n\t"
-                    "v_mad_u32_u24 v49, v47, s41, v49\n\t"
                     "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                    "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
+                    "v_mad_u32_u24 v49, v47, s41, v49\n\t"
+                    "s_mov_b32 m0, %[i]\n\t"
                     "s_ff1_i32_b64 s44, vcc\n\t"
-                    "v_readlane_b32 s46, v44, s44\n\t"
-                    "v_readlane_b32 s47, v45, s44\n\t"
                     "v_readlane_b32 s48, v48, s44\n\t"
                     "v_readlane_b32 s49, v49, s44\n\t"
+                    "v_readlane_b32 s46, v44, s44\n\t"
+                    "v_readlane_b32 s47, v45, s44\n\t"
                     "s_cmp_eq_u32 s49, 0\n\t"
                     "s_cbranch_scc1 3f\n\t"
+                    "s_mov_b64 s[52:53], s[48:49]\n\t"
                     "s_sub_u32 s50, s50, s46\n\t"
                     "s_subb_u32 s51, s51, s47\n\t"
-                    "s_mov_b64 s[52:53], s[48:49]\n\t"
-                    "s_mov_b32 m0, %[i]\n\t"
                     "v_writelane_b32 %[raw], s44, m0\n\t"
                     "s_add_u32 %[i], %[i], 1\n\t"
                     "v_add_u32 %[ta], 0x600, %[ta]\n\t"
