@@ -117,7 +117,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     from cool_chic_amd import DecodeBatch
-    from cool_chic_amd.parallel import gather_bytes
+    from cool_chic_amd.parallel import EqualSizeGather
 
     items, streams = build_kodak24(local_rank)
     n_frames = len(items)
@@ -130,11 +130,12 @@ def main():
     sh = stream.cuda_stream
     dev = f"cuda:{local_rank}"
 
+    planes = [torch.as_tensor(batch.plane_device(s, p), device=dev).reshape(-1) for s in range(n_frames) for p in range(3)]
+    gatherer = EqualSizeGather(sum(int(p.numel()) * p.element_size() for p in planes), dev, dst=0) if world > 1 else None
+
     def gather_planes():
-        if world == 1:
-            return
-        planes = [torch.as_tensor(batch.plane_device(s, p), device=dev).reshape(-1) for s in range(n_frames) for p in range(3)]
-        gather_bytes(torch.cat(planes), dst=0)
+        if world > 1:  # decoded integer planes of this rank's frames -> writer rank (RCCL over xGMI), inside the timed region
+            gatherer(planes)
 
     def step():
         batch.run(sh)

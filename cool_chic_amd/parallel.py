@@ -40,6 +40,22 @@ def gather_bytes(local: torch.Tensor, dst: int = 0, group=None) -> Optional[List
     return [b[: int(s.item())] for b, s in zip(bucket, sizes)]
 
 
+class EqualSizeGather:
+    """Gather of same-sized byte messages to `dst` with persistent buffers: no size exchange, no host synchronisation, no
+    per-call allocation (the steady-state path when every rank decodes frames of the same geometry)."""
+
+    def __init__(self, n_bytes: int, device, dst: int = 0, group=None):
+        self.dst, self.group = dst, group
+        self.local = torch.empty(n_bytes, dtype=torch.uint8, device=device)
+        world = dist.get_world_size(group)
+        self.bucket = [torch.empty_like(self.local) for _ in range(world)] if dist.get_rank(group) == dst else None
+
+    def __call__(self, planes: Sequence[torch.Tensor]) -> Optional[List[torch.Tensor]]:
+        torch.cat([p.contiguous().view(torch.uint8).reshape(-1) for p in planes], out=self.local)
+        dist.gather(self.local, self.bucket, dst=self.dst, group=self.group)
+        return self.bucket
+
+
 def unshard(per_rank_items: Sequence[Sequence], n_frames: int) -> list:
     """Inverse of shard_indices: per_rank_items[r][k] is frame r + k * world_size."""
     world = len(per_rank_items)

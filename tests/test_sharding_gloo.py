@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from cool_chic_amd.parallel import gather_bytes, pack_planes, shard_indices, unshard
+from cool_chic_amd.parallel import EqualSizeGather, gather_bytes, pack_planes, shard_indices, unshard
 
 
 def _free_port():
@@ -40,6 +40,19 @@ def _worker(rank, world, port, n_frames, q):
             per_rank.append(list(torch.split(b, [int(x) for x in l])))
         frames = unshard(per_rank, n_frames)
         ok = all(torch.equal(f, pack_planes(_frame(i))) for i, f in enumerate(frames))
+    # the fixed-size, persistent-buffer gather bench.py uses at N > 1 (same geometry on every rank), called twice
+    planes = [torch.full((4, 6), 10 * rank + p, dtype=torch.uint8) for p in range(3)] + [torch.full((2, 3), 1000 + rank, dtype=torch.int16).view(torch.uint16)]
+    g = EqualSizeGather(sum(p.numel() * p.element_size() for p in planes), "cpu", dst=0)
+    for rep in range(2):
+        got2 = g(planes)
+        if rank == 0:
+            for r in range(world):
+                want = torch.cat([torch.full((24,), 10 * r + p, dtype=torch.uint8) for p in range(3)]
+                                 + [torch.full((6,), 1000 + r, dtype=torch.int16).view(torch.uint8)])
+                ok = ok and torch.equal(got2[r], want)
+        else:
+            assert got2 is None
+    if rank == 0:
         q.put(ok)
     dist.barrier()
     dist.destroy_process_group()
