@@ -236,217 +236,284 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     uint32_t word_pos = uni(S.word_pos), wbase = uni(S.wbase), wbuf = S.wbuf;
     const uint32_t n_words = uni(P.n_words);
     const glb_ptr<const uint32_t> words_g = (glb_ptr<const uint32_t>)P.words;
-    const glb_ptr<int8_t> lat_g = (glb_ptr<int8_t>)C.lat;
     const int task_pix = uni(C.task_pix);
+    const int grid_w = uni(C.W);
     // pixels per batch: 16 (two 8-pixel or four 4-pixel tasks) or 8 (four 2-pixel tasks).  32-pixel batches were tried:
     // the decoder saves ~20 ticks / symbol of per-batch overhead, but progress is published (and the producers of the next
     // step released) only half as often, which costs more in stalls than it saves.
     const int bpx = task_pix == 2 ? 8 : 16;
+    const uint32_t bpx_shift = task_pix == 2 ? 3u : 4u;
     const int slot_mask = kRows / bpx - 1;       // 8 / 16 slots share the 128 table rows
     const int task_shift = task_pix == 8 ? 3 : (task_pix == 4 ? 2 : 1);
+    // LDS byte addresses (the dynamic LDS starts at 0) and per-lane constants of the step loop below
+    const uint32_t ready_base = C.s_ready.off, consumed_addr = C.s_consumed.off, ring_base = C.s_ring.off;
+    const uint32_t top_base = C.s_meta.off + static_cast<uint32_t>(offsetof(RowMeta, top));
+    const uint32_t tab_lane = C.s_tab.off + static_cast<uint32_t>(lane) * 8u;
+    const uint32_t lane_top_off = static_cast<uint32_t>(lane & (bpx - 1)) * 4u;
+    const uint64_t lat_addr = uni(reinterpret_cast<uint64_t>(C.lat));
+    const uint32_t glo_stride = static_cast<uint32_t>(bpx * (grid_w - 10));
+    const RowMeta& meta = *C.s_meta;
     bool ok = true;
+    int raw = 0, top_l = 0;  // lane p: window lane chosen for / top symbol of pixel p of the current batch
     while (ok && it.next()) {
-        for (int i0 = 0; i0 < it.n; i0 += bpx, ++seq) {
-            const int cnt = uni(min(bpx, it.n - i0));
+        // ---- one wavefront step = one asm region: per batch the ready check, the symbol loop (hand-scheduled recurrence, see
+        // the file header) and the epilogue (symbols -> LDS ring + latent grid, slot handed back, progress published) without
+        // returning to compiled code.  It leaves early for a symbol whose new range has a zero high word (renormalisation,
+        // window miss, invalid data: status 1, handled below, then re-entered) and for a batch that is not ready (status 2).
+        const uint32_t n_step = static_cast<uint32_t>(it.n);
+        uint32_t i = 0, mode = 0;
+        // lane p <-> pixel p of the step's first batch; both advance by one batch in the epilogue
+        uint32_t v_ring = static_cast<uint32_t>((((it.y0 + lane) & (kRingRows - 1)) << 6) | ((it.x0 + 10 * it.y0) & 63));
+        uint32_t v_goff = static_cast<uint32_t>((it.y0 + lane) * grid_w + (it.x0 - 10 * lane));
+        while (true) {
+            uint32_t status, k_rare;
+                asm volatile(
+                "s_mov_b64 s[50:51], %[dst]\n\t"
+                "s_mov_b64 s[52:53], %[rng]\n\t"
+                "s_sub_u32 s62, %[bpx], 1\n\t"
+                "s_cmp_eq_u32 %[mode], 0\n\t"
+                "s_cbranch_scc0 6f\n\t"
+                // ---- batch start: symbol index i is the first of a batch
+                "5:\n\t"
+                "s_add_u32 s54, %[i], %[bpx]\n\t"
+                "s_min_u32 s54, s54, %[n]\n\t"
+                "s_and_b32 s55, %[seq], %[smask]\n\t"
+                "s_lshl_b32 s59, s55, 2\n\t"
+                "s_add_u32 s59, s59, %[rdy]\n\t"
+                "v_mov_b32 v51, s59\n\t"
+                "ds_read_b32 v52, v51\n\t"
+                "s_lshl_b32 s56, s55, %[bshift]\n\t"
+                "s_sub_u32 s57, s54, %[i]\n\t"
+                "s_add_u32 s57, s57, %[tadd]\n\t"
+                "s_lshr_b32 s57, s57, %[tshift]\n\t"
+                "s_lshl_b32 s58, s56, 9\n\t"
+                "v_add_u32 v50, s58, %[tabl]\n\t"
+                "s_lshl_b32 s58, s56, 2\n\t"
+                "s_add_u32 s58, s58, %[topb]\n\t"
+                "v_add_u32 v53, s58, %[l4]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_readfirstlane_b32 s58, v52\n\t"
+                "s_cmp_eq_u32 s58, s57\n\t"
+                "s_cbranch_scc0 7f\n\t"
+                "ds_read_b32 %[top], v53\n\t"
+                "v_mov_b32 %[raw], 0\n\t"
+                "8:\n\t"
+                "ds_read_b64 v[40:41], v50\n\t"
+                "ds_read_b64 v[42:43], v50 offset:512\n\t"
+                ".p2align 6\n\t"
+                "1:\n\t"
+                // ---- copy 0: (L, P) of the current symbol in v[40:41], two rows ahead in flight (order: dloop_variants.hip)
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[46:47], v50 offset:1024\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
+                "v_mad_u32_u24 v45, v40, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
+                "v_mad_u32_u24 v49, v41, s41, v49\n\t"
+                "s_and_b32 m0, %[i], s62\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 3f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, m0\n\t"
+                "s_add_u32 %[i], %[i], 1\n\t"
+                "s_cmp_lt_u32 %[i], s54\n\t"
+                "s_cbranch_scc0 2f\n\t"
+                // ---- copy 1: (L, P) of the current symbol in v[42:43], two rows ahead in flight (order: dloop_variants.hip)
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[40:41], v50 offset:1536\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
+                "v_mad_u32_u24 v45, v42, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
+                "v_mad_u32_u24 v49, v43, s41, v49\n\t"
+                "s_and_b32 m0, %[i], s62\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 3f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, m0\n\t"
+                "s_add_u32 %[i], %[i], 1\n\t"
+                "s_cmp_lt_u32 %[i], s54\n\t"
+                "s_cbranch_scc0 2f\n\t"
+                // ---- copy 2: (L, P) of the current symbol in v[46:47], two rows ahead in flight (order: dloop_variants.hip)
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[42:43], v50 offset:2048\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
+                "v_mad_u32_u24 v45, v46, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
+                "v_mad_u32_u24 v49, v47, s41, v49\n\t"
+                "s_and_b32 m0, %[i], s62\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 3f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, m0\n\t"
+                "s_add_u32 %[i], %[i], 1\n\t"
+                "v_add_u32 v50, 0x600, v50\n\t"
+                "s_cmp_lt_u32 %[i], s54\n\t"
+                "s_cbranch_scc1 1b\n\t"
+                // ---- batch end: symbols of the batch -> ring + latent grid, hand the slot back, publish progress
+                "2:\n\t"
+                "s_sub_u32 s58, s54, 1\n\t"
+                "s_sub_u32 s57, %[bpx], 1\n\t"
+                "s_and_b32 s58, s58, s57\n\t"
+                "s_add_u32 s58, s58, 1\n\t"
+                "v_cmp_gt_u32 vcc, s58, %[lane]\n\t"
+                "s_and_saveexec_b64 s[60:61], vcc\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_sub_u32 v52, %[top], %[raw]\n\t"
+                "v_add_u32 v52, 1, v52\n\t"
+                "v_add_u32 v51, %[ringb], %[ring]\n\t"
+                "ds_write_b8 v51, v52\n\t"
+                "global_store_byte %[goff], v52, %[lat]\n\t"
+                "s_mov_b64 exec, s[60:61]\n\t"
+                "v_add_u32 %[ring], %[rstride], %[ring]\n\t"
+                "v_and_b32 %[ring], 0x7fff, %[ring]\n\t"
+                "v_add_u32 %[goff], %[gstride], %[goff]\n\t"
+                "v_mov_b32 v51, s59\n\t"
+                "v_mov_b32 v52, 0\n\t"
+                "ds_write_b32 v51, v52\n\t"
+                "s_add_u32 %[seq], %[seq], 1\n\t"
+                "v_mov_b32 v51, %[cons]\n\t"
+                "v_mov_b32 v52, %[seq]\n\t"
+                "ds_write_b32 v51, v52\n\t"
+                "s_cmp_lt_u32 %[i], %[n]\n\t"
+                "s_cbranch_scc1 5b\n\t"
+                "s_mov_b32 %[st], 0\n\t"
+                "s_branch 4f\n\t"
+                // ---- re-entry after a symbol decoded by the C++ path: i already points behind it
+                "6:\n\t"
+                "s_sub_u32 s58, %[i], 1\n\t"
+                "s_sub_u32 s57, %[bpx], 1\n\t"
+                "s_andn2_b32 s58, s58, s57\n\t"
+                "s_add_u32 s54, s58, %[bpx]\n\t"
+                "s_min_u32 s54, s54, %[n]\n\t"
+                "s_and_b32 s55, %[seq], %[smask]\n\t"
+                "s_lshl_b32 s59, s55, 2\n\t"
+                "s_add_u32 s59, s59, %[rdy]\n\t"
+                "s_lshl_b32 s56, s55, %[bshift]\n\t"
+                "s_sub_u32 s57, %[i], s58\n\t"
+                "s_add_u32 s57, s57, s56\n\t"
+                "s_lshl_b32 s57, s57, 9\n\t"
+                "v_add_u32 v50, s57, %[tabl]\n\t"
+                "s_cmp_lt_u32 %[i], s54\n\t"
+                "s_cbranch_scc1 8b\n\t"
+                "s_branch 2b\n\t"
+                "7:\n\t"
+                "s_mov_b32 %[st], 2\n\t"
+                "s_branch 4f\n\t"
+                "3:\n\t"
+                "s_mov_b32 %[st], 1\n\t"
+                "4:\n\t"
+                "s_mov_b32 %[kr], s44\n\t"
+                "s_mov_b64 %[dst], s[50:51]\n\t"
+                "s_mov_b64 %[rng], s[52:53]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [i] "+s"(i), [seq] "+s"(seq), [raw] "+v"(raw), [top] "+v"(top_l),
+                  [ring] "+v"(v_ring), [goff] "+v"(v_goff), [st] "=s"(status), [kr] "=s"(k_rare)
+                : [mode] "s"(mode), [n] "s"(n_step), [smask] "s"(static_cast<uint32_t>(slot_mask)), [bpx] "s"(static_cast<uint32_t>(bpx)),
+                  [bshift] "s"(bpx_shift), [tadd] "s"(static_cast<uint32_t>(task_pix - 1)), [tshift] "s"(static_cast<uint32_t>(task_shift)),
+                  [rdy] "s"(ready_base), [cons] "s"(consumed_addr), [topb] "s"(top_base), [ringb] "s"(ring_base),
+                  [rstride] "s"(static_cast<uint32_t>(bpx * 64)), [gstride] "s"(glo_stride), [tabl] "v"(tab_lane), [lane] "v"(static_cast<uint32_t>(lane)),
+                  [l4] "v"(lane_top_off), [lat] "s"(lat_addr)
+                : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
+                  "s56", "s57", "s58", "s59", "s60", "s61", "s62", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53");
+            if (status == 0) break;
+            const int i0 = static_cast<int>(status == 2 ? i : ((i) & ~static_cast<uint32_t>(bpx - 1)));
             const int slot = uni(static_cast<int>(seq) & slot_mask);
             const int row0 = slot * bpx;
-            {
-                const unsigned long long t0 = PROF_T();
-                {   // one counter per slot: every finished part adds 1, the decoder clears it when the batch is consumed
-                    const uint32_t n_parts = static_cast<uint32_t>((cnt + task_pix - 1) >> task_shift);
-                    if (uni(lds_load_acquire(&C.s_ready[slot])) != n_parts) {
+            if (status == 2) {  // the batch starting at symbol i is not complete yet: poll, then enter again
+                const int cnt = min(bpx, it.n - i0);
+                const uint32_t n_parts = static_cast<uint32_t>((cnt + task_pix - 1) >> task_shift);
 #ifdef CCD_PIPE_PROFILE
-                        const unsigned long long ts = __builtin_amdgcn_s_memtime();
+                const unsigned long long ts = __builtin_amdgcn_s_memtime();
 #endif
-                        if (!wait_ge(&C.s_ready[slot], n_parts, C.s_abort)) ok = false;
+                if (!wait_ge(&C.s_ready[slot], n_parts, C.s_abort)) { ok = false; break; }
 #ifdef CCD_PIPE_PROFILE
-                        const unsigned long long dts = __builtin_amdgcn_s_memtime() - ts;
-                        S.stall_ticks += dts;
-                        S.stall_events += 1;
-                        if (it.n >= 48) S.wait_by_j[min(i0 / bpx, 5)] += dts;  // finest grid: stall ticks by batch position
+                const unsigned long long dts = __builtin_amdgcn_s_memtime() - ts;
+                S.stall_ticks += dts;
+                S.stall_events += 1;
+                if (it.n >= 48) S.wait_by_j[min(i0 / bpx, 5)] += dts;  // finest grid: stall ticks by batch position
 #endif
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                }
-                if (!ok) break;
-                PROF_ADD(S.prof_wait, t0);
-#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE >= 3
-                if (C.W == 768 && it.n >= 64) S.wait_by_j[min(i0 / bpx, 5)] += __builtin_amdgcn_s_memtime() - t0;
-#endif
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                mode = 0;
+                continue;
             }
-            const unsigned long long t_dec = PROF_T();
+#ifdef CCD_PIPE_PROFILE
+            S.n_rare += 1;
+#endif
+            // ---- rare path for symbol i (state untouched by the asm region) -----------------------------------
+            const int pi = static_cast<int>(i) - i0;  // pixel within the batch
             const uint2* tab = C.s_tab + static_cast<size_t>(row0) * 64 + lane;
-            const RowMeta& meta = *C.s_meta;
-            int raw = 0;  // lane i: window lane chosen for pixel i
-            const int top_l = meta.top[row0 + (lane & (kBatch - 1))];  // needed after the loop: the read overlaps it
-            // ---- symbol loop: hand-scheduled recurrence (see the file header).  The asm block walks symbols
-            // i .. cnt-1 and stops early (status 1) at the first symbol whose new range has a zero high word:
-            // renormalisation, window miss or invalid data - all handled in C++ below, then the loop resumes.
-            uint32_t i = 0;
-            const uint32_t tab_addr = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(tab));  // LDS byte address of this lane's (L, P)
-            while (i < static_cast<uint32_t>(cnt)) {
-                uint32_t status, k_rare;
-                uint32_t taddr = tab_addr + i * 512u;
-                asm volatile(
-                    "s_mov_b64 s[50:51], %[dst]\n\t"
-                    "s_mov_b64 s[52:53], %[rng]\n\t"
-                    "ds_read_b64 v[40:41], %[ta]\n\t"
-                    "ds_read_b64 v[42:43], %[ta] offset:512\n\t"
-                    ".p2align 6\n\t"
-                    "1:\n\t"
-                    // ---- copy 0: (L, P) of the current symbol in v[40:41], two rows ahead in flight.  Order found by sweeping
-                    // orderings in tools/ubench/dloop_variants.hip: compare before the scale * P products, range before dist.
-                    "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
-                    "ds_read_b64 v[46:47], %[ta] offset:1024\n\t"
-                    "s_waitcnt lgkmcnt(2)\n\t"
-                    "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
-                    "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                    "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                    "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
-                    "v_mad_u32_u24 v49, v41, s41, v49\n\t"
-                    "s_mov_b32 m0, %[i]\n\t"
-                    "s_ff1_i32_b64 s44, vcc\n\t"
-                    "v_readlane_b32 s48, v48, s44\n\t"
-                    "v_readlane_b32 s49, v49, s44\n\t"
-                    "v_readlane_b32 s46, v44, s44\n\t"
-                    "v_readlane_b32 s47, v45, s44\n\t"
-                    "s_cmp_eq_u32 s49, 0\n\t"
-                    "s_cbranch_scc1 3f\n\t"
-                    "s_mov_b64 s[52:53], s[48:49]\n\t"
-                    "s_sub_u32 s50, s50, s46\n\t"
-                    "s_subb_u32 s51, s51, s47\n\t"
-                    "v_writelane_b32 %[raw], s44, m0\n\t"
-                    "s_add_u32 %[i], %[i], 1\n\t"
-                    "s_cmp_lt_u32 %[i], %[cnt]\n\t"
-                    "s_cbranch_scc0 2f\n\t"
-                    // ---- copy 1: (L, P) of the current symbol in v[42:43], two rows ahead in flight.  Order found by sweeping
-                    // orderings in tools/ubench/dloop_variants.hip: compare before the scale * P products, range before dist.
-                    "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
-                    "ds_read_b64 v[40:41], %[ta] offset:1536\n\t"
-                    "s_waitcnt lgkmcnt(2)\n\t"
-                    "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
-                    "v_mad_u32_u24 v45, v42, s41, v45\n\t"
-                    "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                    "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
-                    "v_mad_u32_u24 v49, v43, s41, v49\n\t"
-                    "s_mov_b32 m0, %[i]\n\t"
-                    "s_ff1_i32_b64 s44, vcc\n\t"
-                    "v_readlane_b32 s48, v48, s44\n\t"
-                    "v_readlane_b32 s49, v49, s44\n\t"
-                    "v_readlane_b32 s46, v44, s44\n\t"
-                    "v_readlane_b32 s47, v45, s44\n\t"
-                    "s_cmp_eq_u32 s49, 0\n\t"
-                    "s_cbranch_scc1 3f\n\t"
-                    "s_mov_b64 s[52:53], s[48:49]\n\t"
-                    "s_sub_u32 s50, s50, s46\n\t"
-                    "s_subb_u32 s51, s51, s47\n\t"
-                    "v_writelane_b32 %[raw], s44, m0\n\t"
-                    "s_add_u32 %[i], %[i], 1\n\t"
-                    "s_cmp_lt_u32 %[i], %[cnt]\n\t"
-                    "s_cbranch_scc0 2f\n\t"
-                    // ---- copy 2: (L, P) of the current symbol in v[46:47], two rows ahead in flight.  Order found by sweeping
-                    // orderings in tools/ubench/dloop_variants.hip: compare before the scale * P products, range before dist.
-                    "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
-                    "ds_read_b64 v[42:43], %[ta] offset:2048\n\t"
-                    "s_waitcnt lgkmcnt(2)\n\t"
-                    "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
-                    "v_mad_u32_u24 v45, v46, s41, v45\n\t"
-                    "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                    "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
-                    "v_mad_u32_u24 v49, v47, s41, v49\n\t"
-                    "s_mov_b32 m0, %[i]\n\t"
-                    "s_ff1_i32_b64 s44, vcc\n\t"
-                    "v_readlane_b32 s48, v48, s44\n\t"
-                    "v_readlane_b32 s49, v49, s44\n\t"
-                    "v_readlane_b32 s46, v44, s44\n\t"
-                    "v_readlane_b32 s47, v45, s44\n\t"
-                    "s_cmp_eq_u32 s49, 0\n\t"
-                    "s_cbranch_scc1 3f\n\t"
-                    "s_mov_b64 s[52:53], s[48:49]\n\t"
-                    "s_sub_u32 s50, s50, s46\n\t"
-                    "s_subb_u32 s51, s51, s47\n\t"
-                    "v_writelane_b32 %[raw], s44, m0\n\t"
-                    "s_add_u32 %[i], %[i], 1\n\t"
-                    "v_add_u32 %[ta], 0x600, %[ta]\n\t"
-                    "s_cmp_lt_u32 %[i], %[cnt]\n\t"
-                    "s_cbranch_scc1 1b\n\t"
-                    "2:\n\t"
-                    "s_mov_b32 %[st], 0\n\t"
-                    "s_branch 4f\n\t"
-                    "3:\n\t"
-                    "s_mov_b32 %[st], 1\n\t"
-                    "4:\n\t"
-                    "s_mov_b32 %[kr], s44\n\t"
-                    "s_mov_b64 %[dst], s[50:51]\n\t"
-                    "s_mov_b64 %[rng], s[52:53]\n\t"
-                    "s_waitcnt lgkmcnt(0)\n\t"
-                    : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [i] "+s"(i), [raw] "+v"(raw), [ta] "+v"(taddr), [st] "=s"(status),
-                      [kr] "=s"(k_rare)
-                    : [cnt] "s"(static_cast<uint32_t>(cnt))
-                    : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "v40", "v41",
-                      "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49");
-                if (status == 0) break;
+            const uint2 cur = tab[pi * 64];
+            const uint32_t sc_lo = static_cast<uint32_t>(rc_range >> 24);
+            const uint32_t sc_hi = static_cast<uint32_t>(rc_range >> 56);
+            const uint64_t p0 = static_cast<uint64_t>(sc_lo) * cur.x;
+            const uint32_t p_lo = static_cast<uint32_t>(p0);
+            const uint32_t p_hi = static_cast<uint32_t>(p0 >> 32) + __umul24(sc_hi, cur.x);
+            int k = static_cast<int>(k_rare);
+            const uint32_t l_lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(p_lo, k));
+            const uint32_t l_hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(p_hi, k));
+            const uint32_t psel = static_cast<uint32_t>(__builtin_amdgcn_readlane(cur.y, k));
+            uint64_t nd = rc_dist - ((static_cast<uint64_t>(l_hi) << 32) | l_lo);
+            uint64_t nr = static_cast<uint64_t>(sc_lo) * psel + (static_cast<uint64_t>(sc_hi * psel) << 32);
+            if (nr == 0) {
 #ifdef CCD_PIPE_PROFILE
-                S.n_rare += 1;
+                S.n_search += 1;
 #endif
-                // ---- rare path for symbol i (state untouched by the asm block) -----------------------------------
-                const uint2 cur = tab[i * 64];
-                const uint32_t sc_lo = static_cast<uint32_t>(rc_range >> 24);
-                const uint32_t sc_hi = static_cast<uint32_t>(rc_range >> 56);
-                const uint64_t p0 = static_cast<uint64_t>(sc_lo) * cur.x;
-                const uint32_t p_lo = static_cast<uint32_t>(p0);
-                const uint32_t p_hi = static_cast<uint32_t>(p0 >> 32) + __umul24(sc_hi, cur.x);
-                int k = static_cast<int>(k_rare);
-                const uint32_t l_lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(p_lo, k));
-                const uint32_t l_hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(p_hi, k));
-                const uint32_t psel = static_cast<uint32_t>(__builtin_amdgcn_readlane(cur.y, k));
-                uint64_t nd = rc_dist - ((static_cast<uint64_t>(l_hi) << 32) | l_lo);
-                uint64_t nr = static_cast<uint64_t>(sc_lo) * psel + (static_cast<uint64_t>(sc_hi * psel) << 32);
-                if (nr == 0) {
-#ifdef CCD_PIPE_PROFILE
-                    S.n_search += 1;
-#endif
-                    // symbol outside the window (or invalid data): full 128-way search
-                    const uint64_t scale = rc_range >> kRcPrecision;
-                    if ((rc_dist >> kRcPrecision) >= scale) {
-                        lds_store_release(C.s_abort, static_cast<uint32_t>(-CCD_ERR_INVALID_DATA));
-                        ok = false;
-                        break;
-                    }
-                    const double mu = -64.0 + static_cast<double>(meta.mu_idx[row0 + i]) * (1.0 / 256.0);
-                    const double b = meta.b[row0 + i], rcp = meta.rcp[row0 + i];
-                    const uint32_t f0 = window_left(mu, b, rcp, kAcLo + lane);
-                    const uint32_t f1 = window_left(mu, b, rcp, kAcLo + 64 + lane);
-                    const unsigned long long m0 = __ballot(scale * f0 <= rc_dist), m1 = __ballot(scale * f1 <= rc_dist);
-                    const int sidx = __popcll(m0) + __popcll(m1) - 1;
-                    const uint32_t left = uni(static_cast<uint32_t>(__shfl(sidx < 64 ? f0 : f1, sidx & 63)));
-                    uint32_t right = uni(static_cast<uint32_t>(__shfl(sidx + 1 < 64 ? f0 : f1, (sidx + 1) & 63)));
-                    if (sidx == kAlphabet - 1) right = 1u << kRcPrecision;
-                    nd = rc_dist - scale * left;
-                    nr = scale * static_cast<uint64_t>(right - left);
-                    k = uni(1 - ((sidx + kAcLo) - meta.top[row0 + i]));  // top - (k - 1) == symbol
+                // symbol outside the window (or invalid data): full 128-way search
+                const uint64_t scale = rc_range >> kRcPrecision;
+                if ((rc_dist >> kRcPrecision) >= scale) {
+                    lds_store_release(C.s_abort, static_cast<uint32_t>(-CCD_ERR_INVALID_DATA));
+                    ok = false;
+                    break;
                 }
-                if (static_cast<uint32_t>(nr >> 32) == 0) {
-                    nr <<= 32;
-                    nd = (nd << 32) | static_cast<uint32_t>(__builtin_amdgcn_readlane(wbuf, (word_pos - wbase) & 63));
-                    ++word_pos;
-                    if (word_pos - wbase == 64) { wbase = word_pos; wbuf = (wbase + lane < n_words) ? words_g[wbase + lane] : 0u; }
-                }
-                rc_dist = uni(nd); rc_range = uni(nr);
-                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(raw) : "s"(k), "s"(i));
-                ++i;
+                const double mu = -64.0 + static_cast<double>(meta.mu_idx[row0 + pi]) * (1.0 / 256.0);
+                const double b = meta.b[row0 + pi], rcp = meta.rcp[row0 + pi];
+                const uint32_t f0 = window_left(mu, b, rcp, kAcLo + lane);
+                const uint32_t f1 = window_left(mu, b, rcp, kAcLo + 64 + lane);
+                const unsigned long long m0 = __ballot(scale * f0 <= rc_dist), m1 = __ballot(scale * f1 <= rc_dist);
+                const int sidx = __popcll(m0) + __popcll(m1) - 1;
+                const uint32_t left = uni(static_cast<uint32_t>(__shfl(sidx < 64 ? f0 : f1, sidx & 63)));
+                uint32_t right = uni(static_cast<uint32_t>(__shfl(sidx + 1 < 64 ? f0 : f1, (sidx + 1) & 63)));
+                if (sidx == kAlphabet - 1) right = 1u << kRcPrecision;
+                nd = rc_dist - scale * left;
+                nr = scale * static_cast<uint64_t>(right - left);
+                k = uni(1 - ((sidx + kAcLo) - meta.top[row0 + pi]));  // top - (k - 1) == symbol
             }
-            if (!ok) break;
-            // ---- vector epilogue of the batch: symbols -> ring + global grid ------------------------
-            if (lane < cnt) {
-                const int y = it.y0 + i0 + lane, x = it.x0 - 10 * (i0 + lane);
-                const int sym = top_l - (raw - 1);
-                C.s_ring[(y & (kRingRows - 1)) * 64 + ((x + 10 * y) & 63)] = static_cast<int8_t>(sym);
-                lat_g[y * C.W + x] = static_cast<int8_t>(sym);
+            if (static_cast<uint32_t>(nr >> 32) == 0) {
+                nr <<= 32;
+                nd = (nd << 32) | static_cast<uint32_t>(__builtin_amdgcn_readlane(wbuf, (word_pos - wbase) & 63));
+                ++word_pos;
+                if (word_pos - wbase == 64) { wbase = word_pos; wbuf = (wbase + lane < n_words) ? words_g[wbase + lane] : 0u; }
             }
-            lds_store_ordered(&C.s_ready[slot], 0u);  // before `consumed`: the slot's next producers wait for that
-            lds_store_ordered(C.s_consumed, seq + 1);
-            PROF_ADD(S.prof_work, t_dec);
+            rc_dist = uni(nd); rc_range = uni(nr);
+            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(raw) : "s"(k), "s"(pi));
+            ++i;
+            mode = 1;
         }
     }
     S.dist = rc_dist; S.range = rc_range; S.word_pos = word_pos; S.wbase = wbase; S.wbuf = wbuf;
