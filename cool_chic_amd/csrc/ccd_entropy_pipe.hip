@@ -255,6 +255,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     const RowMeta& meta = *C.s_meta;
     bool ok = true;
     int raw = 0, top_l = 0;  // lane p: window lane chosen for / top symbol of pixel p of the current batch
+    uint32_t n_spins = 0;    // polls of a ready counter inside the asm region (profile builds report them)
     while (ok && it.next()) {
         // ---- one wavefront step = one asm region: per batch the ready check, the symbol loop (hand-scheduled recurrence, see
         // the file header) and the epilogue (symbols -> LDS ring + latent grid, slot handed back, progress published) without
@@ -267,7 +268,8 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
         uint32_t v_goff = static_cast<uint32_t>((it.y0 + lane) * grid_w + (it.x0 - 10 * lane));
         while (true) {
             uint32_t status, k_rare;
-                asm volatile(
+            i = uni(i); seq = uni(seq); mode = uni(mode); n_spins = uni(n_spins);  // scalar operands of the region below
+            asm volatile(
                 "s_mov_b64 s[50:51], %[dst]\n\t"
                 "s_mov_b64 s[52:53], %[rng]\n\t"
                 "s_sub_u32 s62, %[bpx], 1\n\t"
@@ -291,10 +293,22 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_lshl_b32 s58, s56, 2\n\t"
                 "s_add_u32 s58, s58, %[topb]\n\t"
                 "v_add_u32 v53, s58, %[l4]\n\t"
+                "s_mov_b32 s68, 0\n\t"
+                "s_branch 12f\n\t"
+                // bounded spin on the slot's counter (short waits are the rule on short steps); a long wait goes back to the
+                // compiled code, which also watches the abort flag
+                "11:\n\t"
+                "s_add_u32 s68, s68, 1\n\t"
+                "s_cmp_lt_u32 s68, 256\n\t"
+                "s_cbranch_scc0 7f\n\t"
+                "s_sleep 1\n\t"
+                "ds_read_b32 v52, v51\n\t"
+                "12:\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
                 "v_readfirstlane_b32 s58, v52\n\t"
                 "s_cmp_eq_u32 s58, s57\n\t"
-                "s_cbranch_scc0 7f\n\t"
+                "s_cbranch_scc0 11b\n\t"
+                "s_add_u32 %[spins], %[spins], s68\n\t"
                 "ds_read_b32 %[top], v53\n\t"
                 "v_mov_b32 %[raw], 0\n\t"
                 "8:\n\t"
@@ -377,13 +391,37 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_cbranch_scc1 1b\n\t"
                 // ---- batch end: symbols of the batch -> ring + latent grid, hand the slot back, publish progress
                 "2:\n\t"
+                // next batch of this step (if any): its ready counter, top symbols and first two rows are requested now; LDS
+                // answers a wave in order and producers store rows before they count a part in, so a counter that reads
+                // complete vouches for the rows read after it.  The round trips hide behind the epilogue.
+                "s_cmp_lt_u32 %[i], %[n]\n\t"
+                "s_cbranch_scc0 9f\n\t"
+                "s_add_u32 s67, %[i], %[bpx]\n\t"
+                "s_min_u32 s67, s67, %[n]\n\t"
+                "s_add_u32 s63, %[seq], 1\n\t"
+                "s_and_b32 s63, s63, %[smask]\n\t"
+                "s_lshl_b32 s66, s63, 2\n\t"
+                "s_add_u32 s66, s66, %[rdy]\n\t"
+                "v_mov_b32 v51, s66\n\t"
+                "ds_read_b32 v54, v51\n\t"
+                "s_lshl_b32 s64, s63, %[bshift]\n\t"
+                "s_lshl_b32 s58, s64, 2\n\t"
+                "s_add_u32 s58, s58, %[topb]\n\t"
+                "v_add_u32 v60, s58, %[l4]\n\t"
+                "ds_read_b32 v55, v60\n\t"
+                "s_lshl_b32 s58, s64, 9\n\t"
+                "v_add_u32 v53, s58, %[tabl]\n\t"
+                "ds_read_b64 v[56:57], v53\n\t"
+                "ds_read_b64 v[58:59], v53 offset:512\n\t"
+                "s_sub_u32 s65, s67, %[i]\n\t"
+                "s_add_u32 s65, s65, %[tadd]\n\t"
+                "s_lshr_b32 s65, s65, %[tshift]\n\t"
+                "9:\n\t"
                 "s_sub_u32 s58, s54, 1\n\t"
-                "s_sub_u32 s57, %[bpx], 1\n\t"
-                "s_and_b32 s58, s58, s57\n\t"
+                "s_and_b32 s58, s58, s62\n\t"
                 "s_add_u32 s58, s58, 1\n\t"
                 "v_cmp_gt_u32 vcc, s58, %[lane]\n\t"
                 "s_and_saveexec_b64 s[60:61], vcc\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
                 "v_sub_u32 v52, %[top], %[raw]\n\t"
                 "v_add_u32 v52, 1, v52\n\t"
                 "v_add_u32 v51, %[ringb], %[ring]\n\t"
@@ -401,7 +439,32 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_mov_b32 v52, %[seq]\n\t"
                 "ds_write_b32 v51, v52\n\t"
                 "s_cmp_lt_u32 %[i], %[n]\n\t"
-                "s_cbranch_scc1 5b\n\t"
+                "s_cbranch_scc0 10f\n\t"
+                // ---- fast entry into the next batch: everything it needs was requested above
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "s_mov_b32 s54, s67\n\t"
+                "s_mov_b32 s55, s63\n\t"
+                "s_mov_b32 s56, s64\n\t"
+                "s_mov_b32 s59, s66\n\t"
+                "s_mov_b32 s57, s65\n\t"
+                "v_mov_b32 v50, v53\n\t"
+                "v_readfirstlane_b32 s58, v54\n\t"
+                "s_cmp_eq_u32 s58, s65\n\t"
+                "s_cbranch_scc1 13f\n\t"
+                // not complete when asked: poll it like a batch entered from the top (the early copies of top / rows are stale)
+                "v_mov_b32 v51, s59\n\t"
+                "v_mov_b32 v53, v60\n\t"
+                "s_mov_b32 s68, 0\n\t"
+                "s_branch 11b\n\t"
+                "13:\n\t"
+                "v_mov_b32 %[top], v55\n\t"
+                "v_mov_b32 %[raw], 0\n\t"
+                "v_mov_b32 v40, v56\n\t"
+                "v_mov_b32 v41, v57\n\t"
+                "v_mov_b32 v42, v58\n\t"
+                "v_mov_b32 v43, v59\n\t"
+                "s_branch 1b\n\t"
+                "10:\n\t"
                 "s_mov_b32 %[st], 0\n\t"
                 "s_branch 4f\n\t"
                 // ---- re-entry after a symbol decoded by the C++ path: i already points behind it
@@ -433,14 +496,14 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_mov_b64 %[rng], s[52:53]\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
                 : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [i] "+s"(i), [seq] "+s"(seq), [raw] "+v"(raw), [top] "+v"(top_l),
-                  [ring] "+v"(v_ring), [goff] "+v"(v_goff), [st] "=s"(status), [kr] "=s"(k_rare)
+                  [ring] "+v"(v_ring), [goff] "+v"(v_goff), [spins] "+s"(n_spins), [st] "=s"(status), [kr] "=s"(k_rare)
                 : [mode] "s"(mode), [n] "s"(n_step), [smask] "s"(static_cast<uint32_t>(slot_mask)), [bpx] "s"(static_cast<uint32_t>(bpx)),
                   [bshift] "s"(bpx_shift), [tadd] "s"(static_cast<uint32_t>(task_pix - 1)), [tshift] "s"(static_cast<uint32_t>(task_shift)),
                   [rdy] "s"(ready_base), [cons] "s"(consumed_addr), [topb] "s"(top_base), [ringb] "s"(ring_base),
                   [rstride] "s"(static_cast<uint32_t>(bpx * 64)), [gstride] "s"(glo_stride), [tabl] "v"(tab_lane), [lane] "v"(static_cast<uint32_t>(lane)),
                   [l4] "v"(lane_top_off), [lat] "s"(lat_addr)
                 : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
-                  "s56", "s57", "s58", "s59", "s60", "s61", "s62", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53");
+                  "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60");
             if (status == 0) break;
             const int i0 = static_cast<int>(status == 2 ? i : ((i) & ~static_cast<uint32_t>(bpx - 1)));
             const int slot = uni(static_cast<int>(seq) & slot_mask);
