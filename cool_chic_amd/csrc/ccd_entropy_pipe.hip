@@ -157,7 +157,7 @@ struct DecState {
     uint64_t dist, range;  // dist = point - lower (all the decoder ever uses)
     uint32_t word_pos, wbase, wbuf;
     uint64_t n_decoded;
-    unsigned long long prof_wait, prof_work, stall_ticks, stall_events, n_rare, n_search;
+    unsigned long long prof_wait, prof_work, stall_ticks, stall_events, n_rare, n_search, n_spins;
     unsigned long long wait_by_j[6];  // grid 0, steps with n >= 64: decoder wait per batch position
 };
 
@@ -580,6 +580,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
         }
     }
     S.dist = rc_dist; S.range = rc_range; S.word_pos = word_pos; S.wbase = wbase; S.wbuf = wbuf;
+    S.n_spins += n_spins;
     return seq;
 }
 
@@ -1006,7 +1007,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
 
     DecState S;
     S.range = ~uint64_t{0}; S.dist = 0; S.word_pos = 2; S.wbase = 2; S.wbuf = 0; S.n_decoded = 0;
-    S.prof_wait = 0; S.prof_work = 0; S.stall_ticks = 0; S.stall_events = 0; S.n_rare = 0; S.n_search = 0;
+    S.prof_wait = 0; S.prof_work = 0; S.stall_ticks = 0; S.stall_events = 0; S.n_rare = 0; S.n_search = 0; S.n_spins = 0;
     for (int i = 0; i < 6; ++i) S.wait_by_j[i] = 0;
     if (wave == 0) {
         // loads through pointers stored in the parameter block are FLAT loads, which the compiler treats as
@@ -1134,7 +1135,8 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         o[0] = __builtin_amdgcn_s_memtime() - prof_total0;
         if (wave == 0) {
             o[1] = S.prof_wait; o[2] = S.prof_work; o[3] = prof_ifce; o[4] = prof_bar;
-            P.status[62] = static_cast<int32_t>(S.n_rare); P.status[63] = static_cast<int32_t>(S.n_search);  // leaves of the asm loop, full searches
+            P.status[62] = static_cast<int32_t>(S.n_rare); P.status[63] = static_cast<int32_t>(S.n_search);
+            P.status[38] = static_cast<int32_t>(S.n_spins);  // polls of ready counters inside the decoder's asm region (~250 ticks each)  // leaves of the asm loop, full searches
         }
         else {
             o[1] = prof[0]; o[2] = prof[1]; o[3] = prof[2]; o[4] = prof[3];
