@@ -53,7 +53,7 @@ namespace ccd {
 constexpr int kPipeThreads = 512;           // 8 waves: 1 decoder + 7 producers
 constexpr int kPipeWaves = kPipeThreads / 64;
 constexpr int kProducers = kPipeWaves - 1;
-constexpr int kBatch = 16;                  // most pixels per decoder batch; 8 with 2-pixel tasks
+// pixels per decoder batch: 16 (two 8-pixel or four 4-pixel tasks), 8 with 2-pixel tasks (bpx / kBpx below)
 constexpr int kRows = 128;                  // table rows in LDS = slots x pixels per batch (4 x 32, 8 x 16 or 16 x 8)
 // Producer task = a part of a batch: 8 pixels x 8 lanes on wide wavefronts, 4 pixels x 16 lanes on short ones
 // (small grids are bound by the producers' latency, not their throughput).
@@ -681,6 +681,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 uint32_t need_early = seq_base;
                 if (prev2_nb > 0) need_early = max(need_early, prev2_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev2_y0), prev2_n - 1) / kBpx) + 1);
                 const unsigned long long lt_a = LPROF_T(pw == 0);
+                (void)lt_a;
 #if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
                 if (pw == 0 && lt_prev_end) prof[4] += lt_a - lt_prev_end;
 #endif
@@ -690,6 +691,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     PROF_ADD(prof[0], t0);
                 }
                 const unsigned long long lt_b = LPROF_T(pw == 0);
+                (void)lt_b;
                 const unsigned long long t_g = PROF_T();
                 // ---- gather: lane q of the pixel's group fetches inputs k = q, q + 8, ... --------------------------
                 if (px < cnt) {
@@ -760,6 +762,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // ---- the left neighbour: wait for it (and for the slot), add its term to the first layer and the stabiliser
                 int32_t xleft = 0;
                 const unsigned long long lt_c = LPROF_T(pw == 0);
+                (void)lt_c;
                 if (split) {
                     const unsigned long long t0 = PROF_T();
                     if (!wait_ge(C.s_consumed, need, C.s_abort)) { ok = false; break; }
@@ -767,6 +770,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     if (px < cnt && x >= 1) xleft = static_cast<int32_t>(C.s_ring[(y & (kRingRows - 1)) * 64 + ((x - 1 + 10 * y) & 63)]) << 16;
                 }
                 const unsigned long long lt_d = LPROF_T(pw == 0);
+                (void)lt_d;
                 mad64(so[0], xleft, wleft_stab);
                 const int64_t stab = so[0] + so[1];
                 if (n_layers >= 2) {

@@ -32,7 +32,7 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? l
 typedef const float __attribute__((address_space(1)))* gcf_t;
 typedef const int8_t __attribute__((address_space(1)))* gci8_t;
 typedef float __attribute__((address_space(1)))* gf_t;
-constexpr int kUpsMaxK = 8;   // fast path for ups_k <= 8 / pre_k <= 7; larger kernels use the generic body
+// fast paths: ups_k == 8 (tconv8_quad) and pre_k == 7 (preconv7_quad); other kernel sizes use the generic body
 
 __device__ __forceinline__ void upsample_generic_one(const UpsampleLevel& L, int ch, int ox, int oy) {
     float acc = 0.0f;
