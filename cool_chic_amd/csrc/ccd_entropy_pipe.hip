@@ -272,12 +272,16 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
             asm volatile(
                 "s_mov_b64 s[50:51], %[dst]\n\t"
                 "s_mov_b64 s[52:53], %[rng]\n\t"
-                "s_sub_u32 s62, %[bpx], 1\n\t"
+                "s_lshl_b32 s69, 1, %[bshift]\n\t"   // pixels per batch
+                "s_sub_u32 s62, s69, 1\n\t"
+                "s_lshl_b32 s70, 1, %[tshift]\n\t"
+                "s_sub_u32 s70, s70, 1\n\t"           // pixels per task - 1
+                "s_lshl_b32 s71, s69, 6\n\t"          // ring cells per batch
                 "s_cmp_eq_u32 %[mode], 0\n\t"
                 "s_cbranch_scc0 6f\n\t"
                 // ---- batch start: symbol index i is the first of a batch
                 "5:\n\t"
-                "s_add_u32 s54, %[i], %[bpx]\n\t"
+                "s_add_u32 s54, %[i], s69\n\t"
                 "s_min_u32 s54, s54, %[n]\n\t"
                 "s_and_b32 s55, %[seq], %[smask]\n\t"
                 "s_lshl_b32 s59, s55, 2\n\t"
@@ -286,7 +290,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "ds_read_b32 v52, v51\n\t"
                 "s_lshl_b32 s56, s55, %[bshift]\n\t"
                 "s_sub_u32 s57, s54, %[i]\n\t"
-                "s_add_u32 s57, s57, %[tadd]\n\t"
+                "s_add_u32 s57, s57, s70\n\t"
                 "s_lshr_b32 s57, s57, %[tshift]\n\t"
                 "s_lshl_b32 s58, s56, 9\n\t"
                 "v_add_u32 v50, s58, %[tabl]\n\t"
@@ -395,7 +399,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 // complete vouches for the rows read after it.  The round trips hide behind the epilogue.
                 "s_cmp_lt_u32 %[i], %[n]\n\t"
                 "s_cbranch_scc0 9f\n\t"
-                "s_add_u32 s67, %[i], %[bpx]\n\t"
+                "s_add_u32 s67, %[i], s69\n\t"
                 "s_min_u32 s67, s67, %[n]\n\t"
                 "s_add_u32 s63, %[seq], 1\n\t"
                 "s_and_b32 s63, s63, %[smask]\n\t"
@@ -413,7 +417,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "ds_read_b64 v[56:57], v53\n\t"
                 "ds_read_b64 v[58:59], v53 offset:512\n\t"
                 "s_sub_u32 s65, s67, %[i]\n\t"
-                "s_add_u32 s65, s65, %[tadd]\n\t"
+                "s_add_u32 s65, s65, s70\n\t"
                 "s_lshr_b32 s65, s65, %[tshift]\n\t"
                 "9:\n\t"
                 "s_sub_u32 s58, s54, 1\n\t"
@@ -427,7 +431,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "ds_write_b8 v51, v52\n\t"
                 "global_store_byte %[goff], v52, %[lat]\n\t"
                 "s_mov_b64 exec, s[60:61]\n\t"
-                "v_add_u32 %[ring], %[rstride], %[ring]\n\t"
+                "v_add_u32 %[ring], s71, %[ring]\n\t"
                 "v_and_b32 %[ring], 0x7fff, %[ring]\n\t"
                 "v_add_u32 %[goff], %[gstride], %[goff]\n\t"
                 "v_mov_b32 v51, s59\n\t"
@@ -469,9 +473,9 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 // ---- re-entry after a symbol decoded by the C++ path: i already points behind it
                 "6:\n\t"
                 "s_sub_u32 s58, %[i], 1\n\t"
-                "s_sub_u32 s57, %[bpx], 1\n\t"
+                "s_sub_u32 s57, s69, 1\n\t"
                 "s_andn2_b32 s58, s58, s57\n\t"
-                "s_add_u32 s54, s58, %[bpx]\n\t"
+                "s_add_u32 s54, s58, s69\n\t"
                 "s_min_u32 s54, s54, %[n]\n\t"
                 "s_and_b32 s55, %[seq], %[smask]\n\t"
                 "s_lshl_b32 s59, s55, 2\n\t"
@@ -487,7 +491,33 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "7:\n\t"
                 "s_mov_b32 %[st], 2\n\t"
                 "s_branch 4f\n\t"
+                // ---- new range below 2^32.  A zero range is a sentinel lane (window miss / invalid data): compiled path.
+                // Otherwise it is an ordinary renormalisation (constriction: state <<= 32, next word shifted in), done here:
+                // commit the symbol, take the word from the 64-word buffer (a lane of `wbuf`), resume like a re-entry.
                 "3:\n\t"
+                "s_cmp_eq_u32 s48, 0\n\t"
+                "s_cbranch_scc1 14f\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "s_and_b32 m0, %[i], s62\n\t"
+                "v_writelane_b32 %[raw], s44, m0\n\t"
+                "s_add_u32 %[i], %[i], 1\n\t"
+                "s_sub_u32 s58, %[wpos], %[wbase]\n\t"
+                "s_and_b32 s58, s58, 63\n\t"
+                "v_readlane_b32 s57, %[wbuf], s58\n\t"
+                "s_mov_b32 s51, s50\n\t"
+                "s_mov_b32 s50, s57\n\t"
+                "s_mov_b32 s53, s48\n\t"
+                "s_mov_b32 s52, 0\n\t"
+                "s_add_u32 %[wpos], %[wpos], 1\n\t"
+                "s_cmp_eq_u32 s58, 63\n\t"
+                "s_cbranch_scc1 15f\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "s_branch 6b\n\t"
+                "15:\n\t"
+                "s_mov_b32 %[st], 3\n\t"
+                "s_branch 4f\n\t"
+                "14:\n\t"
                 "s_mov_b32 %[st], 1\n\t"
                 "4:\n\t"
                 "s_mov_b32 %[kr], s44\n\t"
@@ -495,15 +525,21 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_mov_b64 %[rng], s[52:53]\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
                 : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [i] "+s"(i), [seq] "+s"(seq), [raw] "+v"(raw), [top] "+v"(top_l),
-                  [ring] "+v"(v_ring), [goff] "+v"(v_goff), [spins] "+s"(n_spins), [st] "=s"(status), [kr] "=s"(k_rare)
-                : [mode] "s"(mode), [n] "s"(n_step), [smask] "s"(static_cast<uint32_t>(slot_mask)), [bpx] "s"(static_cast<uint32_t>(bpx)),
-                  [bshift] "s"(bpx_shift), [tadd] "s"(static_cast<uint32_t>(task_pix - 1)), [tshift] "s"(static_cast<uint32_t>(task_shift)),
+                  [ring] "+v"(v_ring), [goff] "+v"(v_goff), [spins] "+s"(n_spins), [wpos] "+s"(word_pos), [st] "=s"(status), [kr] "=s"(k_rare)
+                : [mode] "s"(mode), [n] "s"(n_step), [smask] "s"(static_cast<uint32_t>(slot_mask)),
+                  [bshift] "s"(bpx_shift), [tshift] "s"(static_cast<uint32_t>(task_shift)),
                   [rdy] "s"(ready_base), [cons] "s"(consumed_addr), [topb] "s"(top_base), [ringb] "s"(ring_base),
-                  [rstride] "s"(static_cast<uint32_t>(bpx * 64)), [gstride] "s"(glo_stride), [tabl] "v"(tab_lane), [lane] "v"(static_cast<uint32_t>(lane)),
+                  [gstride] "s"(glo_stride), [wbuf] "v"(wbuf), [wbase] "s"(wbase), [tabl] "v"(tab_lane), [lane] "v"(static_cast<uint32_t>(lane)),
                   [l4] "v"(lane_top_off), [lat] "s"(lat_addr)
                 : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
-                  "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60");
+                  "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60");
             if (status == 0) break;
+            if (status == 3) {  // the region renormalised with the last buffered payload word: refill, resume inside the batch
+                wbase = word_pos;
+                wbuf = (wbase + lane < n_words) ? words_g[wbase + lane] : 0u;
+                mode = 1;
+                continue;
+            }
             const int i0 = static_cast<int>(status == 2 ? i : ((i) & ~static_cast<uint32_t>(bpx - 1)));
             const int slot = uni(static_cast<int>(seq) & slot_mask);
             const int row0 = slot * bpx;
