@@ -335,7 +335,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_readlane_b32 s46, v44, s44\n\t"
                 "v_readlane_b32 s47, v45, s44\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
-                "s_cbranch_scc1 3f\n\t"
+                "s_cbranch_scc1 40f\n\t"
                 "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
@@ -343,6 +343,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_add_u32 %[i], %[i], 1\n\t"
                 "s_cmp_lt_u32 %[i], s54\n\t"
                 "s_cbranch_scc0 2f\n\t"
+                "16:\n\t"
                 // ---- copy 1: (L, P) of the current symbol in v[42:43], two rows ahead in flight (order: dloop_variants.hip)
                 "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
                 "ds_read_b64 v[40:41], v50 offset:1536\n\t"
@@ -359,7 +360,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_readlane_b32 s46, v44, s44\n\t"
                 "v_readlane_b32 s47, v45, s44\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
-                "s_cbranch_scc1 3f\n\t"
+                "s_cbranch_scc1 41f\n\t"
                 "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
@@ -367,6 +368,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_add_u32 %[i], %[i], 1\n\t"
                 "s_cmp_lt_u32 %[i], s54\n\t"
                 "s_cbranch_scc0 2f\n\t"
+                "17:\n\t"
                 // ---- copy 2: (L, P) of the current symbol in v[46:47], two rows ahead in flight (order: dloop_variants.hip)
                 "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
                 "ds_read_b64 v[42:43], v50 offset:2048\n\t"
@@ -383,7 +385,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_readlane_b32 s46, v44, s44\n\t"
                 "v_readlane_b32 s47, v45, s44\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
-                "s_cbranch_scc1 3f\n\t"
+                "s_cbranch_scc1 42f\n\t"
                 "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
@@ -491,10 +493,11 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "7:\n\t"
                 "s_mov_b32 %[st], 2\n\t"
                 "s_branch 4f\n\t"
-                // ---- new range below 2^32.  A zero range is a sentinel lane (window miss / invalid data): compiled path.
-                // Otherwise it is an ordinary renormalisation (constriction: state <<= 32, next word shifted in), done here:
-                // commit the symbol, take the word from the 64-word buffer (a lane of `wbuf`), resume like a re-entry.
-                "3:\n\t"
+                // ---- new range below 2^32 (one block per copy of the loop).  A zero range is a sentinel lane (window miss /
+                // invalid data): compiled path.  Otherwise it is an ordinary renormalisation (constriction: state <<= 32, next
+                // word shifted in), done here: commit the symbol, take the word from the 64-word buffer (a lane of `wbuf`) and go
+                // on with the next copy of the loop - its rows are already in flight.
+                "40:\n\t"
                 "s_cmp_eq_u32 s48, 0\n\t"
                 "s_cbranch_scc1 14f\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
@@ -512,8 +515,52 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_add_u32 %[wpos], %[wpos], 1\n\t"
                 "s_cmp_eq_u32 s58, 63\n\t"
                 "s_cbranch_scc1 15f\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "s_branch 6b\n\t"
+                "s_cmp_lt_u32 %[i], s54\n\t"
+                "s_cbranch_scc0 2b\n\t"
+                "s_branch 16b\n\t"
+                "41:\n\t"
+                "s_cmp_eq_u32 s48, 0\n\t"
+                "s_cbranch_scc1 14f\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "s_and_b32 m0, %[i], s62\n\t"
+                "v_writelane_b32 %[raw], s44, m0\n\t"
+                "s_add_u32 %[i], %[i], 1\n\t"
+                "s_sub_u32 s58, %[wpos], %[wbase]\n\t"
+                "s_and_b32 s58, s58, 63\n\t"
+                "v_readlane_b32 s57, %[wbuf], s58\n\t"
+                "s_mov_b32 s51, s50\n\t"
+                "s_mov_b32 s50, s57\n\t"
+                "s_mov_b32 s53, s48\n\t"
+                "s_mov_b32 s52, 0\n\t"
+                "s_add_u32 %[wpos], %[wpos], 1\n\t"
+                "s_cmp_eq_u32 s58, 63\n\t"
+                "s_cbranch_scc1 15f\n\t"
+                "s_cmp_lt_u32 %[i], s54\n\t"
+                "s_cbranch_scc0 2b\n\t"
+                "s_branch 17b\n\t"
+                "42:\n\t"
+                "s_cmp_eq_u32 s48, 0\n\t"
+                "s_cbranch_scc1 14f\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "s_and_b32 m0, %[i], s62\n\t"
+                "v_writelane_b32 %[raw], s44, m0\n\t"
+                "s_add_u32 %[i], %[i], 1\n\t"
+                "s_sub_u32 s58, %[wpos], %[wbase]\n\t"
+                "s_and_b32 s58, s58, 63\n\t"
+                "v_readlane_b32 s57, %[wbuf], s58\n\t"
+                "s_mov_b32 s51, s50\n\t"
+                "s_mov_b32 s50, s57\n\t"
+                "s_mov_b32 s53, s48\n\t"
+                "s_mov_b32 s52, 0\n\t"
+                "s_add_u32 %[wpos], %[wpos], 1\n\t"
+                "s_cmp_eq_u32 s58, 63\n\t"
+                "s_cbranch_scc1 15f\n\t"
+                "v_add_u32 v50, 0x600, v50\n\t"
+                "s_cmp_lt_u32 %[i], s54\n\t"
+                "s_cbranch_scc0 2b\n\t"
+                "s_branch 1b\n\t"
                 "15:\n\t"
                 "s_mov_b32 %[st], 3\n\t"
                 "s_branch 4f\n\t"
