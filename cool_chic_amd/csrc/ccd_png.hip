@@ -1,0 +1,569 @@
+// ccd_png.hip - PNG packing of decoded 8-bit RGB planes on the device.
+//
+// Reference behaviour: coolchic/io/format/png.py:44-62 (write_png: [1,3,H,W] float in [0,1] -> HWC uint8 -> PIL save,
+// i.e. zlib deflate on the host).  The integer planes already exist on the device (ccd_batch_plane); this file turns
+// them into the bytes of a .png there, so that only the compressed file crosses PCIe and no host core runs zlib.
+// PNG bytes are not normative (any conforming zlib stream of the filtered scanlines is the same picture): the device
+// does not imitate zlib's LZ77 choices.  Parity bar (tests/test_gpu_parity.py): the picture PIL reads back is
+// pixel-exact, and the bytes equal those of the CPU restatement oracle/png_pack.py (all steps are integer).
+//
+// Format: signature, IHDR, one IDAT with a zlib stream (0x78 0x01) of the filtered scanlines, IEND.
+//   filter   per row the one of None/Sub/Up/Average/Paeth with the smallest sum of absolute signed residuals
+//   deflate  rows grouped into blocks of rows_per_block(w) rows (about 32 KB of scanlines); every block is a
+//            dynamic-Huffman block of literals only + end-of-block: HLIT = 257, HDIST = 1 (length 0), code-length
+//            alphabet = 4-bit codes for the lengths 0..15, no run-length symbols; literal lengths are optimal
+//            (Moffat-Katajainen in-place construction on symbols sorted by (count, symbol)), limited to 15 bits
+//
+// Kernels (all HBM traffic is one read of the planes, one write + one read of the scanlines, one write of the file):
+//   png_filter_huff_kernel  one workgroup per deflate block: filter choice, scanlines, per-row Adler sums, histogram in
+//                           LDS, bitonic sort of the used symbols, code lengths + canonical codes, bits of the block
+//   png_emit_kernel         one workgroup per deflate block: block start = sum of the previous blocks' bits; scanlines
+//                           staged in LDS, per-thread bit counts, scan, bit packing (whole words stored, the two
+//                           boundary words of a thread merged with atomicOr into the zeroed file)
+//   png_trailer_kernel      container bytes, Adler-32 from the row sums
+//   png_crc_kernel          CRC-32 of the IDAT chunk as XOR of 512-byte chunk CRCs multiplied by x^(8 * bytes behind)
+//   png_crc_final_kernel    stores the CRC, the IEND chunk and the file size
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <algorithm>
+#include <cstring>
+#include <new>
+
+#include "../../include/ccd.h"
+
+namespace {
+
+constexpr int kMaxBits = 15;
+constexpr int kHeaderBits = 3 + 5 + 5 + 4 + 19 * 3 + 258 * 4;  // 1106 bits in front of the first literal
+constexpr int kBlockTarget = 32768;   // bytes of scanlines per deflate block (at least one row)
+constexpr int kCrcChunk = 512;
+constexpr int kDataStart = 43;        // signature 8 + IHDR 25 + IDAT length/type 8 + zlib header 2
+constexpr int kMaxDim = 16383;        // 14-bit picture sizes (header.py:244-307); one scanline then fits the LDS stage
+constexpr int kStageBytes = 49152;    // LDS stage of png_emit_kernel: >= max(kBlockTarget, 3 * kMaxDim + 1)
+constexpr uint32_t kPoly = 0xEDB88320u;
+
+inline int rows_per_block(int w) { const int r = kBlockTarget / (3 * w + 1); return r < 1 ? 1 : r; }
+
+struct PngJob {
+    const uint8_t* plane[3];   // r, g, b: [h][w]
+    int32_t h, w, rows, nblk;  // rows = rows per deflate block
+    uint8_t* scan;             // [h][3 w + 1] filtered scanlines
+    uint32_t* codes;           // [nblk][257] bit-reversed code | length << 16
+    uint32_t* blk_bits;        // [nblk]
+    uint32_t* row_adler;       // [h][2] (sum d_i, sum (n - i) d_i) mod 65521
+    uint32_t* meta;            // [0] deflate bits, [1] deflate bytes, [2] file bytes, [3] crc accumulator, [4] overflow flag
+    uint32_t* out;             // the file (zeroed before the emit kernel), 4-byte aligned
+    uint64_t cap_bits;
+    uint32_t x2n[32];          // x^(2^k) mod P (CRC-32, reflected)
+    uint8_t head[kDataStart];  // signature + IHDR chunk + "IDAT" + zlib header (IDAT length filled in on the device)
+};
+
+__device__ __forceinline__ int abs_res(int v) { v &= 255; return v < 128 ? v : 256 - v; }
+
+__device__ __forceinline__ int paeth(int a, int b, int c) {
+    const int p = a + b - c;
+    const int pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+__device__ __forceinline__ int filt_one(int f, int x, int a, int b, int c) {
+    switch (f) {
+        case 0: return x & 255;
+        case 1: return (x - a) & 255;
+        case 2: return (x - b) & 255;
+        case 3: return (x - ((a + b) >> 1)) & 255;
+        default: return (x - paeth(a, b, c)) & 255;
+    }
+}
+
+__device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __brev(v) >> (32 - n); }
+
+// ---- kernel A -----------------------------------------------------------------------------------------------------
+constexpr int kThreadsA = 512;
+
+__global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngJob J) {
+    __shared__ uint32_t s_hist[257];
+    __shared__ uint32_t s_key[512];
+    __shared__ uint32_t s_len[257];
+    __shared__ uint32_t s_A[257];   // scratch of the code-length construction
+    __shared__ unsigned long long s_red[8][8];
+    __shared__ uint32_t s_m, s_sum;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int k = blockIdx.x;
+    const int w = J.w, n = 3 * w, N = n + 1;
+    const int y_lo = k * J.rows, y_hi = min(J.h, y_lo + J.rows);
+    for (int i = tid; i < 257; i += kThreadsA) { s_hist[i] = 0; s_len[i] = 0; }
+    if (tid == 0) { s_m = 0; s_sum = 0; }
+    __syncthreads();
+    for (int y = y_lo; y < y_hi; ++y) {
+        // ---- pass 1: cost of the five filters
+        unsigned long long cost[5] = {0, 0, 0, 0, 0};
+        for (int x = tid; x < w; x += kThreadsA) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint8_t* p = J.plane[c] + static_cast<size_t>(y) * w + x;
+                const int cur = p[0];
+                const int a = x > 0 ? p[-1] : 0;
+                const int b = y > 0 ? p[-w] : 0;
+                const int cc = (x > 0 && y > 0) ? p[-w - 1] : 0;
+                cost[0] += abs_res(cur);
+                cost[1] += abs_res(cur - a);
+                cost[2] += abs_res(cur - b);
+                cost[3] += abs_res(cur - ((a + b) >> 1));
+                cost[4] += abs_res(cur - paeth(a, b, cc));
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            unsigned long long v = cost[f];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (lane == 0) s_red[wave][f] = v;
+        }
+        __syncthreads();
+        int ftype = 0;
+        {
+            unsigned long long best = ~0ull;
+#pragma unroll
+            for (int f = 0; f < 5; ++f) {
+                unsigned long long v = 0;
+                for (int q = 0; q < 8; ++q) v += s_red[q][f];
+                if (v < best) { best = v; ftype = f; }
+            }
+        }
+        __syncthreads();
+        // ---- pass 2: scanline, histogram, Adler sums
+        uint8_t* row = J.scan + static_cast<size_t>(y) * N;
+        unsigned long long sa = 0, sb = 0;
+        if (tid == 0) {
+            row[0] = static_cast<uint8_t>(ftype);
+            atomicAdd(&s_hist[ftype], 1u);
+            sa += ftype;
+            sb += static_cast<unsigned long long>(N) * ftype;
+        }
+        for (int x = tid; x < w; x += kThreadsA) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const uint8_t* p = J.plane[c] + static_cast<size_t>(y) * w + x;
+                const int cur = p[0];
+                const int a = x > 0 ? p[-1] : 0;
+                const int b = y > 0 ? p[-w] : 0;
+                const int cc = (x > 0 && y > 0) ? p[-w - 1] : 0;
+                const int v = filt_one(ftype, cur, a, b, cc);
+                const int idx = 1 + 3 * x + c;
+                row[idx] = static_cast<uint8_t>(v);
+                atomicAdd(&s_hist[v], 1u);
+                sa += v;
+                sb += static_cast<unsigned long long>(N - idx) * v;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) { sa += __shfl_down(sa, o); sb += __shfl_down(sb, o); }
+        if (lane == 0) { s_red[wave][5] = sa; s_red[wave][6] = sb; }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long ta = 0, tb = 0;
+            for (int q = 0; q < 8; ++q) { ta += s_red[q][5]; tb += s_red[q][6]; }
+            J.row_adler[2 * y] = static_cast<uint32_t>(ta % 65521u);
+            J.row_adler[2 * y + 1] = static_cast<uint32_t>(tb % 65521u);
+        }
+        __syncthreads();
+    }
+    // ---- used symbols sorted by (count, symbol)
+    if (tid == 0) s_hist[256] = 1;
+    __syncthreads();
+    {
+        uint32_t key = 0xFFFFFFFFu;
+        if (tid < 257 && s_hist[tid] > 0) { key = (s_hist[tid] << 9) | static_cast<uint32_t>(tid); atomicAdd(&s_m, 1u); }
+        s_key[tid] = key;
+    }
+    __syncthreads();
+    for (int size = 2; size <= 512; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int partner = tid ^ stride;
+            if (partner > tid) {
+                const uint32_t a = s_key[tid], b = s_key[partner];
+                const bool up = (tid & size) == 0;
+                if ((a > b) == up) { s_key[tid] = b; s_key[partner] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- code lengths (one lane; at most 257 symbols)
+    if (tid == 0) {
+        const int m = static_cast<int>(s_m);
+        uint32_t* A = s_A;
+        for (int i = 0; i < m; ++i) A[i] = s_key[i] >> 9;
+        // Moffat-Katajainen: parent pointers, internal depths, leaf depths - in place on the ascending counts
+        A[0] += A[1];
+        int root = 0, leaf = 2;
+        for (int nxt = 1; nxt < m - 1; ++nxt) {
+            if (leaf >= m || A[root] < A[leaf]) { A[nxt] = A[root]; A[root++] = nxt; }
+            else A[nxt] = A[leaf++];
+            if (leaf >= m || (root < nxt && A[root] < A[leaf])) { A[nxt] += A[root]; A[root++] = nxt; }
+            else A[nxt] += A[leaf++];
+        }
+        A[m - 2] = 0;
+        for (int nxt = m - 3; nxt >= 0; --nxt) A[nxt] = A[A[nxt]] + 1;
+        {
+            int avbl = 1, used = 0, dpth = 0, nxt = m - 1;
+            root = m - 2;
+            while (avbl > 0) {
+                while (root >= 0 && static_cast<int>(A[root]) == dpth) { ++used; --root; }
+                while (avbl > used) { A[nxt--] = dpth; --avbl; }
+                avbl = 2 * used; ++dpth; used = 0;
+            }
+        }
+        // limit to 15 bits: fold longer codes into the limit, then work the Kraft excess off
+        int num[kMaxBits + 1];
+        for (int l = 0; l <= kMaxBits; ++l) num[l] = 0;
+        for (int i = 0; i < m; ++i) num[min(static_cast<int>(A[i]), kMaxBits)]++;
+        uint32_t total = 0;
+        for (int l = 1; l <= kMaxBits; ++l) total += static_cast<uint32_t>(num[l]) << (kMaxBits - l);
+        while (total != (1u << kMaxBits)) {
+            num[kMaxBits]--;
+            for (int l = kMaxBits - 1; l > 0; --l)
+                if (num[l]) { num[l]--; num[l + 1] += 2; break; }
+            --total;
+        }
+        int j = 0;
+        for (int l = kMaxBits; l > 0; --l)  // rarest symbols take the longest codes
+            for (int q = 0; q < num[l]; ++q) s_len[s_key[j++] & 511u] = static_cast<uint32_t>(l);
+        // canonical codes (RFC 1951 3.2.2): first code of every length, then symbols in order
+        uint32_t next_code[kMaxBits + 2];
+        uint32_t code = 0;
+        next_code[0] = 0;
+        for (int bits = 1; bits <= kMaxBits; ++bits) {
+            code = (code + (bits > 1 ? static_cast<uint32_t>(num[bits - 1]) : 0u)) << 1;
+            next_code[bits] = code;
+        }
+        uint32_t* out = J.codes + static_cast<size_t>(k) * 257;
+        for (int s = 0; s < 257; ++s) {
+            const int l = static_cast<int>(s_len[s]);
+            uint32_t v = 0;
+            if (l) { v = rev_bits(next_code[l], l) | (static_cast<uint32_t>(l) << 16); next_code[l]++; }
+            out[s] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < 257) atomicAdd(&s_sum, s_hist[tid] * s_len[tid]);
+    __syncthreads();
+    if (tid == 0) J.blk_bits[k] = kHeaderBits + s_sum;
+}
+
+// ---- kernel B -----------------------------------------------------------------------------------------------------
+constexpr int kThreadsB = 256;
+
+__device__ __forceinline__ void or_bits(uint32_t* out, uint64_t pos, uint32_t value, int nbits) {
+    if (nbits == 0) return;
+    const uint64_t v = static_cast<uint64_t>(value) << (pos & 31);
+    atomicOr(&out[pos >> 5], static_cast<uint32_t>(v));
+    if ((pos & 31) + nbits > 32) atomicOr(&out[(pos >> 5) + 1], static_cast<uint32_t>(v >> 32));
+}
+
+__global__ __launch_bounds__(kThreadsB) void png_emit_kernel(PngJob J) {
+    __shared__ uint8_t s_data[kStageBytes];
+    __shared__ uint32_t s_code[257];
+    __shared__ unsigned long long s_part[kThreadsB / 64];
+    __shared__ uint32_t s_scan[kThreadsB];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int k = blockIdx.x;
+    const int N = 3 * J.w + 1;
+    const int y_lo = k * J.rows, y_hi = min(J.h, y_lo + J.rows);
+    const int nb = (y_hi - y_lo) * N;
+    // start of the block = bits of all blocks before it
+    unsigned long long before = 0;
+    for (int i = tid; i < k; i += kThreadsB) before += J.blk_bits[i];
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
+    if (lane == 0) s_part[wave] = before;
+    for (int i = tid; i < 257; i += kThreadsB) s_code[i] = J.codes[static_cast<size_t>(k) * 257 + i];
+    {   // scanlines of the block -> LDS (4-byte words where the block start allows it)
+        const uint8_t* src = J.scan + static_cast<size_t>(y_lo) * N;
+        for (int i = tid; i < nb; i += kThreadsB) s_data[i] = src[i];
+    }
+    __syncthreads();
+    before = 0;
+    for (int q = 0; q < kThreadsB / 64; ++q) before += s_part[q];
+    const uint32_t my_bits = J.blk_bits[k];
+    const uint64_t start = static_cast<uint64_t>(kDataStart) * 8 + before;
+    if (k == J.nblk - 1 && tid == 0) J.meta[0] = static_cast<uint32_t>(before + my_bits);
+    if (start + my_bits + 256 > J.cap_bits) {  // 20 container bytes follow the last block
+        if (tid == 0) J.meta[4] = 1;  // never with a buffer of ccd_png_bound() bytes
+        return;
+    }
+    // ---- block header
+    if (tid == 0) {
+        const uint32_t final_blk = k == J.nblk - 1 ? 1u : 0u;
+        or_bits(J.out, start, final_blk | (2u << 1) | (0u << 3) | (0u << 8) | (15u << 13), 17);
+        const uint32_t eob = s_code[256];
+        or_bits(J.out, start + my_bits - (eob >> 16), eob & 0xFFFFu, static_cast<int>(eob >> 16));
+    }
+    if (tid < 19) or_bits(J.out, start + 17 + 3 * tid, tid < 3 ? 0u : 4u, 3);  // lengths of the code-length codes 16, 17, 18, then 0..15
+    for (int s = tid; s < 258; s += kThreadsB)
+        or_bits(J.out, start + 74 + 4 * s, rev_bits(s < 257 ? (s_code[s] >> 16) : 0u, 4), 4);
+    // ---- literals: contiguous chunk per thread
+    const int cb = (nb + kThreadsB - 1) / kThreadsB;
+    const int lo = min(nb, tid * cb), hi = min(nb, lo + cb);
+    uint32_t bits = 0;
+    for (int i = lo; i < hi; ++i) bits += s_code[s_data[i]] >> 16;
+    // exclusive scan over the workgroup
+    uint32_t incl = bits;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) s_scan[wave] = incl;
+    __syncthreads();
+    uint32_t offset = incl - bits;
+    for (int q = 0; q < wave; ++q) offset += s_scan[q];
+    uint64_t pos = start + kHeaderBits + offset;
+    uint32_t wi = static_cast<uint32_t>(pos >> 5);
+    int nacc = static_cast<int>(pos & 31);
+    uint64_t acc = 0;
+    bool first = true;
+    for (int i = lo; i < hi; ++i) {
+        const uint32_t c = s_code[s_data[i]];
+        acc |= static_cast<uint64_t>(c & 0xFFFFu) << nacc;
+        nacc += static_cast<int>(c >> 16);
+        if (nacc >= 32) {
+            if (first) atomicOr(&J.out[wi], static_cast<uint32_t>(acc));
+            else J.out[wi] = static_cast<uint32_t>(acc);  // every bit of this word belongs to this thread
+            first = false;
+            ++wi;
+            acc >>= 32;
+            nacc -= 32;
+        }
+    }
+    if (nacc > 0 && acc != 0) atomicOr(&J.out[wi], static_cast<uint32_t>(acc));
+}
+
+// ---- kernel C -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void put_be32(uint8_t* p, uint32_t v) {
+    p[0] = static_cast<uint8_t>(v >> 24); p[1] = static_cast<uint8_t>(v >> 16);
+    p[2] = static_cast<uint8_t>(v >> 8); p[3] = static_cast<uint8_t>(v);
+}
+
+__global__ void png_trailer_kernel(PngJob J) {
+    if (threadIdx.x != 0 || J.meta[4]) return;
+    uint8_t* out = reinterpret_cast<uint8_t*>(J.out);
+    const uint32_t n_def = (J.meta[0] + 7u) >> 3;
+    J.meta[1] = n_def;
+    // bytes 40..42 share a word with the first deflate byte, which is already there: OR them in
+    for (int i = 0; i < 40; ++i) out[i] = J.head[i];
+    for (int i = 40; i < kDataStart; ++i) out[i] |= J.head[i];
+    put_be32(out + 33, 2u + n_def + 4u);
+    // Adler-32 of the scanlines, row after row: B += n A + b_r, A += a_r
+    const uint32_t N = static_cast<uint32_t>(3 * J.w + 1) % 65521u;
+    uint32_t A = 1, B = 0;
+    for (int y = 0; y < J.h; ++y) {
+        B = static_cast<uint32_t>((B + static_cast<uint64_t>(N) * A + J.row_adler[2 * y + 1]) % 65521u);
+        A = (A + J.row_adler[2 * y]) % 65521u;
+    }
+    put_be32(out + kDataStart + n_def, (B << 16) | A);
+}
+
+// ---- kernel D -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b) {
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ kPoly : b >> 1;
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(256) void png_crc_kernel(PngJob J) {
+    __shared__ uint32_t s_tab[256];
+    {
+        uint32_t c = threadIdx.x;
+        for (int i = 0; i < 8; ++i) c = (c & 1u) ? (c >> 1) ^ kPoly : c >> 1;
+        s_tab[threadIdx.x] = c;
+    }
+    __syncthreads();
+    if (J.meta[4]) return;
+    // the IDAT chunk's CRC covers its type and data: file bytes [37, 37 + n)
+    const uint64_t n = 4ull + 2ull + J.meta[1] + 4ull;
+    const uint64_t lo = (static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x) * kCrcChunk;
+    if (lo >= n) return;
+    const uint64_t hi = min(n, lo + kCrcChunk);
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(J.out) + 37;
+    uint32_t crc = 0xFFFFFFFFu;
+    for (uint64_t i = lo; i < hi; ++i) crc = s_tab[(crc ^ p[i]) & 255u] ^ (crc >> 8);
+    crc ^= 0xFFFFFFFFu;
+    // multiply by x^(8 * bytes behind the chunk)
+    uint64_t behind = n - hi;
+    uint32_t xp = 1u << 31;
+    for (int kbit = 3; behind; behind >>= 1, ++kbit)
+        if (behind & 1) xp = multmodp(J.x2n[kbit & 31], xp);
+    atomicXor(&J.meta[3], multmodp(xp, crc));
+}
+
+__global__ void png_crc_final_kernel(PngJob J) {
+    if (threadIdx.x != 0 || J.meta[4]) return;
+    uint8_t* out = reinterpret_cast<uint8_t*>(J.out);
+    const uint32_t n_def = J.meta[1];
+    uint8_t* p = out + kDataStart + n_def + 4;
+    put_be32(p, J.meta[3]);
+    const uint8_t iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xAE, 0x42, 0x60, 0x82};
+    for (int i = 0; i < 12; ++i) p[4 + i] = iend[i];
+    J.meta[2] = kDataStart + n_def + 4 + 4 + 12;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+uint32_t host_multmodp(uint32_t a, uint32_t b) {
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) {
+            p ^= b;
+            if ((a & (m - 1)) == 0) break;
+        }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ kPoly : b >> 1;
+    }
+    return p;
+}
+
+uint32_t host_crc32(const uint8_t* p, size_t n) {
+    uint32_t crc = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; ++i) {
+        crc ^= p[i];
+        for (int k = 0; k < 8; ++k) crc = (crc & 1u) ? (crc >> 1) ^ kPoly : crc >> 1;
+    }
+    return crc ^ 0xFFFFFFFFu;
+}
+
+}  // namespace
+
+struct ccd_png {
+    int device = 0;
+    size_t scan_cap = 0, rows_cap = 0;
+    uint8_t* d_scan = nullptr;
+    uint32_t* d_codes = nullptr;     // [rows_cap][257] (a block holds at least one row)
+    uint32_t* d_blk_bits = nullptr;  // [rows_cap]
+    uint32_t* d_row_adler = nullptr; // [rows_cap][2]
+    uint32_t* d_meta = nullptr;      // [8]
+    uint32_t* h_meta = nullptr;      // pinned copy of d_meta
+    uint32_t x2n[32];
+    bool pending = false;
+};
+
+extern "C" {
+
+size_t ccd_png_bound(int h, int w) {
+    if (h <= 0 || w <= 0 || h > kMaxDim || w > kMaxDim) return 0;
+    const size_t raw = static_cast<size_t>(h) * (3 * static_cast<size_t>(w) + 1);
+    const size_t nblk = (static_cast<size_t>(h) + rows_per_block(w) - 1) / rows_per_block(w);
+    return (raw * 10 + 7) / 8 + nblk * 144 + 128;
+}
+
+int ccd_png_create(int device, ccd_png** out) {
+    if (!out) return CCD_ERR_ARG;
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) return CCD_ERR_HIP;
+    ccd_png* p = new (std::nothrow) ccd_png();
+    if (!p) return CCD_ERR_NOMEM;
+    p->device = device;
+    if (hipMalloc(&p->d_meta, 8 * sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc(&p->h_meta, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+        if (p->d_meta) (void)hipFree(p->d_meta);
+        delete p;
+        return CCD_ERR_NOMEM;
+    }
+    p->x2n[0] = 1u << 30;
+    for (int k = 1; k < 32; ++k) p->x2n[k] = host_multmodp(p->x2n[k - 1], p->x2n[k - 1]);
+    *out = p;
+    return CCD_OK;
+}
+
+void ccd_png_destroy(ccd_png* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->device);
+    if (p->d_scan) (void)hipFree(p->d_scan);
+    if (p->d_codes) (void)hipFree(p->d_codes);
+    if (p->d_blk_bits) (void)hipFree(p->d_blk_bits);
+    if (p->d_row_adler) (void)hipFree(p->d_row_adler);
+    if (p->d_meta) (void)hipFree(p->d_meta);
+    if (p->h_meta) (void)hipHostFree(p->h_meta);
+    delete p;
+}
+
+int ccd_png_pack(ccd_png* p, const uint8_t* r, const uint8_t* g, const uint8_t* b, int h, int w, uint8_t* out, size_t cap,
+                 void* stream) {
+    if (!p || !r || !g || !b || !out || h <= 0 || w <= 0 || h > kMaxDim || w > kMaxDim) return CCD_ERR_ARG;
+    if (reinterpret_cast<uintptr_t>(out) & 3u) return CCD_ERR_ARG;
+    if (cap < ccd_png_bound(h, w)) return CCD_ERR_ARG;
+    if (hipSetDevice(p->device) != hipSuccess) return CCD_ERR_HIP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t N = 3 * static_cast<size_t>(w) + 1;
+    const size_t scan_bytes = static_cast<size_t>(h) * N;
+    if (scan_bytes > p->scan_cap || static_cast<size_t>(h) > p->rows_cap) {
+        // the previous pack may still read the old workspace
+        if (hipStreamSynchronize(st) != hipSuccess) return CCD_ERR_HIP;
+        if (scan_bytes > p->scan_cap) {
+            if (p->d_scan) (void)hipFree(p->d_scan);
+            p->d_scan = nullptr; p->scan_cap = 0;
+            if (hipMalloc(&p->d_scan, scan_bytes) != hipSuccess) return CCD_ERR_NOMEM;
+            p->scan_cap = scan_bytes;
+        }
+        if (static_cast<size_t>(h) > p->rows_cap) {
+            if (p->d_codes) (void)hipFree(p->d_codes);
+            if (p->d_blk_bits) (void)hipFree(p->d_blk_bits);
+            if (p->d_row_adler) (void)hipFree(p->d_row_adler);
+            p->d_codes = p->d_blk_bits = p->d_row_adler = nullptr; p->rows_cap = 0;
+            if (hipMalloc(&p->d_codes, static_cast<size_t>(h) * 257 * 4) != hipSuccess ||
+                hipMalloc(&p->d_blk_bits, static_cast<size_t>(h) * 4) != hipSuccess ||
+                hipMalloc(&p->d_row_adler, static_cast<size_t>(h) * 8) != hipSuccess) return CCD_ERR_NOMEM;
+            p->rows_cap = h;
+        }
+    }
+    PngJob J;
+    std::memset(&J, 0, sizeof(J));
+    J.plane[0] = r; J.plane[1] = g; J.plane[2] = b;
+    J.h = h; J.w = w; J.rows = rows_per_block(w); J.nblk = (h + J.rows - 1) / J.rows;
+    J.scan = p->d_scan; J.codes = p->d_codes; J.blk_bits = p->d_blk_bits; J.row_adler = p->d_row_adler; J.meta = p->d_meta;
+    J.out = reinterpret_cast<uint32_t*>(out);
+    J.cap_bits = static_cast<uint64_t>(cap) * 8;
+    std::memcpy(J.x2n, p->x2n, sizeof(J.x2n));
+    {   // signature, IHDR (8-bit RGB, deflate, adaptive filtering, no interlace), IDAT type, zlib header (32 KB window, check bits)
+        uint8_t* q = J.head;
+        const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+        std::memcpy(q, sig, 8);
+        uint8_t ihdr[17] = {'I', 'H', 'D', 'R', 0, 0, 0, 0, 0, 0, 0, 0, 8, 2, 0, 0, 0};
+        for (int i = 0; i < 4; ++i) { ihdr[4 + i] = static_cast<uint8_t>(static_cast<uint32_t>(w) >> (24 - 8 * i)); ihdr[8 + i] = static_cast<uint8_t>(static_cast<uint32_t>(h) >> (24 - 8 * i)); }
+        q[8] = 0; q[9] = 0; q[10] = 0; q[11] = 13;
+        std::memcpy(q + 12, ihdr, 17);
+        const uint32_t c = host_crc32(ihdr, 17);
+        for (int i = 0; i < 4; ++i) q[29 + i] = static_cast<uint8_t>(c >> (24 - 8 * i));
+        q[37] = 'I'; q[38] = 'D'; q[39] = 'A'; q[40] = 'T'; q[41] = 0x78; q[42] = 0x01;
+    }
+    const size_t bound = ccd_png_bound(h, w);
+    // the bit packer merges into zeroed words
+    const size_t zero_bytes = std::min(cap & ~static_cast<size_t>(3), (bound + 3) & ~static_cast<size_t>(3));
+    if (hipMemsetAsync(out, 0, zero_bytes, st) != hipSuccess) return CCD_ERR_HIP;
+    if (hipMemsetAsync(p->d_meta, 0, 8 * sizeof(uint32_t), st) != hipSuccess) return CCD_ERR_HIP;
+    hipLaunchKernelGGL(png_filter_huff_kernel, dim3(J.nblk), dim3(kThreadsA), 0, st, J);
+    hipLaunchKernelGGL(png_emit_kernel, dim3(J.nblk), dim3(kThreadsB), 0, st, J);
+    hipLaunchKernelGGL(png_trailer_kernel, dim3(1), dim3(64), 0, st, J);
+    const size_t max_crc_bytes = bound;
+    const unsigned crc_blocks = static_cast<unsigned>((max_crc_bytes / kCrcChunk + 256) / 256);
+    hipLaunchKernelGGL(png_crc_kernel, dim3(crc_blocks), dim3(256), 0, st, J);
+    hipLaunchKernelGGL(png_crc_final_kernel, dim3(1), dim3(64), 0, st, J);
+    if (hipGetLastError() != hipSuccess) return CCD_ERR_HIP;
+    if (hipMemcpyAsync(p->h_meta, p->d_meta, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return CCD_ERR_HIP;
+    p->pending = true;
+    return CCD_OK;
+}
+
+int64_t ccd_png_finish(ccd_png* p, void* stream) {
+    if (!p || !p->pending) return CCD_ERR_ARG;
+    if (hipSetDevice(p->device) != hipSuccess) return CCD_ERR_HIP;
+    if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return CCD_ERR_HIP;
+    p->pending = false;
+    if (p->h_meta[4]) return CCD_ERR_NOMEM;  // the file did not fit `cap` (cannot happen with ccd_png_bound())
+    return static_cast<int64_t>(p->h_meta[2]);
+}
+
+}  // extern "C"

@@ -39,13 +39,22 @@ def save_frame_data_to_file(frame_data: FrameData, file_path: str, append: bool 
     """io/io.py:53-105."""
     ext = os.path.splitext(file_path)[1]
     assert ext in (".yuv", ".png", ".ppm"), f"expected a .yuv, .png or .ppm path, found {file_path}"
-    planes = frame_data.integer_planes()
     if ext == ".png":
+        # io/format/png.py:44-62.  The file is packed on the GPU (csrc/ccd_png.hip): only compressed bytes leave HBM.
         assert frame_data.frame_data_type == "rgb" and frame_data.bitdepth == 8, "PNG output needs 8-bit RGB"
-        from PIL import Image
+        import torch
 
-        Image.fromarray(np.stack(planes, axis=-1), mode="RGB").save(file_path)  # io/format/png.py:44-62
-    elif ext == ".ppm":
+        from .png import device_png_bytes
+
+        data = frame_data.data
+        if not data.is_cuda:
+            data = data.cuda()
+        planes = torch.round(data[0].to(torch.float32) * 255.0).to(torch.uint8)
+        with open(file_path, "wb") as f:
+            f.write(device_png_bytes(planes))
+        return
+    planes = frame_data.integer_planes()
+    if ext == ".ppm":
         assert frame_data.frame_data_type == "rgb"
         h, w = planes[0].shape
         maxv = 2 ** frame_data.bitdepth - 1
