@@ -173,6 +173,41 @@ def main():
             e1.record(stream)
             torch.cuda.synchronize(local_rank)
             stage_ms[name] = e0.elapsed_time(e1) / args.steps
+    # ---- second leg (reported beside the metric, never as `value`): the same step followed by PNG packing of every
+    # decoded frame on the device (ccd_png_*), packs spread over side streams
+    png_leg = None
+    if rank == 0:
+        from cool_chic_amd.io.png import PngPacker
+
+        packers = [PngPacker(local_rank) for _ in range(n_frames)]
+        side = [torch.cuda.Stream(device=dev) for _ in range(8)]
+        files = [torch.empty(PngPacker.bound(h, w) + 4, dtype=torch.uint8, device=dev) for *_, (h, w) in items]
+        addr = [[batch.plane_device(s, p).__cuda_array_interface__["data"][0] for p in range(3)] for s in range(n_frames)]
+
+        def step_png():
+            batch.run(sh)
+            done = torch.cuda.Event()
+            done.record(stream)
+            for s_, (*_, (h, w)) in enumerate(items):
+                st = side[s_ % len(side)]
+                st.wait_event(done)
+                packers[s_].pack_async(addr[s_][0], addr[s_][1], addr[s_][2], h, w, files[s_], st.cuda_stream)
+            for st in side:
+                stream.wait_stream(st)
+
+        step_png()
+        torch.cuda.synchronize(local_rank)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_png()
+        torch.cuda.synchronize(local_rank)
+        dt_png = time.perf_counter() - t1
+        sizes = [pk.finish(side[s_ % len(side)].cuda_stream) for s_, pk in enumerate(packers)]
+        png_leg = {"value": px_per_step * args.steps / dt_png / 1e6, "unit": "Mpixel/s", "n_gpus": 1,
+                   "ms_per_step": dt_png / args.steps * 1e3, "png_bytes_per_step": int(sum(sizes)),
+                   "note": "decode + on-device PNG packing of all frames (files left in HBM); rank 0 alone"}
+        for pk in packers:
+            pk.close()
     if world > 1:
         dist.barrier()
 
@@ -235,6 +270,7 @@ def main():
             "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, raw KiB counters summed "
                               "(profiles/r01/kodak24_pmc_traffic.json; FETCH_SIZE uncalibrated for 4-byte accesses on gfx950)",
         }
+        res["with_png_packing"] = png_leg
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(streams)
         print(json.dumps(res))

@@ -80,21 +80,23 @@ __device__ __forceinline__ int filt_one(int f, int x, int a, int b, int c) {
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __brev(v) >> (32 - n); }
 
 // ---- kernel A -----------------------------------------------------------------------------------------------------
-constexpr int kThreadsA = 512;
+constexpr int kThreadsA = 256;
 
 __global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngJob J) {
     __shared__ uint32_t s_hist[257];
     __shared__ uint32_t s_key[512];
     __shared__ uint32_t s_len[257];
     __shared__ uint32_t s_A[257];   // scratch of the code-length construction
-    __shared__ unsigned long long s_red[8][8];
+    __shared__ unsigned long long s_red[kThreadsA / 64][8];
     __shared__ uint32_t s_m, s_sum;
+    __shared__ uint32_t s_num[kMaxBits + 1], s_first[kMaxBits + 1], s_base[kMaxBits + 1];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int k = blockIdx.x;
     const int w = J.w, n = 3 * w, N = n + 1;
     const int y_lo = k * J.rows, y_hi = min(J.h, y_lo + J.rows);
     for (int i = tid; i < 257; i += kThreadsA) { s_hist[i] = 0; s_len[i] = 0; }
     if (tid == 0) { s_m = 0; s_sum = 0; }
+    if (tid <= kMaxBits) s_num[tid] = 0;
     __syncthreads();
     for (int y = y_lo; y < y_hi; ++y) {
         // ---- pass 1: cost of the five filters
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngJob J) {
 #pragma unroll
             for (int f = 0; f < 5; ++f) {
                 unsigned long long v = 0;
-                for (int q = 0; q < 8; ++q) v += s_red[q][f];
+                for (int q = 0; q < kThreadsA / 64; ++q) v += s_red[q][f];
                 if (v < best) { best = v; ftype = f; }
             }
         }
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngJob J) {
         __syncthreads();
         if (tid == 0) {
             unsigned long long ta = 0, tb = 0;
-            for (int q = 0; q < 8; ++q) { ta += s_red[q][5]; tb += s_red[q][6]; }
+            for (int q = 0; q < kThreadsA / 64; ++q) { ta += s_red[q][5]; tb += s_red[q][6]; }
             J.row_adler[2 * y] = static_cast<uint32_t>(ta % 65521u);
             J.row_adler[2 * y + 1] = static_cast<uint32_t>(tb % 65521u);
         }
@@ -171,26 +173,28 @@ __global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngJob J) {
     // ---- used symbols sorted by (count, symbol)
     if (tid == 0) s_hist[256] = 1;
     __syncthreads();
-    {
+    for (int t = tid; t < 512; t += kThreadsA) {
         uint32_t key = 0xFFFFFFFFu;
-        if (tid < 257 && s_hist[tid] > 0) { key = (s_hist[tid] << 9) | static_cast<uint32_t>(tid); atomicAdd(&s_m, 1u); }
-        s_key[tid] = key;
+        if (t < 257 && s_hist[t] > 0) { key = (s_hist[t] << 9) | static_cast<uint32_t>(t); atomicAdd(&s_m, 1u); }
+        s_key[t] = key;
     }
     __syncthreads();
     for (int size = 2; size <= 512; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int partner = tid ^ stride;
-            if (partner > tid) {
-                const uint32_t a = s_key[tid], b = s_key[partner];
-                const bool up = (tid & size) == 0;
-                if ((a > b) == up) { s_key[tid] = b; s_key[partner] = a; }
+            for (int t = tid; t < 512; t += kThreadsA) {
+                const int partner = t ^ stride;
+                if (partner > t) {
+                    const uint32_t a = s_key[t], b = s_key[partner];
+                    const bool up = (t & size) == 0;
+                    if ((a > b) == up) { s_key[t] = b; s_key[partner] = a; }
+                }
             }
             __syncthreads();
         }
     }
-    // ---- code lengths (one lane; at most 257 symbols)
+    // ---- optimal code lengths of the sorted symbols (one lane: the two-queue merge is sequential; at most 257 symbols)
+    const int m = static_cast<int>(s_m);
     if (tid == 0) {
-        const int m = static_cast<int>(s_m);
         uint32_t* A = s_A;
         for (int i = 0; i < m; ++i) A[i] = s_key[i] >> 9;
         // Moffat-Katajainen: parent pointers, internal depths, leaf depths - in place on the ascending counts
@@ -213,39 +217,48 @@ __global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngJob J) {
                 avbl = 2 * used; ++dpth; used = 0;
             }
         }
-        // limit to 15 bits: fold longer codes into the limit, then work the Kraft excess off
-        int num[kMaxBits + 1];
-        for (int l = 0; l <= kMaxBits; ++l) num[l] = 0;
-        for (int i = 0; i < m; ++i) num[min(static_cast<int>(A[i]), kMaxBits)]++;
+    }
+    __syncthreads();
+    // ---- limit to 15 bits: codes per length (longer ones folded into the limit), then the Kraft excess is worked off
+    for (int i = tid; i < m; i += kThreadsA) atomicAdd(&s_num[min(static_cast<int>(s_A[i]), kMaxBits)], 1u);
+    __syncthreads();
+    if (tid == 0) {
         uint32_t total = 0;
-        for (int l = 1; l <= kMaxBits; ++l) total += static_cast<uint32_t>(num[l]) << (kMaxBits - l);
+        for (int l = 1; l <= kMaxBits; ++l) total += s_num[l] << (kMaxBits - l);
         while (total != (1u << kMaxBits)) {
-            num[kMaxBits]--;
+            s_num[kMaxBits]--;
             for (int l = kMaxBits - 1; l > 0; --l)
-                if (num[l]) { num[l]--; num[l + 1] += 2; break; }
+                if (s_num[l]) { s_num[l]--; s_num[l + 1] += 2; break; }
             --total;
         }
-        int j = 0;
-        for (int l = kMaxBits; l > 0; --l)  // rarest symbols take the longest codes
-            for (int q = 0; q < num[l]; ++q) s_len[s_key[j++] & 511u] = static_cast<uint32_t>(l);
-        // canonical codes (RFC 1951 3.2.2): first code of every length, then symbols in order
-        uint32_t next_code[kMaxBits + 2];
-        uint32_t code = 0;
-        next_code[0] = 0;
+        // rarest symbols take the longest codes: sorted positions [s_first[l], s_first[l] + num[l]) get length l;
+        // canonical codes (RFC 1951 3.2.2): first code of every length
+        uint32_t first = 0, code = 0;
+        for (int l = kMaxBits; l > 0; --l) { s_first[l] = first; first += s_num[l]; }
         for (int bits = 1; bits <= kMaxBits; ++bits) {
-            code = (code + (bits > 1 ? static_cast<uint32_t>(num[bits - 1]) : 0u)) << 1;
-            next_code[bits] = code;
-        }
-        uint32_t* out = J.codes + static_cast<size_t>(k) * 257;
-        for (int s = 0; s < 257; ++s) {
-            const int l = static_cast<int>(s_len[s]);
-            uint32_t v = 0;
-            if (l) { v = rev_bits(next_code[l], l) | (static_cast<uint32_t>(l) << 16); next_code[l]++; }
-            out[s] = v;
+            code = (code + (bits > 1 ? s_num[bits - 1] : 0u)) << 1;
+            s_base[bits] = code;
         }
     }
     __syncthreads();
-    if (tid < 257) atomicAdd(&s_sum, s_hist[tid] * s_len[tid]);
+    for (int j = tid; j < m; j += kThreadsA) {
+        int l = kMaxBits;
+        while (static_cast<uint32_t>(j) >= s_first[l] + s_num[l]) --l;
+        s_len[s_key[j] & 511u] = static_cast<uint32_t>(l);
+    }
+    __syncthreads();
+    // ---- canonical codes: within a length, symbols in increasing order
+    for (int sy = tid; sy < 257; sy += kThreadsA) {
+        const uint32_t l = s_len[sy];
+        uint32_t v = 0;
+        if (l) {
+            uint32_t rank = 0;
+            for (int q = 0; q < sy; ++q) rank += s_len[q] == l ? 1u : 0u;
+            v = rev_bits(s_base[l] + rank, static_cast<int>(l)) | (l << 16);
+        }
+        J.codes[static_cast<size_t>(k) * 257 + sy] = v;
+        atomicAdd(&s_sum, s_hist[sy] * l);
+    }
     __syncthreads();
     if (tid == 0) J.blk_bits[k] = kHeaderBits + s_sum;
 }
@@ -342,8 +355,28 @@ __device__ __forceinline__ void put_be32(uint8_t* p, uint32_t v) {
     p[2] = static_cast<uint8_t>(v >> 8); p[3] = static_cast<uint8_t>(v);
 }
 
-__global__ void png_trailer_kernel(PngJob J) {
-    if (threadIdx.x != 0 || J.meta[4]) return;
+__global__ __launch_bounds__(256) void png_trailer_kernel(PngJob J) {
+    __shared__ unsigned long long s_r[4][3];
+    if (J.meta[4]) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // Adler-32 of the scanlines from the row sums.  Row after row it is B += N A + b_r, A += a_r, starting at A = 1, B = 0;
+    // in closed form A = 1 + sum a_q and B = sum b_q + N (H + sum a_q (H - 1 - q)), everything modulo 65521.
+    unsigned long long sa = 0, sb = 0, sw = 0;
+    for (int q = tid; q < J.h; q += 256) {
+        const unsigned long long a = J.row_adler[2 * q];
+        sa += a;
+        sb += J.row_adler[2 * q + 1];
+        sw += a * static_cast<unsigned long long>(J.h - 1 - q);  // < 2^16 * 2^14 per term, at most 64 terms per thread
+    }
+    for (int o = 32; o > 0; o >>= 1) { sa += __shfl_down(sa, o); sb += __shfl_down(sb, o); sw += __shfl_down(sw, o); }
+    if (lane == 0) { s_r[wave][0] = sa; s_r[wave][1] = sb; s_r[wave][2] = sw; }
+    __syncthreads();
+    if (tid != 0) return;
+    sa = sb = sw = 0;
+    for (int q = 0; q < 4; ++q) { sa += s_r[q][0]; sb += s_r[q][1]; sw += s_r[q][2]; }
+    const unsigned long long M = 65521ull, N = static_cast<unsigned long long>(3 * J.w + 1) % M;
+    const uint32_t A = static_cast<uint32_t>((1 + sa) % M);
+    const uint32_t B = static_cast<uint32_t>((sb % M + N * ((static_cast<unsigned long long>(J.h) + sw % M) % M)) % M);
     uint8_t* out = reinterpret_cast<uint8_t*>(J.out);
     const uint32_t n_def = (J.meta[0] + 7u) >> 3;
     J.meta[1] = n_def;
@@ -351,13 +384,6 @@ __global__ void png_trailer_kernel(PngJob J) {
     for (int i = 0; i < 40; ++i) out[i] = J.head[i];
     for (int i = 40; i < kDataStart; ++i) out[i] |= J.head[i];
     put_be32(out + 33, 2u + n_def + 4u);
-    // Adler-32 of the scanlines, row after row: B += n A + b_r, A += a_r
-    const uint32_t N = static_cast<uint32_t>(3 * J.w + 1) % 65521u;
-    uint32_t A = 1, B = 0;
-    for (int y = 0; y < J.h; ++y) {
-        B = static_cast<uint32_t>((B + static_cast<uint64_t>(N) * A + J.row_adler[2 * y + 1]) % 65521u);
-        A = (A + J.row_adler[2 * y]) % 65521u;
-    }
     put_be32(out + kDataStart + n_def, (B << 16) | A);
 }
 
@@ -376,25 +402,38 @@ __device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b) {
 }
 
 __global__ __launch_bounds__(256) void png_crc_kernel(PngJob J) {
-    __shared__ uint32_t s_tab[256];
+    // slice-by-4 tables: s_tab[j][v] = CRC of byte v followed by j zero bytes
+    __shared__ uint32_t s_tab[4][256];
     {
         uint32_t c = threadIdx.x;
         for (int i = 0; i < 8; ++i) c = (c & 1u) ? (c >> 1) ^ kPoly : c >> 1;
-        s_tab[threadIdx.x] = c;
+        s_tab[0][threadIdx.x] = c;
     }
     __syncthreads();
+    for (int j = 1; j < 4; ++j) {
+        const uint32_t c = s_tab[j - 1][threadIdx.x];
+        s_tab[j][threadIdx.x] = (c >> 8) ^ s_tab[0][c & 255u];
+        __syncthreads();
+    }
     if (J.meta[4]) return;
-    // the IDAT chunk's CRC covers its type and data: file bytes [37, 37 + n)
-    const uint64_t n = 4ull + 2ull + J.meta[1] + 4ull;
-    const uint64_t lo = (static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x) * kCrcChunk;
-    if (lo >= n) return;
-    const uint64_t hi = min(n, lo + kCrcChunk);
-    const uint8_t* p = reinterpret_cast<const uint8_t*>(J.out) + 37;
+    // The IDAT chunk's CRC covers its type and data: file bytes [37, end).  Chunks are cut at multiples of kCrcChunk of
+    // the FILE offset, so every chunk but the first starts on a word.
+    const uint64_t end = 37ull + 4ull + 2ull + J.meta[1] + 4ull;
+    const uint64_t c0 = (static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x) * kCrcChunk;
+    if (c0 >= end) return;
+    uint64_t i = c0 < 37 ? 37 : c0;
+    const uint64_t hi = min(end, c0 + kCrcChunk);
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(J.out);
     uint32_t crc = 0xFFFFFFFFu;
-    for (uint64_t i = lo; i < hi; ++i) crc = s_tab[(crc ^ p[i]) & 255u] ^ (crc >> 8);
+    for (; i < hi && (i & 3); ++i) crc = s_tab[0][(crc ^ p[i]) & 255u] ^ (crc >> 8);
+    for (; i + 4 <= hi; i += 4) {
+        crc ^= J.out[i >> 2];
+        crc = s_tab[3][crc & 255u] ^ s_tab[2][(crc >> 8) & 255u] ^ s_tab[1][(crc >> 16) & 255u] ^ s_tab[0][crc >> 24];
+    }
+    for (; i < hi; ++i) crc = s_tab[0][(crc ^ p[i]) & 255u] ^ (crc >> 8);
     crc ^= 0xFFFFFFFFu;
     // multiply by x^(8 * bytes behind the chunk)
-    uint64_t behind = n - hi;
+    uint64_t behind = end - hi;
     uint32_t xp = 1u << 31;
     for (int kbit = 3; behind; behind >>= 1, ++kbit)
         if (behind & 1) xp = multmodp(J.x2n[kbit & 31], xp);
@@ -546,9 +585,8 @@ int ccd_png_pack(ccd_png* p, const uint8_t* r, const uint8_t* g, const uint8_t* 
     if (hipMemsetAsync(p->d_meta, 0, 8 * sizeof(uint32_t), st) != hipSuccess) return CCD_ERR_HIP;
     hipLaunchKernelGGL(png_filter_huff_kernel, dim3(J.nblk), dim3(kThreadsA), 0, st, J);
     hipLaunchKernelGGL(png_emit_kernel, dim3(J.nblk), dim3(kThreadsB), 0, st, J);
-    hipLaunchKernelGGL(png_trailer_kernel, dim3(1), dim3(64), 0, st, J);
-    const size_t max_crc_bytes = bound;
-    const unsigned crc_blocks = static_cast<unsigned>((max_crc_bytes / kCrcChunk + 256) / 256);
+    hipLaunchKernelGGL(png_trailer_kernel, dim3(1), dim3(256), 0, st, J);
+    const unsigned crc_blocks = static_cast<unsigned>((bound / kCrcChunk + 256) / 256);
     hipLaunchKernelGGL(png_crc_kernel, dim3(crc_blocks), dim3(256), 0, st, J);
     hipLaunchKernelGGL(png_crc_final_kernel, dim3(1), dim3(64), 0, st, J);
     if (hipGetLastError() != hipSuccess) return CCD_ERR_HIP;
