@@ -179,21 +179,14 @@ def main():
     if rank == 0:
         from cool_chic_amd.io.png import PngPacker
 
-        packers = [PngPacker(local_rank) for _ in range(n_frames)]
-        side = [torch.cuda.Stream(device=dev) for _ in range(8)]
+        packer = PngPacker(local_rank)
         files = [torch.empty(PngPacker.bound(h, w) + 4, dtype=torch.uint8, device=dev) for *_, (h, w) in items]
         addr = [[batch.plane_device(s, p).__cuda_array_interface__["data"][0] for p in range(3)] for s in range(n_frames)]
+        png_items = [(addr[s_][0], addr[s_][1], addr[s_][2], h, w, files[s_]) for s_, (*_, (h, w)) in enumerate(items)]
 
         def step_png():
             batch.run(sh)
-            done = torch.cuda.Event()
-            done.record(stream)
-            for s_, (*_, (h, w)) in enumerate(items):
-                st = side[s_ % len(side)]
-                st.wait_event(done)
-                packers[s_].pack_async(addr[s_][0], addr[s_][1], addr[s_][2], h, w, files[s_], st.cuda_stream)
-            for st in side:
-                stream.wait_stream(st)
+            packer.pack_batch_async(png_items, sh)  # all deflate blocks of all frames: one set of five launches
 
         step_png()
         torch.cuda.synchronize(local_rank)
@@ -202,12 +195,11 @@ def main():
             step_png()
         torch.cuda.synchronize(local_rank)
         dt_png = time.perf_counter() - t1
-        sizes = [pk.finish(side[s_ % len(side)].cuda_stream) for s_, pk in enumerate(packers)]
+        sizes = packer.finish_batch(sh)
         png_leg = {"value": px_per_step * args.steps / dt_png / 1e6, "unit": "Mpixel/s", "n_gpus": 1,
                    "ms_per_step": dt_png / args.steps * 1e3, "png_bytes_per_step": int(sum(sizes)),
                    "note": "decode + on-device PNG packing of all frames (files left in HBM); rank 0 alone"}
-        for pk in packers:
-            pk.close()
+        packer.close()
     if world > 1:
         dist.barrier()
 

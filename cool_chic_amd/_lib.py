@@ -63,6 +63,11 @@ class Frame(C.Structure):
                 ("plane", C.POINTER(C.c_uint16) * 3)]
 
 
+class PngItem(C.Structure):
+    _fields_ = [("r", C.c_void_p), ("g", C.c_void_p), ("b", C.c_void_p), ("h", C.c_int32), ("w", C.c_int32),
+                ("out", C.c_void_p), ("cap", C.c_size_t)]
+
+
 class Video(C.Structure):
     _fields_ = [("n_frames", C.c_int32), ("frames", C.POINTER(Frame))]
 
@@ -119,6 +124,8 @@ SIGNATURES = {
     "ccd_png_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                C.c_void_p]),
     "ccd_png_finish": (C.c_int64, [C.c_void_p, C.c_void_p]),
+    "ccd_png_pack_batch": (C.c_int, [C.c_void_p, C.POINTER(PngItem), C.c_int, C.c_void_p]),
+    "ccd_png_finish_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "ccd_debug_laplace_bounds": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_void_p]),
 }

@@ -45,19 +45,38 @@ constexpr uint32_t kPoly = 0xEDB88320u;
 
 inline int rows_per_block(int w) { const int r = kBlockTarget / (3 * w + 1); return r < 1 ? 1 : r; }
 
-struct PngJob {
+constexpr int kMaxBatch = 64;        // pictures per launch set (a longer list is packed in several sets)
+
+struct PngJob {                // one picture (a table of these lives in device memory)
     const uint8_t* plane[3];   // r, g, b: [h][w]
-    int32_t h, w, rows, nblk;  // rows = rows per deflate block
+    uint32_t* out;             // the file, 4-byte aligned
+    uint64_t cap_bits;
     uint8_t* scan;             // [h][3 w + 1] filtered scanlines
     uint32_t* codes;           // [nblk][257] bit-reversed code | length << 16
     uint32_t* blk_bits;        // [nblk]
     uint32_t* row_adler;       // [h][2] (sum d_i, sum (n - i) d_i) mod 65521
     uint32_t* meta;            // [0] deflate bits, [1] deflate bytes, [2] file bytes, [3] crc accumulator, [4] overflow flag
-    uint32_t* out;             // the file (zeroed before the emit kernel), 4-byte aligned
-    uint64_t cap_bits;
-    uint32_t x2n[32];          // x^(2^k) mod P (CRC-32, reflected)
-    uint8_t head[kDataStart];  // signature + IHDR chunk + "IDAT" + zlib header (IDAT length filled in on the device)
+    int32_t h, w, rows, nblk;  // rows = rows per deflate block
+    uint32_t zero_words, pad;  // words of `out` cleared before the bit packer merges into them
 };
+
+struct PngBatch {              // kernel argument
+    const PngJob* img;
+    int32_t n, pad;
+    uint32_t blk_prefix[kMaxBatch + 1];  // first workgroup of picture i in the per-block kernels
+    uint32_t crc_prefix[kMaxBatch + 1];  // first workgroup of picture i in the CRC kernel
+    uint32_t x2n[32];                    // x^(2^k) mod P (CRC-32, reflected)
+};
+
+// picture that owns workgroup `wg` (prefix[] sits in the kernel argument segment: scalar loads)
+__device__ __forceinline__ int find_image(const uint32_t* prefix, int n, uint32_t wg) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (prefix[mid] <= wg) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
 
 __device__ __forceinline__ int abs_res(int v) { v &= 255; return v < 128 ? v : 256 - v; }
 
@@ -82,7 +101,7 @@ __device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __brev(
 // ---- kernel A -----------------------------------------------------------------------------------------------------
 constexpr int kThreadsA = 256;
 
-__global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngJob J) {
+__global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngBatch B) {
     __shared__ uint32_t s_hist[257];
     __shared__ uint32_t s_key[512];
     __shared__ uint32_t s_len[257];
@@ -91,8 +110,16 @@ __global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngJob J) {
     __shared__ uint32_t s_m, s_sum;
     __shared__ uint32_t s_num[kMaxBits + 1], s_first[kMaxBits + 1], s_base[kMaxBits + 1];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int k = blockIdx.x;
+    const int im = find_image(B.blk_prefix, B.n, blockIdx.x);
+    const PngJob J = B.img[im];
+    const int k = static_cast<int>(blockIdx.x - B.blk_prefix[im]);
     const int w = J.w, n = 3 * w, N = n + 1;
+    {   // this block's share of the file is cleared here (the bit packer of the next kernel merges into zeroed words)
+        const uint32_t share = (J.zero_words + J.nblk - 1) / J.nblk;
+        const uint32_t z_lo = min(J.zero_words, static_cast<uint32_t>(k) * share), z_hi = min(J.zero_words, z_lo + share);
+        for (uint32_t i = z_lo + tid; i < z_hi; i += kThreadsA) J.out[i] = 0;
+        if (k == 0 && tid < 8) J.meta[tid] = 0;
+    }
     const int y_lo = k * J.rows, y_hi = min(J.h, y_lo + J.rows);
     for (int i = tid; i < 257; i += kThreadsA) { s_hist[i] = 0; s_len[i] = 0; }
     if (tid == 0) { s_m = 0; s_sum = 0; }
@@ -273,13 +300,15 @@ __device__ __forceinline__ void or_bits(uint32_t* out, uint64_t pos, uint32_t va
     if ((pos & 31) + nbits > 32) atomicOr(&out[(pos >> 5) + 1], static_cast<uint32_t>(v >> 32));
 }
 
-__global__ __launch_bounds__(kThreadsB) void png_emit_kernel(PngJob J) {
+__global__ __launch_bounds__(kThreadsB) void png_emit_kernel(PngBatch B) {
     __shared__ uint8_t s_data[kStageBytes];
     __shared__ uint32_t s_code[257];
     __shared__ unsigned long long s_part[kThreadsB / 64];
     __shared__ uint32_t s_scan[kThreadsB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int k = blockIdx.x;
+    const int im = find_image(B.blk_prefix, B.n, blockIdx.x);
+    const PngJob J = B.img[im];
+    const int k = static_cast<int>(blockIdx.x - B.blk_prefix[im]);
     const int N = 3 * J.w + 1;
     const int y_lo = k * J.rows, y_hi = min(J.h, y_lo + J.rows);
     const int nb = (y_hi - y_lo) * N;
@@ -355,8 +384,9 @@ __device__ __forceinline__ void put_be32(uint8_t* p, uint32_t v) {
     p[2] = static_cast<uint8_t>(v >> 8); p[3] = static_cast<uint8_t>(v);
 }
 
-__global__ __launch_bounds__(256) void png_trailer_kernel(PngJob J) {
+__global__ __launch_bounds__(256) void png_trailer_kernel(PngBatch B) {
     __shared__ unsigned long long s_r[4][3];
+    const PngJob J = B.img[blockIdx.x];
     if (J.meta[4]) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // Adler-32 of the scanlines from the row sums.  Row after row it is B += N A + b_r, A += a_r, starting at A = 1, B = 0;
@@ -375,16 +405,35 @@ __global__ __launch_bounds__(256) void png_trailer_kernel(PngJob J) {
     sa = sb = sw = 0;
     for (int q = 0; q < 4; ++q) { sa += s_r[q][0]; sb += s_r[q][1]; sw += s_r[q][2]; }
     const unsigned long long M = 65521ull, N = static_cast<unsigned long long>(3 * J.w + 1) % M;
-    const uint32_t A = static_cast<uint32_t>((1 + sa) % M);
-    const uint32_t B = static_cast<uint32_t>((sb % M + N * ((static_cast<unsigned long long>(J.h) + sw % M) % M)) % M);
+    const uint32_t ad_a = static_cast<uint32_t>((1 + sa) % M);
+    const uint32_t ad_b = static_cast<uint32_t>((sb % M + N * ((static_cast<unsigned long long>(J.h) + sw % M) % M)) % M);
     uint8_t* out = reinterpret_cast<uint8_t*>(J.out);
     const uint32_t n_def = (J.meta[0] + 7u) >> 3;
     J.meta[1] = n_def;
-    // bytes 40..42 share a word with the first deflate byte, which is already there: OR them in
-    for (int i = 0; i < 40; ++i) out[i] = J.head[i];
-    for (int i = 40; i < kDataStart; ++i) out[i] |= J.head[i];
+    // signature, IHDR (8-bit RGB, deflate, adaptive filtering, no interlace), IDAT type, zlib header (32 KB window, no
+    // preset dictionary, check bits).  Bytes 40..42 share a word with the first deflate byte, which is already there.
+    uint8_t head[kDataStart];
+    for (int i = 0; i < kDataStart; ++i) head[i] = 0;
+    const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
+    for (int i = 0; i < 8; ++i) head[i] = sig[i];
+    head[11] = 13;
+    head[12] = 'I'; head[13] = 'H'; head[14] = 'D'; head[15] = 'R';
+    put_be32(head + 16, static_cast<uint32_t>(J.w));
+    put_be32(head + 20, static_cast<uint32_t>(J.h));
+    head[24] = 8; head[25] = 2;
+    {
+        uint32_t crc = 0xFFFFFFFFu;
+        for (int i = 12; i < 29; ++i) {
+            crc ^= head[i];
+            for (int b = 0; b < 8; ++b) crc = (crc & 1u) ? (crc >> 1) ^ kPoly : crc >> 1;
+        }
+        put_be32(head + 29, crc ^ 0xFFFFFFFFu);
+    }
+    head[37] = 'I'; head[38] = 'D'; head[39] = 'A'; head[40] = 'T'; head[41] = 0x78; head[42] = 0x01;
+    for (int i = 0; i < 40; ++i) out[i] = head[i];
+    for (int i = 40; i < kDataStart; ++i) out[i] |= head[i];
     put_be32(out + 33, 2u + n_def + 4u);
-    put_be32(out + kDataStart + n_def, (B << 16) | A);
+    put_be32(out + kDataStart + n_def, (ad_b << 16) | ad_a);
 }
 
 // ---- kernel D -----------------------------------------------------------------------------------------------------
@@ -401,7 +450,7 @@ __device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b) {
     return p;
 }
 
-__global__ __launch_bounds__(256) void png_crc_kernel(PngJob J) {
+__global__ __launch_bounds__(256) void png_crc_kernel(PngBatch B) {
     // slice-by-4 tables: s_tab[j][v] = CRC of byte v followed by j zero bytes
     __shared__ uint32_t s_tab[4][256];
     {
@@ -415,11 +464,13 @@ __global__ __launch_bounds__(256) void png_crc_kernel(PngJob J) {
         s_tab[j][threadIdx.x] = (c >> 8) ^ s_tab[0][c & 255u];
         __syncthreads();
     }
+    const int im = find_image(B.crc_prefix, B.n, blockIdx.x);
+    const PngJob J = B.img[im];
     if (J.meta[4]) return;
     // The IDAT chunk's CRC covers its type and data: file bytes [37, end).  Chunks are cut at multiples of kCrcChunk of
     // the FILE offset, so every chunk but the first starts on a word.
     const uint64_t end = 37ull + 4ull + 2ull + J.meta[1] + 4ull;
-    const uint64_t c0 = (static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x) * kCrcChunk;
+    const uint64_t c0 = (static_cast<uint64_t>(blockIdx.x - B.crc_prefix[im]) * 256 + threadIdx.x) * kCrcChunk;
     if (c0 >= end) return;
     uint64_t i = c0 < 37 ? 37 : c0;
     const uint64_t hi = min(end, c0 + kCrcChunk);
@@ -436,11 +487,12 @@ __global__ __launch_bounds__(256) void png_crc_kernel(PngJob J) {
     uint64_t behind = end - hi;
     uint32_t xp = 1u << 31;
     for (int kbit = 3; behind; behind >>= 1, ++kbit)
-        if (behind & 1) xp = multmodp(J.x2n[kbit & 31], xp);
+        if (behind & 1) xp = multmodp(B.x2n[kbit & 31], xp);
     atomicXor(&J.meta[3], multmodp(xp, crc));
 }
 
-__global__ void png_crc_final_kernel(PngJob J) {
+__global__ void png_crc_final_kernel(PngBatch B) {
+    const PngJob J = B.img[blockIdx.x];
     if (threadIdx.x != 0 || J.meta[4]) return;
     uint8_t* out = reinterpret_cast<uint8_t*>(J.out);
     const uint32_t n_def = J.meta[1];
@@ -465,28 +517,30 @@ uint32_t host_multmodp(uint32_t a, uint32_t b) {
     return p;
 }
 
-uint32_t host_crc32(const uint8_t* p, size_t n) {
-    uint32_t crc = 0xFFFFFFFFu;
-    for (size_t i = 0; i < n; ++i) {
-        crc ^= p[i];
-        for (int k = 0; k < 8; ++k) crc = (crc & 1u) ? (crc >> 1) ^ kPoly : crc >> 1;
-    }
-    return crc ^ 0xFFFFFFFFu;
+template <typename T>
+bool grow(T** buf, size_t* cap, size_t need) {  // device buffer of at least `need` elements (contents are scratch)
+    if (need <= *cap) return true;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; *cap = 0;
+    if (hipMalloc(reinterpret_cast<void**>(buf), need * sizeof(T)) != hipSuccess) return false;
+    *cap = need;
+    return true;
 }
 
 }  // namespace
 
 struct ccd_png {
     int device = 0;
-    size_t scan_cap = 0, rows_cap = 0;
+    size_t scan_cap = 0, codes_cap = 0, bits_cap = 0, adler_cap = 0, jobs_cap = 0, meta_cap = 0;
     uint8_t* d_scan = nullptr;
-    uint32_t* d_codes = nullptr;     // [rows_cap][257] (a block holds at least one row)
-    uint32_t* d_blk_bits = nullptr;  // [rows_cap]
-    uint32_t* d_row_adler = nullptr; // [rows_cap][2]
-    uint32_t* d_meta = nullptr;      // [8]
+    uint32_t* d_codes = nullptr;     // [blocks][257]
+    uint32_t* d_blk_bits = nullptr;  // [blocks]
+    uint32_t* d_row_adler = nullptr; // [rows][2]
+    uint32_t* d_meta = nullptr;      // [pictures][8]
     uint32_t* h_meta = nullptr;      // pinned copy of d_meta
+    PngJob* d_jobs = nullptr;
     uint32_t x2n[32];
-    bool pending = false;
+    int pending = 0;                 // pictures of the pack in flight
 };
 
 extern "C" {
@@ -505,12 +559,6 @@ int ccd_png_create(int device, ccd_png** out) {
     ccd_png* p = new (std::nothrow) ccd_png();
     if (!p) return CCD_ERR_NOMEM;
     p->device = device;
-    if (hipMalloc(&p->d_meta, 8 * sizeof(uint32_t)) != hipSuccess ||
-        hipHostMalloc(&p->h_meta, 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
-        if (p->d_meta) (void)hipFree(p->d_meta);
-        delete p;
-        return CCD_ERR_NOMEM;
-    }
     p->x2n[0] = 1u << 30;
     for (int k = 1; k < 32; ++k) p->x2n[k] = host_multmodp(p->x2n[k - 1], p->x2n[k - 1]);
     *out = p;
@@ -525,83 +573,117 @@ void ccd_png_destroy(ccd_png* p) {
     if (p->d_blk_bits) (void)hipFree(p->d_blk_bits);
     if (p->d_row_adler) (void)hipFree(p->d_row_adler);
     if (p->d_meta) (void)hipFree(p->d_meta);
+    if (p->d_jobs) (void)hipFree(p->d_jobs);
     if (p->h_meta) (void)hipHostFree(p->h_meta);
     delete p;
 }
 
-int ccd_png_pack(ccd_png* p, const uint8_t* r, const uint8_t* g, const uint8_t* b, int h, int w, uint8_t* out, size_t cap,
-                 void* stream) {
-    if (!p || !r || !g || !b || !out || h <= 0 || w <= 0 || h > kMaxDim || w > kMaxDim) return CCD_ERR_ARG;
-    if (reinterpret_cast<uintptr_t>(out) & 3u) return CCD_ERR_ARG;
-    if (cap < ccd_png_bound(h, w)) return CCD_ERR_ARG;
+int ccd_png_pack_batch(ccd_png* p, const ccd_png_item* items, int n, void* stream) {
+    if (!p || !items || n <= 0) return CCD_ERR_ARG;
+    size_t scan_need = 0, blocks = 0, rows = 0;
+    for (int i = 0; i < n; ++i) {
+        const ccd_png_item& it = items[i];
+        if (!it.r || !it.g || !it.b || !it.out || it.h <= 0 || it.w <= 0 || it.h > kMaxDim || it.w > kMaxDim) return CCD_ERR_ARG;
+        if ((reinterpret_cast<uintptr_t>(it.out) & 3u) || it.cap < ccd_png_bound(it.h, it.w)) return CCD_ERR_ARG;
+        const int rpb = rows_per_block(it.w);
+        scan_need += (static_cast<size_t>(it.h) * (3 * static_cast<size_t>(it.w) + 1) + 15) & ~static_cast<size_t>(15);
+        blocks += (it.h + rpb - 1) / rpb;
+        rows += it.h;
+    }
     if (hipSetDevice(p->device) != hipSuccess) return CCD_ERR_HIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t N = 3 * static_cast<size_t>(w) + 1;
-    const size_t scan_bytes = static_cast<size_t>(h) * N;
-    if (scan_bytes > p->scan_cap || static_cast<size_t>(h) > p->rows_cap) {
-        // the previous pack may still read the old workspace
-        if (hipStreamSynchronize(st) != hipSuccess) return CCD_ERR_HIP;
-        if (scan_bytes > p->scan_cap) {
-            if (p->d_scan) (void)hipFree(p->d_scan);
-            p->d_scan = nullptr; p->scan_cap = 0;
-            if (hipMalloc(&p->d_scan, scan_bytes) != hipSuccess) return CCD_ERR_NOMEM;
-            p->scan_cap = scan_bytes;
+    if (scan_need > p->scan_cap || blocks * 257 > p->codes_cap || blocks > p->bits_cap || rows * 2 > p->adler_cap ||
+        static_cast<size_t>(n) > p->jobs_cap || static_cast<size_t>(n) * 8 > p->meta_cap) {
+        if (hipStreamSynchronize(st) != hipSuccess) return CCD_ERR_HIP;  // the previous pack may still use the old workspace
+        if (static_cast<size_t>(n) * 8 > p->meta_cap) {
+            if (p->h_meta) (void)hipHostFree(p->h_meta);
+            p->h_meta = nullptr;
+            if (hipHostMalloc(reinterpret_cast<void**>(&p->h_meta), static_cast<size_t>(n) * 8 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+                return CCD_ERR_NOMEM;
         }
-        if (static_cast<size_t>(h) > p->rows_cap) {
-            if (p->d_codes) (void)hipFree(p->d_codes);
-            if (p->d_blk_bits) (void)hipFree(p->d_blk_bits);
-            if (p->d_row_adler) (void)hipFree(p->d_row_adler);
-            p->d_codes = p->d_blk_bits = p->d_row_adler = nullptr; p->rows_cap = 0;
-            if (hipMalloc(&p->d_codes, static_cast<size_t>(h) * 257 * 4) != hipSuccess ||
-                hipMalloc(&p->d_blk_bits, static_cast<size_t>(h) * 4) != hipSuccess ||
-                hipMalloc(&p->d_row_adler, static_cast<size_t>(h) * 8) != hipSuccess) return CCD_ERR_NOMEM;
-            p->rows_cap = h;
+        if (!grow(&p->d_scan, &p->scan_cap, scan_need) || !grow(&p->d_codes, &p->codes_cap, blocks * 257) ||
+            !grow(&p->d_blk_bits, &p->bits_cap, blocks) || !grow(&p->d_row_adler, &p->adler_cap, rows * 2) ||
+            !grow(&p->d_jobs, &p->jobs_cap, static_cast<size_t>(n)) || !grow(&p->d_meta, &p->meta_cap, static_cast<size_t>(n) * 8))
+            return CCD_ERR_NOMEM;
+    }
+    // job table (pageable source: the runtime stages it before the call returns)
+    PngJob* jobs = new (std::nothrow) PngJob[n];
+    if (!jobs) return CCD_ERR_NOMEM;
+    size_t scan_off = 0, blk_off = 0, row_off = 0;
+    for (int i = 0; i < n; ++i) {
+        const ccd_png_item& it = items[i];
+        PngJob& J = jobs[i];
+        std::memset(&J, 0, sizeof(J));
+        J.plane[0] = it.r; J.plane[1] = it.g; J.plane[2] = it.b;
+        J.out = reinterpret_cast<uint32_t*>(it.out);
+        J.cap_bits = static_cast<uint64_t>(it.cap) * 8;
+        J.h = it.h; J.w = it.w; J.rows = rows_per_block(it.w); J.nblk = (it.h + J.rows - 1) / J.rows;
+        J.scan = p->d_scan + scan_off;
+        J.codes = p->d_codes + blk_off * 257;
+        J.blk_bits = p->d_blk_bits + blk_off;
+        J.row_adler = p->d_row_adler + row_off * 2;
+        J.meta = p->d_meta + static_cast<size_t>(i) * 8;
+        const size_t bound = ccd_png_bound(it.h, it.w);
+        J.zero_words = static_cast<uint32_t>(std::min(it.cap & ~static_cast<size_t>(3), (bound + 3) & ~static_cast<size_t>(3)) / 4);
+        scan_off += (static_cast<size_t>(it.h) * (3 * static_cast<size_t>(it.w) + 1) + 15) & ~static_cast<size_t>(15);
+        blk_off += J.nblk;
+        row_off += it.h;
+    }
+    hipError_t e = hipMemcpyAsync(p->d_jobs, jobs, static_cast<size_t>(n) * sizeof(PngJob), hipMemcpyHostToDevice, st);
+    int rc = e == hipSuccess ? CCD_OK : CCD_ERR_HIP;
+    for (int first = 0; first < n && rc == CCD_OK; first += kMaxBatch) {
+        const int cnt = std::min(kMaxBatch, n - first);
+        PngBatch B;
+        std::memset(&B, 0, sizeof(B));
+        B.img = p->d_jobs + first;
+        B.n = cnt;
+        std::memcpy(B.x2n, p->x2n, sizeof(B.x2n));
+        for (int i = 0; i < cnt; ++i) {
+            const PngJob& J = jobs[first + i];
+            B.blk_prefix[i + 1] = B.blk_prefix[i] + static_cast<uint32_t>(J.nblk);
+            const size_t chunks = ccd_png_bound(J.h, J.w) / kCrcChunk + 1;
+            B.crc_prefix[i + 1] = B.crc_prefix[i] + static_cast<uint32_t>((chunks + 255) / 256);
         }
+        hipLaunchKernelGGL(png_filter_huff_kernel, dim3(B.blk_prefix[cnt]), dim3(kThreadsA), 0, st, B);
+        hipLaunchKernelGGL(png_emit_kernel, dim3(B.blk_prefix[cnt]), dim3(kThreadsB), 0, st, B);
+        hipLaunchKernelGGL(png_trailer_kernel, dim3(cnt), dim3(256), 0, st, B);
+        hipLaunchKernelGGL(png_crc_kernel, dim3(B.crc_prefix[cnt]), dim3(256), 0, st, B);
+        hipLaunchKernelGGL(png_crc_final_kernel, dim3(cnt), dim3(64), 0, st, B);
+        if (hipGetLastError() != hipSuccess) rc = CCD_ERR_HIP;
     }
-    PngJob J;
-    std::memset(&J, 0, sizeof(J));
-    J.plane[0] = r; J.plane[1] = g; J.plane[2] = b;
-    J.h = h; J.w = w; J.rows = rows_per_block(w); J.nblk = (h + J.rows - 1) / J.rows;
-    J.scan = p->d_scan; J.codes = p->d_codes; J.blk_bits = p->d_blk_bits; J.row_adler = p->d_row_adler; J.meta = p->d_meta;
-    J.out = reinterpret_cast<uint32_t*>(out);
-    J.cap_bits = static_cast<uint64_t>(cap) * 8;
-    std::memcpy(J.x2n, p->x2n, sizeof(J.x2n));
-    {   // signature, IHDR (8-bit RGB, deflate, adaptive filtering, no interlace), IDAT type, zlib header (32 KB window, check bits)
-        uint8_t* q = J.head;
-        const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n'};
-        std::memcpy(q, sig, 8);
-        uint8_t ihdr[17] = {'I', 'H', 'D', 'R', 0, 0, 0, 0, 0, 0, 0, 0, 8, 2, 0, 0, 0};
-        for (int i = 0; i < 4; ++i) { ihdr[4 + i] = static_cast<uint8_t>(static_cast<uint32_t>(w) >> (24 - 8 * i)); ihdr[8 + i] = static_cast<uint8_t>(static_cast<uint32_t>(h) >> (24 - 8 * i)); }
-        q[8] = 0; q[9] = 0; q[10] = 0; q[11] = 13;
-        std::memcpy(q + 12, ihdr, 17);
-        const uint32_t c = host_crc32(ihdr, 17);
-        for (int i = 0; i < 4; ++i) q[29 + i] = static_cast<uint8_t>(c >> (24 - 8 * i));
-        q[37] = 'I'; q[38] = 'D'; q[39] = 'A'; q[40] = 'T'; q[41] = 0x78; q[42] = 0x01;
-    }
-    const size_t bound = ccd_png_bound(h, w);
-    // the bit packer merges into zeroed words
-    const size_t zero_bytes = std::min(cap & ~static_cast<size_t>(3), (bound + 3) & ~static_cast<size_t>(3));
-    if (hipMemsetAsync(out, 0, zero_bytes, st) != hipSuccess) return CCD_ERR_HIP;
-    if (hipMemsetAsync(p->d_meta, 0, 8 * sizeof(uint32_t), st) != hipSuccess) return CCD_ERR_HIP;
-    hipLaunchKernelGGL(png_filter_huff_kernel, dim3(J.nblk), dim3(kThreadsA), 0, st, J);
-    hipLaunchKernelGGL(png_emit_kernel, dim3(J.nblk), dim3(kThreadsB), 0, st, J);
-    hipLaunchKernelGGL(png_trailer_kernel, dim3(1), dim3(256), 0, st, J);
-    const unsigned crc_blocks = static_cast<unsigned>((bound / kCrcChunk + 256) / 256);
-    hipLaunchKernelGGL(png_crc_kernel, dim3(crc_blocks), dim3(256), 0, st, J);
-    hipLaunchKernelGGL(png_crc_final_kernel, dim3(1), dim3(64), 0, st, J);
-    if (hipGetLastError() != hipSuccess) return CCD_ERR_HIP;
-    if (hipMemcpyAsync(p->h_meta, p->d_meta, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess) return CCD_ERR_HIP;
-    p->pending = true;
+    delete[] jobs;
+    if (rc != CCD_OK) return rc;
+    if (hipMemcpyAsync(p->h_meta, p->d_meta, static_cast<size_t>(n) * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess)
+        return CCD_ERR_HIP;
+    p->pending = n;
     return CCD_OK;
 }
 
-int64_t ccd_png_finish(ccd_png* p, void* stream) {
-    if (!p || !p->pending) return CCD_ERR_ARG;
+int ccd_png_finish_batch(ccd_png* p, void* stream, int64_t* sizes, int n) {
+    if (!p || !sizes || p->pending <= 0 || n != p->pending) return CCD_ERR_ARG;
     if (hipSetDevice(p->device) != hipSuccess) return CCD_ERR_HIP;
     if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return CCD_ERR_HIP;
-    p->pending = false;
-    if (p->h_meta[4]) return CCD_ERR_NOMEM;  // the file did not fit `cap` (cannot happen with ccd_png_bound())
-    return static_cast<int64_t>(p->h_meta[2]);
+    p->pending = 0;
+    int rc = CCD_OK;
+    for (int i = 0; i < n; ++i) {
+        const uint32_t* m = p->h_meta + static_cast<size_t>(i) * 8;
+        if (m[4]) { sizes[i] = CCD_ERR_NOMEM; rc = CCD_ERR_NOMEM; }  // the file did not fit `cap` (cannot happen with ccd_png_bound())
+        else sizes[i] = static_cast<int64_t>(m[2]);
+    }
+    return rc;
+}
+
+int ccd_png_pack(ccd_png* p, const uint8_t* r, const uint8_t* g, const uint8_t* b, int h, int w, uint8_t* out, size_t cap,
+                 void* stream) {
+    ccd_png_item it;
+    it.r = r; it.g = g; it.b = b; it.h = h; it.w = w; it.out = out; it.cap = cap;
+    return ccd_png_pack_batch(p, &it, 1, stream);
+}
+
+int64_t ccd_png_finish(ccd_png* p, void* stream) {
+    int64_t size = 0;
+    const int rc = ccd_png_finish_batch(p, stream, &size, 1);
+    return rc < 0 ? rc : size;
 }
 
 }  // extern "C"

@@ -7,7 +7,7 @@ import ctypes as C
 
 import torch
 
-from .._lib import check, lib
+from .._lib import PngItem, check, lib
 
 
 class PngPacker:
@@ -43,6 +43,36 @@ class PngPacker:
 
     def finish(self, stream: int = 0) -> int:
         return check(lib().ccd_png_finish(self._h, C.c_void_p(stream or None)), "ccd_png_finish")
+
+    def pack_batch_async(self, items, stream: int = 0) -> None:
+        """items: sequence of (r, g, b, h, w, out) - device addresses of the planes and a uint8 CUDA tensor per picture.
+        Every deflate block of every picture becomes a workgroup of the same five launches."""
+        arr = (PngItem * len(items))()
+        for a, (r, g, b, h, w, out) in zip(arr, items):
+            a.r, a.g, a.b, a.h, a.w, a.out, a.cap = r, g, b, int(h), int(w), out.data_ptr(), out.numel()
+        self._n = len(items)
+        check(lib().ccd_png_pack_batch(self._h, arr, len(items), C.c_void_p(stream or None)), "ccd_png_pack_batch")
+
+    def finish_batch(self, stream: int = 0):
+        sizes = (C.c_int64 * self._n)()
+        check(lib().ccd_png_finish_batch(self._h, C.c_void_p(stream or None), sizes, self._n), "ccd_png_finish_batch")
+        return list(sizes)
+
+    def pack_many(self, pictures) -> list:
+        """pictures: list of [3, H, W] uint8 CUDA tensors -> list of PNG byte strings (one set of launches)."""
+        pictures = [p.contiguous() for p in pictures]
+        for p in pictures:
+            if p.dtype != torch.uint8 or p.dim() != 3 or p.shape[0] != 3 or not p.is_cuda:
+                raise ValueError("PNG output needs [3, H, W] uint8 tensors on the GPU")
+        outs = [torch.empty(self.bound(p.shape[1], p.shape[2]) + 4, dtype=torch.uint8, device=p.device) for p in pictures]
+        stream = torch.cuda.current_stream(pictures[0].device).cuda_stream
+        items = []
+        for p, o in zip(pictures, outs):
+            _, h, w = p.shape
+            items.append((p.data_ptr(), p.data_ptr() + h * w, p.data_ptr() + 2 * h * w, h, w, o))
+        self.pack_batch_async(items, stream)
+        sizes = self.finish_batch(stream)
+        return [o[:n].cpu().numpy().tobytes() for o, n in zip(outs, sizes)]
 
     def pack(self, planes: torch.Tensor) -> bytes:
         """planes: [3, H, W] uint8 CUDA tensor (r, g, b) -> the bytes of a .png."""

@@ -215,15 +215,25 @@ void ccd_free(void* p);
  * array to PIL / zlib on the host).  r, g, b: device pointers to [h][w] uint8 planes (ccd_batch_plane); out: device
  * buffer, 4-byte aligned, of at least ccd_png_bound(h, w) bytes.  ccd_png_pack only enqueues work on `stream`;
  * ccd_png_finish synchronises the stream and returns the size of the file in `out` (or a negative code).  One pack
- * may be in flight per handle.  The file holds the filtered scanlines in literal-only dynamic-Huffman deflate blocks:
+ * (single or batch) may be in flight per handle.  The file holds the filtered scanlines in literal-only dynamic-Huffman deflate blocks:
  * any PNG reader decodes exactly the input planes; the bytes differ from PIL's (PNG bytes are not normative). */
 typedef struct ccd_png ccd_png;
+typedef struct {
+    const uint8_t *r, *g, *b; /* device planes [h][w] */
+    int32_t h, w;
+    uint8_t* out;             /* device buffer, 4-byte aligned */
+    size_t cap;               /* >= ccd_png_bound(h, w) */
+} ccd_png_item;
 size_t ccd_png_bound(int h, int w);  /* 0 if a side is outside 1..16383 */
 int ccd_png_create(int device, ccd_png** out);
 void ccd_png_destroy(ccd_png* p);
 int ccd_png_pack(ccd_png* p, const uint8_t* r, const uint8_t* g, const uint8_t* b, int h, int w, uint8_t* out,
                  size_t cap, void* stream);
 int64_t ccd_png_finish(ccd_png* p, void* stream);
+/* Many pictures in one set of launches (every deflate block of every picture is a workgroup of the same kernels);
+ * ccd_png_finish_batch synchronises the stream and fills sizes[n] (n = the count given to the pack). */
+int ccd_png_pack_batch(ccd_png* p, const ccd_png_item* items, int n, void* stream);
+int ccd_png_finish_batch(ccd_png* p, void* stream, int64_t* sizes, int n);
 
 /* Leaky-quantised-Laplace boundaries computed ON THE GPU for a list of (mu_idx, scale_idx, s):
  * left[i], right[i] as the entropy kernel sees them (exhaustive parity tests of the f64 CDF). */

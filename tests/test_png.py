@@ -130,6 +130,25 @@ def test_device_png_of_the_kodak_fixture(packer):
 
 
 @pytest.mark.gpu
+def test_device_png_batch_of_mixed_sizes(packer):
+    """One set of launches for many pictures: same bytes as one by one (= the oracle's)."""
+    import torch
+
+    from oracle import png_pack
+
+    pics = [_pictures(h, w)[kind] for (h, w), kind in zip(SIZES + [(300, 200), (64, 512)],
+                                                         ["random", "smooth", "photo", "zeros", "skewed"] * 2)]
+    got = packer.pack_many([torch.from_numpy(p).cuda() for p in pics])
+    for p, png in zip(pics, got):
+        assert np.array_equal(_read_png(png), p)
+        assert png == png_pack.pack_rgb8(p)
+    # more pictures than one launch set takes (64)
+    many = [_pictures(9 + i % 5, 11 + i % 7, seed=i)["photo"] for i in range(70)]
+    for p, png in zip(many, packer.pack_many([torch.from_numpy(p).cuda() for p in many])):
+        assert np.array_equal(_read_png(png), p)
+
+
+@pytest.mark.gpu
 def test_device_png_full_size_round_trips(packer):
     """BASELINE sizes (4K, 2K portrait) through the size-independent property: an independent reader gets the pixels."""
     import torch

@@ -49,6 +49,22 @@ def main():
         print(f"{h}x{w}: device pack {gpu_ms:.3f} ms ({raw / gpu_ms / 1e6:.1f} GB/s of pixels), file {n} B "
               f"(PIL {len(b.getvalue())} B), D2H of the file {d2h_ms:.2f} ms, PIL save on the host {pil_ms:.1f} ms")
         assert bytes(host.numpy().tobytes()[:8]) == b"\x89PNG\r\n\x1a\n"
+    # 24 Kodak-sized pictures in one set of launches
+    pics = [torch.from_numpy(photo(512, 768, seed=i)).cuda() for i in range(24)]
+    outs = [torch.empty(p.bound(512, 768) + 4, dtype=torch.uint8, device="cuda") for _ in pics]
+    items = [(q.data_ptr(), q.data_ptr() + 512 * 768, q.data_ptr() + 2 * 512 * 768, 512, 768, o) for q, o in zip(pics, outs)]
+    st = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        p.pack_batch_async(items, st)
+        p.finish_batch(st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        p.pack_batch_async(items, st)
+    e1.record()
+    sizes = p.finish_batch(st)
+    ms = e0.elapsed_time(e1) / 20
+    print(f"24 x 512x768 in one batch: {ms:.3f} ms ({24 * 3 * 512 * 768 / ms / 1e6:.1f} GB/s of pixels), {sum(sizes)} B")
 
 
 if __name__ == "__main__":
