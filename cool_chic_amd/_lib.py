@@ -118,6 +118,7 @@ SIGNATURES = {
     "ccd_write_frame_header": (C.c_int, [C.POINTER(FrameHeader), C.c_void_p, C.c_size_t]),
     "ccd_write_video_header": (C.c_int, [C.POINTER(VideoHeader), C.c_void_p, C.c_size_t]),
     "ccd_free": (None, [C.c_void_p]),
+    "ccd_compute_rate": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "ccd_png_bound": (C.c_size_t, [C.c_int, C.c_int]),
     "ccd_png_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "ccd_png_destroy": (None, [C.c_void_p]),

@@ -99,7 +99,7 @@ __device__ __forceinline__ int filt_one(int f, int x, int a, int b, int c) {
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __brev(v) >> (32 - n); }
 
 // ---- kernel A -----------------------------------------------------------------------------------------------------
-constexpr int kThreadsA = 256;
+constexpr int kThreadsA = 256;   // 1024 threads: single pictures 10-20 % faster, batches and 4K 2x slower (occupancy; measured)
 
 __global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngBatch B) {
     __shared__ uint32_t s_hist[257];
@@ -109,8 +109,9 @@ __global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngBatch B) 
     __shared__ unsigned long long s_red[kThreadsA / 64][8];
     __shared__ uint32_t s_m, s_sum;
     __shared__ uint32_t s_num[kMaxBits + 1], s_first[kMaxBits + 1], s_base[kMaxBits + 1];
+    __shared__ uint32_t s_par[256], s_dep[256], s_cnt[258];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int im = find_image(B.blk_prefix, B.n, blockIdx.x);
+    const int im = __builtin_amdgcn_readfirstlane(find_image(B.blk_prefix, B.n, blockIdx.x));
     const PngJob J = B.img[im];
     const int k = static_cast<int>(blockIdx.x - B.blk_prefix[im]);
     const int w = J.w, n = 3 * w, N = n + 1;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngBatch B) 
         if (k == 0 && tid < 8) J.meta[tid] = 0;
     }
     const int y_lo = k * J.rows, y_hi = min(J.h, y_lo + J.rows);
-    for (int i = tid; i < 257; i += kThreadsA) { s_hist[i] = 0; s_len[i] = 0; }
+    for (int i = tid; i < 258; i += kThreadsA) { s_cnt[i] = 0; if (i < 257) { s_hist[i] = 0; s_len[i] = 0; } }
     if (tid == 0) { s_m = 0; s_sum = 0; }
     if (tid <= kMaxBits) s_num[tid] = 0;
     __syncthreads();
@@ -219,12 +220,12 @@ __global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngBatch B) 
             __syncthreads();
         }
     }
-    // ---- optimal code lengths of the sorted symbols (one lane: the two-queue merge is sequential; at most 257 symbols)
+    // ---- Huffman tree over the sorted symbols (one lane: the two-queue merge is sequential; at most 257 symbols).
+    // Moffat-Katajainen phase 1, in place on the ascending counts: afterwards s_A[i] is the parent of internal node i.
     const int m = static_cast<int>(s_m);
     if (tid == 0) {
         uint32_t* A = s_A;
         for (int i = 0; i < m; ++i) A[i] = s_key[i] >> 9;
-        // Moffat-Katajainen: parent pointers, internal depths, leaf depths - in place on the ascending counts
         A[0] += A[1];
         int root = 0, leaf = 2;
         for (int nxt = 1; nxt < m - 1; ++nxt) {
@@ -233,21 +234,34 @@ __global__ __launch_bounds__(kThreadsA) void png_filter_huff_kernel(PngBatch B) 
             if (leaf >= m || (root < nxt && A[root] < A[leaf])) { A[nxt] += A[root]; A[root++] = nxt; }
             else A[nxt] += A[leaf++];
         }
-        A[m - 2] = 0;
-        for (int nxt = m - 3; nxt >= 0; --nxt) A[nxt] = A[A[nxt]] + 1;
-        {
-            int avbl = 1, used = 0, dpth = 0, nxt = m - 1;
-            root = m - 2;
-            while (avbl > 0) {
-                while (root >= 0 && static_cast<int>(A[root]) == dpth) { ++used; --root; }
-                while (avbl > used) { A[nxt--] = dpth; --avbl; }
-                avbl = 2 * used; ++dpth; used = 0;
-            }
-        }
     }
     __syncthreads();
-    // ---- limit to 15 bits: codes per length (longer ones folded into the limit), then the Kraft excess is worked off
-    for (int i = tid; i < m; i += kThreadsA) atomicAdd(&s_num[min(static_cast<int>(s_A[i]), kMaxBits)], 1u);
+    // ---- depth of the internal nodes 0 .. m-2 (node m-2 is the root) by pointer jumping, one node per thread
+    const int ni = m - 1;
+    uint32_t par = 0, dep = 0;
+    if (tid < ni) {
+        par = tid == ni - 1 ? static_cast<uint32_t>(tid) : s_A[tid];
+        dep = tid == ni - 1 ? 0u : 1u;
+        s_par[tid] = par; s_dep[tid] = dep;
+    }
+    __syncthreads();
+    for (int r = 0; r < 9; ++r) {  // 2^9 > 256 levels
+        uint32_t pd = 0, pp = 0;
+        if (tid < ni) { pd = s_dep[par]; pp = s_par[par]; }
+        __syncthreads();
+        if (tid < ni) { dep += pd; par = pp; s_dep[tid] = dep; s_par[tid] = par; }
+        __syncthreads();
+    }
+    // ---- leaves per depth: the two children of every internal node at depth d - 1 are the internal nodes and the leaves at
+    // depth d.  Sorted by count the leaves have non-increasing depths, so the counts per length are all that is needed.
+    // Limit to 15 bits: longer codes are folded into the limit, then the Kraft excess is worked off.
+    if (tid < ni) atomicAdd(&s_cnt[dep], 1u);
+    __syncthreads();
+    if (tid < 256) {
+        const int d = tid + 1;  // 1 .. 256
+        const uint32_t leaves = 2u * s_cnt[d - 1] - s_cnt[d];
+        if (leaves) atomicAdd(&s_num[min(d, kMaxBits)], leaves);
+    }
     __syncthreads();
     if (tid == 0) {
         uint32_t total = 0;
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(kThreadsB) void png_emit_kernel(PngBatch B) {
     __shared__ unsigned long long s_part[kThreadsB / 64];
     __shared__ uint32_t s_scan[kThreadsB];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int im = find_image(B.blk_prefix, B.n, blockIdx.x);
+    const int im = __builtin_amdgcn_readfirstlane(find_image(B.blk_prefix, B.n, blockIdx.x));
     const PngJob J = B.img[im];
     const int k = static_cast<int>(blockIdx.x - B.blk_prefix[im]);
     const int N = 3 * J.w + 1;
@@ -464,31 +478,36 @@ __global__ __launch_bounds__(256) void png_crc_kernel(PngBatch B) {
         s_tab[j][threadIdx.x] = (c >> 8) ^ s_tab[0][c & 255u];
         __syncthreads();
     }
-    const int im = find_image(B.crc_prefix, B.n, blockIdx.x);
+    const int im = __builtin_amdgcn_readfirstlane(find_image(B.crc_prefix, B.n, blockIdx.x));
     const PngJob J = B.img[im];
     if (J.meta[4]) return;
     // The IDAT chunk's CRC covers its type and data: file bytes [37, end).  Chunks are cut at multiples of kCrcChunk of
     // the FILE offset, so every chunk but the first starts on a word.
     const uint64_t end = 37ull + 4ull + 2ull + J.meta[1] + 4ull;
     const uint64_t c0 = (static_cast<uint64_t>(blockIdx.x - B.crc_prefix[im]) * 256 + threadIdx.x) * kCrcChunk;
-    if (c0 >= end) return;
-    uint64_t i = c0 < 37 ? 37 : c0;
-    const uint64_t hi = min(end, c0 + kCrcChunk);
-    const uint8_t* p = reinterpret_cast<const uint8_t*>(J.out);
-    uint32_t crc = 0xFFFFFFFFu;
-    for (; i < hi && (i & 3); ++i) crc = s_tab[0][(crc ^ p[i]) & 255u] ^ (crc >> 8);
-    for (; i + 4 <= hi; i += 4) {
-        crc ^= J.out[i >> 2];
-        crc = s_tab[3][crc & 255u] ^ s_tab[2][(crc >> 8) & 255u] ^ s_tab[1][(crc >> 16) & 255u] ^ s_tab[0][crc >> 24];
+    uint32_t part = 0;  // this chunk's term of the file CRC
+    if (c0 < end) {
+        uint64_t i = c0 < 37 ? 37 : c0;
+        const uint64_t hi = min(end, c0 + kCrcChunk);
+        const uint8_t* p = reinterpret_cast<const uint8_t*>(J.out);
+        uint32_t crc = 0xFFFFFFFFu;
+        for (; i < hi && (i & 3); ++i) crc = s_tab[0][(crc ^ p[i]) & 255u] ^ (crc >> 8);
+        for (; i + 4 <= hi; i += 4) {
+            crc ^= J.out[i >> 2];
+            crc = s_tab[3][crc & 255u] ^ s_tab[2][(crc >> 8) & 255u] ^ s_tab[1][(crc >> 16) & 255u] ^ s_tab[0][crc >> 24];
+        }
+        for (; i < hi; ++i) crc = s_tab[0][(crc ^ p[i]) & 255u] ^ (crc >> 8);
+        crc ^= 0xFFFFFFFFu;
+        // multiply by x^(8 * bytes behind the chunk)
+        uint64_t behind = end - hi;
+        uint32_t xp = 1u << 31;
+        for (int kbit = 3; behind; behind >>= 1, ++kbit)
+            if (behind & 1) xp = multmodp(B.x2n[kbit & 31], xp);
+        part = multmodp(xp, crc);
     }
-    for (; i < hi; ++i) crc = s_tab[0][(crc ^ p[i]) & 255u] ^ (crc >> 8);
-    crc ^= 0xFFFFFFFFu;
-    // multiply by x^(8 * bytes behind the chunk)
-    uint64_t behind = end - hi;
-    uint32_t xp = 1u << 31;
-    for (int kbit = 3; behind; behind >>= 1, ++kbit)
-        if (behind & 1) xp = multmodp(B.x2n[kbit & 31], xp);
-    atomicXor(&J.meta[3], multmodp(xp, crc));
+    // one atomic per wave (tens of thousands of chunks otherwise queue up on one address)
+    for (int o = 32; o > 0; o >>= 1) part ^= __shfl_xor(part, o);
+    if ((threadIdx.x & 63) == 0 && part) atomicXor(&J.meta[3], part);
 }
 
 __global__ void png_crc_final_kernel(PngBatch B) {

@@ -235,6 +235,12 @@ int64_t ccd_png_finish(ccd_png* p, void* stream);
 int ccd_png_pack_batch(ccd_png* p, const ccd_png_item* items, int n, void* stream);
 int ccd_png_finish_batch(ccd_png* p, void* stream, int64_t* sizes, int n);
 
+/* ---- rate model (reference: coolchic/component/core/arm.py:448-485 compute_rate / _laplace_cdf, float32) ------
+ * rate[i] = -log2(max(cdf(x+0.5) - cdf(x-0.5), 2^-16)) with the continuous Laplace(mu, scale) of the reference.
+ * x, mu, scale, rate (optional), total_bits (optional, one double) are DEVICE pointers; asynchronous on `stream`. */
+int ccd_compute_rate(int device, void* stream, const float* x, const float* mu, const float* scale, int64_t n,
+                     float* rate, double* total_bits);
+
 /* Leaky-quantised-Laplace boundaries computed ON THE GPU for a list of (mu_idx, scale_idx, s):
  * left[i], right[i] as the entropy kernel sees them (exhaustive parity tests of the f64 CDF). */
 int ccd_debug_laplace_bounds(int device, const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* s,
