@@ -122,3 +122,75 @@ def decode_video(bitstream_path: str, decoded_path: Optional[str] = None, max_de
         if decoded_path is not None:
             save_frame_data_to_file(frames[display_idx], decoded_path, append=display_idx != 0)
     return all_frames
+
+
+@torch.no_grad()
+def decode_video_sharded(bitstream_path: str, device: int = 0, group=None) -> Dict[str, FrameData]:
+    """decode_video for one process per GPU (torch.distributed initialised by the caller; works unsharded without).
+
+    Frame at coding index k belongs to rank k mod world_size.  Every rank first decodes ALL cool-chics of its own
+    frames in one DecodeBatch (residue and motion networks of every owned frame in flight together - they do not
+    depend on other frames, decode.py:132-153); then the frames are reconstructed in coding order on their owner
+    and their integer planes broadcast, because later frames warp them (decode.py:156-189).  Every rank returns the
+    whole sequence, like decode_video."""
+    import torch.distributed as dist
+
+    from ..parallel import gop_owner, run_sharded_gop
+    from .intercoding import reconstruct_inter_frame
+
+    with open(bitstream_path, "rb") as f:
+        rest = f.read()
+    vh = VideoHeader()
+    rest = vh.read_header(rest)
+    n_frames = vh.get_value("n_frames")
+    initialised = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if initialised else 1
+    rank = dist.get_rank(group) if initialised else 0
+    dev = torch.device(f"cuda:{device}")
+    parsed = []
+    for _ in range(n_frames):
+        fh, ccs, rest = _split_frame(rest)
+        parsed.append((fh, ccs))
+    display = [fh.get_value("display_index") for fh, _ in parsed]
+    coding_of_display = {d: k for k, d in enumerate(display)}
+    references = [[coding_of_display[r] for r in fh.get_value("index_references")] for fh, _ in parsed]
+    specs = []
+    for fh, ccs in parsed:
+        h, w = ccs[0][0].c.img_size[0], ccs[0][0].c.img_size[1]
+        bd, fdt = fh.get_value("bitdepth"), fh.get_value("frame_data_type")
+        dt = torch.uint8 if bd == 8 else torch.uint16
+        chroma = (h // 2, w // 2) if fdt == "yuv420" else (h, w)
+        specs.append([((h, w), dt), (chroma, dt), (chroma, dt)])
+    batch = DecodeBatch(device)
+    try:
+        slots = {}
+        for k, (fh, ccs) in enumerate(parsed):
+            if gop_owner(k, world) != rank:
+                continue
+            intra = fh.get_value("frame_type") == "I"
+            bd, fdt = fh.get_value("bitdepth"), fh.get_value("frame_data_type")
+            slots[k] = [batch.add(ch.raw, nn, lat, bd if intra else 0, _FDT_INDEX[fdt] if intra else 0) for ch, nn, lat in ccs]
+        stream = torch.cuda.current_stream(device).cuda_stream
+        if slots:
+            batch.run(stream)
+            batch.wait(stream)
+
+        def to_frame_data(k, planes):
+            fh = parsed[k][0]
+            return _planes_to_frame_data(planes, fh.get_value("bitdepth"), fh.get_value("frame_data_type"))
+
+        def produce(k, refs):
+            fh = parsed[k][0]
+            if fh.get_value("frame_type") == "I":
+                return [torch.as_tensor(batch.plane_device(slots[k][0], p), device=dev).clone() for p in range(3)]
+            outs = [torch.as_tensor(batch.output_device(s), device=dev) for s in slots[k]]
+            ref_fd = [to_frame_data(r, pl) for r, pl in zip(references[k], refs)]
+            fd = reconstruct_inter_frame(fh, outs[0], outs[1], ref_fd)
+            from .intercoding import _integer_planes
+
+            return _integer_planes(fd, dev)
+
+        done = run_sharded_gop(n_frames, specs, references, produce, device=dev, group=group)
+    finally:
+        batch.close()
+    return {str(display[k]): to_frame_data(k, done[k]) for k in sorted(done, key=lambda k: display[k])}

@@ -64,3 +64,52 @@ def unshard(per_rank_items: Sequence[Sequence], n_frames: int) -> list:
         for k, it in enumerate(items):
             out[r + k * world] = it
     return out
+
+
+# ---- a GOP sharded over ranks (video) --------------------------------------------------------
+def gop_owner(coding_index: int, world_size: int) -> int:
+    """Frame at coding index k is decoded and reconstructed by rank k mod world_size."""
+    return coding_index % world_size
+
+
+def exchange_planes(planes: Optional[Sequence[torch.Tensor]], specs: Sequence, src: int, device, group=None) -> List[torch.Tensor]:
+    """The owner's decoded integer planes -> every rank (the one real exchange step of a sharded GOP: the next
+    frames in coding order use them as references).  One broadcast of one packed message, RCCL over xGMI with the
+    "nccl" backend (3.1 MB for a 1080p 4:2:0 8-bit frame); `specs` = [(shape, dtype), ...] is known to every rank
+    from the frame header, so no sizes travel.  With "gloo" the message is staged through the host."""
+    if dist.get_world_size(group) == 1:
+        return list(planes)
+    n_bytes = [int(torch.Size(s).numel()) * torch.empty(0, dtype=d).element_size() for s, d in specs]
+    staged = dist.get_backend(group) == "gloo"
+    buf_dev = torch.device("cpu") if staged else torch.device(device)
+    if dist.get_rank(group) == src:
+        buf = pack_planes([p.to(buf_dev) for p in planes])
+    else:
+        buf = torch.empty(sum(n_bytes), dtype=torch.uint8, device=buf_dev)
+    dist.broadcast(buf, src=src, group=group)
+    if dist.get_rank(group) == src:
+        return list(planes)
+    out, off = [], 0
+    for (shape, dtype), nb in zip(specs, n_bytes):
+        out.append(buf[off:off + nb].view(dtype).reshape(shape).to(device))
+        off += nb
+    return out
+
+
+def run_sharded_gop(n_frames: int, plane_specs, references, produce, device="cpu", group=None) -> dict:
+    """Coding-order schedule of a GOP whose frames are spread round-robin over the ranks.
+
+    plane_specs[k]  [(shape, dtype) x 3] of frame k (coding index), known to every rank
+    references[k]   coding indices of the frames frame k predicts from (all < k)
+    produce(k, refs) -> planes of frame k; called ONLY on gop_owner(k); refs = planes of references[k]
+    Returns {k: planes} on every rank.  The expensive part of `produce` (the cool-chic decodes) does not depend on
+    the references, so an owner runs it for all of its frames up front and `produce` only reconstructs."""
+    initialised = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if initialised else 1
+    rank = dist.get_rank(group) if initialised else 0
+    done = {}
+    for k in range(n_frames):
+        owner = gop_owner(k, world)
+        planes = produce(k, [done[r] for r in references[k]]) if rank == owner else None
+        done[k] = list(planes) if world == 1 else exchange_planes(planes, plane_specs[k], owner, device, group)
+    return done

@@ -514,3 +514,62 @@ def test_rate_model_matches_the_float32_formula(gpu):
     assert shaped.shape == (1, 1, 1024, 1024)
     with pytest.raises(ValueError):
         compute_rate(x, mu, scale)  # host tensors
+
+
+def _sharded_worker(rank, world, port, path, q):
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # one GPU on the box: both ranks use cuda:0, host-staged exchange
+    from cool_chic_amd.bitstream.decode import decode_video_sharded
+
+    frames = decode_video_sharded(path, device=0)
+    out = {}
+    for k, fd in frames.items():
+        planes = fd.integer_planes()
+        out[k] = [np.asarray(p) for p in planes]
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_video_gop_sharded_over_ranks(gpu, oracle):
+    """The I/P/B fixture decoded (a) unsharded through decode_video_sharded, (b) by two ranks that each decode the
+    cool-chics of their own frames and exchange reconstructed planes: both equal the oracle's planes."""
+    import os
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from conftest import GOLDEN
+    from cool_chic_amd.bitstream.decode import decode_video_sharded
+
+    path = os.path.join(GOLDEN, "vid5.cool")
+    bs, _, _ = load_golden("vid5")
+    want = {str(fr["display_index"]): fr["planes"] for fr in oracle.decode_video(bs)}
+    single = decode_video_sharded(path, device=0)
+    assert sorted(single) == sorted(want)
+    for k, fd in single.items():
+        for p, w in zip(fd.integer_planes(), want[k]):
+            assert np.array_equal(np.asarray(p).astype(np.uint16), w), k
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for rank, out in results:
+        assert sorted(out) == sorted(want)
+        for k in out:
+            for p, w in zip(out[k], want[k]):
+                assert np.array_equal(p.astype(np.uint16), w), (rank, k)

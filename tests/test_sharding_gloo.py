@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from cool_chic_amd.parallel import EqualSizeGather, gather_bytes, pack_planes, shard_indices, unshard
+from cool_chic_amd.parallel import EqualSizeGather, gather_bytes, gop_owner, pack_planes, run_sharded_gop, shard_indices, unshard
 
 
 def _free_port():
@@ -72,3 +72,63 @@ def test_round_robin_and_gather_world2():
         p.join(timeout=120)
         assert p.exitcode == 0
     assert ok
+
+
+# ---- a GOP sharded over ranks: coding-order schedule + broadcast of reference planes --------------------------------
+# hierarchical GOP like the reference's (I0 P4 B2 B1 B3 I8 B6 ...): references by coding index
+_GOP_REFS = [[], [0], [0, 1], [0, 2], [2, 1], [], [1, 5], [1, 6], [6, 5]]
+
+
+def _gop_specs(k):
+    h, w = 6 + (k % 3), 10
+    dt = torch.uint8 if k % 2 == 0 else torch.uint16
+    return [((h, w), dt), ((h // 2, w // 2), dt), ((h // 2, w // 2), dt)]
+
+
+def _gop_produce(k, refs):
+    """Fake reconstruction: every sample depends on k and on the content of every reference plane."""
+    mix = sum(int(p.to(torch.int64).sum()) * (i + 1) for i, r in enumerate(refs) for p in r)
+    out = []
+    for j, (shape, dt) in enumerate(_gop_specs(k)):
+        base = torch.arange(shape[0] * shape[1], dtype=torch.int64).reshape(shape)
+        out.append(((base * (k + 3) + 7 * j + mix) % (256 if dt == torch.uint8 else 1024)).to(torch.int32).to(dt))
+    return out
+
+
+def _gop_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def produce(k, refs):
+        calls.append(k)
+        return _gop_produce(k, refs)
+
+    n = len(_GOP_REFS)
+    done = run_sharded_gop(n, [_gop_specs(k) for k in range(n)], _GOP_REFS, produce, device="cpu")
+    q.put((rank, calls, {k: [p.to(torch.int32).numpy() for p in v] for k, v in done.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_gop_schedule_world2():
+    n = len(_GOP_REFS)
+    serial = run_sharded_gop(n, [_gop_specs(k) for k in range(n)], _GOP_REFS, _gop_produce)  # no process group: one rank
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gop_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, calls, done in results:
+        assert calls == [k for k in range(n) if gop_owner(k, 2) == rank]  # only its own frames, in coding order
+        assert sorted(done) == list(range(n))
+        for k in range(n):
+            for got, want, (shape, dt) in zip(done[k], serial[k], _gop_specs(k)):
+                assert got.shape == tuple(shape)
+                assert np.array_equal(got, want.to(torch.int32).numpy()), (rank, k)
