@@ -768,8 +768,8 @@ int ccd_inter_reconstruct(int device, void* stream, int frame_type, int h, int w
     if ((frame_type != 1 && frame_type != 2) || !residue || !motion || !ref0_planes || !global_flow || !out_planes ||
         (frame_type == 2 && !ref1_planes) || h <= 0 || w <= 0 || bitdepth < 8 || bitdepth > 16)
         return CCD_ERR_ARG;
-    if (warp_filter_size < 6) return CCD_ERR_UNSUPPORTED;  // 2 / 4 taps = torch grid_sample bilinear / bicubic (warp.py:49-56)
-    if (warp_filter_size > 16 || (warp_filter_size & 1)) return CCD_ERR_VALUE;
+    // 2 / 4 taps = grid_sample bilinear / bicubic, 6.. = sinc (warp.py:49-56); odd or < 2 fails the reference's asserts (warp.py:41-47)
+    if (warp_filter_size < 2 || warp_filter_size > 16 || (warp_filter_size & 1)) return CCD_ERR_VALUE;
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t frame_bytes = static_cast<size_t>(3) * h * w * sizeof(float);

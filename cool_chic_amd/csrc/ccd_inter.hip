@@ -4,7 +4,8 @@
 //   bitstream/decode.py:156-189                      global shift, warp, alpha / beta blend, + residue
 //   component/intercoding/globalmotion.py:151-160    integer global translation (nearest, border clamp)
 //   component/intercoding/warp.py:226-243,294-397    sinc-windowed N-tap warp, TRAINING mode (the decoder never
-//                                                    calls .eval(): flows are NOT quantised), border clamp
+//                                                    calls .eval(): flows are NOT quantised), border clamp;
+//                                                    2 / 4 taps = F.grid_sample bilinear / bicubic (warp.py:325-343)
 //   io/format/yuv.py:303-316                         4:2:0 references -> 4:4:4 by nearest x2
 //
 // Numerics: identical formulas to oracle/cc_oracle.c section 11 (sin / cos in f64 with explicit fma, rounded to
@@ -123,6 +124,83 @@ __device__ __forceinline__ void ic_warp_pixel(const float* __restrict__ ref, int
     }
 }
 
+// ---- warp_filter_size 2 / 4: the Warper's native path = F.grid_sample(bilinear | bicubic, border, align_corners=True)
+// (warp.py:92-116, 325-343).  Same float32 operation sequence as oracle/cc_oracle.c section 11 (the canon of the
+// reference run: fused linspace, plain weight products + fma accumulation for bilinear, the mixed plain / fused
+// evaluation of the bicubic coefficients and sums).
+__device__ __forceinline__ float ic_lin_coord(int i, int n) {
+    if (n == 1) return -1.0f;
+    const float step = __fdiv_rn(2.0f, static_cast<float>(n - 1));
+    return i < n / 2 ? __fmaf_rn(step, static_cast<float>(i), -1.0f) : __fmaf_rn(-step, static_cast<float>(n - 1 - i), 1.0f);
+}
+__device__ __forceinline__ float ic_cubic_inner(float x) {
+    const float A = -0.75f;
+    const float t = __fmul_rn(__fmaf_rn(A + 2.0f, x, -(A + 3.0f)), x);
+    return __fmaf_rn(t, x, 1.0f);
+}
+__device__ __forceinline__ float ic_cubic_outer(float x) {
+    const float A = -0.75f;
+    float t = __fmul_rn(A, x);
+    t = __fsub_rn(t, 5.0f * A);
+    t = __fmul_rn(t, x);
+    t = __fadd_rn(t, 8.0f * A);
+    t = __fmul_rn(t, x);
+    return __fsub_rn(t, 4.0f * A);
+}
+__device__ __forceinline__ void ic_warp_pixel_native(const float* __restrict__ ref, int H, int W, int gx, int gy, int n_taps, float fx,
+                                                     float fy, int y, int x, float out[3]) {
+    const float sx = static_cast<float>((W - 1.0) / 2.0), sy = static_cast<float>((H - 1.0) / 2.0);
+    const float gxn = __fadd_rn(ic_lin_coord(x, W), __fdiv_rn(fx, sx)), gyn = __fadd_rn(ic_lin_coord(y, H), __fdiv_rn(fy, sy));
+    float ix = __fmul_rn(__fadd_rn(gxn, 1.0f), sx), iy = __fmul_rn(__fadd_rn(gyn, 1.0f), sy);
+    const size_t plane = static_cast<size_t>(H) * W;
+    if (n_taps == 2) {
+        ix = fminf(static_cast<float>(W - 1), fmaxf(ix, 0.0f));
+        iy = fminf(static_cast<float>(H - 1), fmaxf(iy, 0.0f));
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float w = __fsub_rn(ix, x0f), e = __fsub_rn(1.0f, w), n = __fsub_rn(iy, y0f), s = __fsub_rn(1.0f, n);
+        const float w_nw = __fmul_rn(s, e), w_ne = __fmul_rn(s, w), w_sw = __fmul_rn(n, e), w_se = __fmul_rn(n, w);
+        const int x0 = static_cast<int>(x0f), y0 = static_cast<int>(y0f);
+        const int xa = ic_clamp(ic_clamp(x0, 0, W - 1) + gx, 0, W - 1), xb = ic_clamp(ic_clamp(x0 + 1, 0, W - 1) + gx, 0, W - 1);
+        const int ya = ic_clamp(ic_clamp(y0, 0, H - 1) + gy, 0, H - 1), yb = ic_clamp(ic_clamp(y0 + 1, 0, H - 1) + gy, 0, H - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* r = ref + c * plane;
+            float acc = __fmul_rn(r[static_cast<size_t>(ya) * W + xa], w_nw);
+            acc = __fmaf_rn(r[static_cast<size_t>(ya) * W + xb], w_ne, acc);
+            acc = __fmaf_rn(r[static_cast<size_t>(yb) * W + xa], w_sw, acc);
+            acc = __fmaf_rn(r[static_cast<size_t>(yb) * W + xb], w_se, acc);
+            out[c] = acc;
+        }
+        return;
+    }
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float tx = __fsub_rn(ix, x0f), ty = __fsub_rn(iy, y0f);
+    const float cx[4] = {ic_cubic_outer(__fadd_rn(tx, 1.0f)), ic_cubic_inner(tx), ic_cubic_inner(__fsub_rn(1.0f, tx)), ic_cubic_outer(__fsub_rn(2.0f, tx))};
+    const float cy[4] = {ic_cubic_outer(__fadd_rn(ty, 1.0f)), ic_cubic_inner(ty), ic_cubic_inner(__fsub_rn(1.0f, ty)), ic_cubic_outer(__fsub_rn(2.0f, ty))};
+    const int x0 = static_cast<int>(fminf(fmaxf(x0f, -4.0f), static_cast<float>(W) + 4.0f));
+    const int y0 = static_cast<int>(fminf(fmaxf(y0f, -4.0f), static_cast<float>(H) + 4.0f));
+    int xs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xs[j] = ic_clamp(ic_clamp(x0 - 1 + j, 0, W - 1) + gx, 0, W - 1);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float row[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = ic_clamp(ic_clamp(y0 - 1 + i, 0, H - 1) + gy, 0, H - 1);
+            const float* r = ref + c * plane + static_cast<size_t>(yy) * W;
+            float acc = __fmaf_rn(r[xs[0]], cx[0], __fmul_rn(r[xs[1]], cx[1]));
+            acc = __fadd_rn(acc, __fmul_rn(r[xs[2]], cx[2]));
+            acc = __fadd_rn(acc, __fmul_rn(r[xs[3]], cx[3]));
+            row[i] = acc;
+        }
+        float acc = __fmaf_rn(row[1], cy[1], __fmul_rn(row[0], cy[0]));
+        acc = __fmaf_rn(row[2], cy[2], acc);
+        acc = __fmaf_rn(row[3], cy[3], acc);
+        out[c] = acc;
+    }
+}
+
 struct InterParams {
     const float* residue;  // [4 | 5][H][W]
     const float* motion;   // [2 | 4][H][W]
@@ -141,12 +219,14 @@ __global__ __launch_bounds__(256) void inter_recon_kernel(InterParams p) {
     float a = p.residue[3 * plane + i] + 0.5f;
     a = a < 0.0f ? 0.0f : (a > 1.0f ? 1.0f : a);
     float w0[3], pred[3];
-    ic_warp_pixel(p.ref0, p.H, p.W, p.gflow[0], p.gflow[1], p.n_taps, p.motion[i], p.motion[plane + i], y, x, w0);
+    if (p.n_taps < 6) ic_warp_pixel_native(p.ref0, p.H, p.W, p.gflow[0], p.gflow[1], p.n_taps, p.motion[i], p.motion[plane + i], y, x, w0);
+    else ic_warp_pixel(p.ref0, p.H, p.W, p.gflow[0], p.gflow[1], p.n_taps, p.motion[i], p.motion[plane + i], y, x, w0);
     if (p.frame_type == 2) {
         float b = p.residue[4 * plane + i] + 0.5f;
         b = b < 0.0f ? 0.0f : (b > 1.0f ? 1.0f : b);
         float w1[3];
-        ic_warp_pixel(p.ref1, p.H, p.W, p.gflow[2], p.gflow[3], p.n_taps, p.motion[2 * plane + i], p.motion[3 * plane + i], y, x, w1);
+        if (p.n_taps < 6) ic_warp_pixel_native(p.ref1, p.H, p.W, p.gflow[2], p.gflow[3], p.n_taps, p.motion[2 * plane + i], p.motion[3 * plane + i], y, x, w1);
+        else ic_warp_pixel(p.ref1, p.H, p.W, p.gflow[2], p.gflow[3], p.n_taps, p.motion[2 * plane + i], p.motion[3 * plane + i], y, x, w1);
 #pragma unroll
         for (int c = 0; c < 3; ++c) { const float t0 = b * w0[c], t1 = (1.0f - b) * w1[c]; pred[c] = t0 + t1; }
     } else {

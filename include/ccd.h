@@ -171,7 +171,7 @@ int ccd_decode_video(const uint8_t* bitstream, size_t n, int device, ccd_video* 
  * [5][h][w] for B: rgb/yuv residue, alpha, beta), motion = output of the "motion" cool-chic ([2] or [4][h][w]:
  * (x, y) flow per reference), refN_planes = the three integer planes of each reference frame (u8 if
  * bitdepth == 8 else u16; half-size chroma for yuv420), global_flow = (x, y) integer translation per reference
- * (frame header), warp_filter_size = taps of the sinc warp (>= 6).  Writes the integer planes of the frame. */
+ * (frame header), warp_filter_size = 2 (bilinear) / 4 (bicubic grid_sample) / 6..16 even (sinc) as in warp.py:49-56.  Writes the integer planes of the frame. */
 int ccd_inter_reconstruct(int device, void* stream, int frame_type, int h, int w, int bitdepth, int frame_data_type,
                           const float* residue, const float* motion, const void* const* ref0_planes,
                           const void* const* ref1_planes, const int32_t* global_flow, int warp_filter_size,

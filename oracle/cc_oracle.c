@@ -1161,6 +1161,85 @@ static void warp_pixel(const float* ref, int H, int W, int gx, int gy, int n_tap
     }
 }
 
+/* ---- warp_filter_size 2 / 4: Warper's native path (warp.py:92-116, 325-343): F.grid_sample(mode = bilinear | bicubic,
+ * padding_mode = "border", align_corners = True) on grid = backward_grid + flow / ((size - 1) / 2), flows unquantised
+ * (training mode).  Canon = the float32 operation sequence of the reference run (PyTorch 2.10 CPU kernels as compiled
+ * for this container, found by matching grid_sample bit for bit on random inputs, tests/golden/gen/warp_canon.py):
+ *   linspace(-1, 1, n)[i]  = fma(step, i, -1) below n / 2, fma(-step, n - 1 - i, 1) from there on, step = 2 / (n - 1)
+ *   source index           = (grid + 1) * ((size - 1) / 2)
+ *   bilinear               clip to [0, size - 1]; weights s e, s w, n e, n w (plain products); nw * w0 then three fma
+ *   bicubic (A = -0.75)    no clip of the index, every tap clipped; outer coefficients ((A x - 5A) x + 8A) x - 4A with
+ *                          every step rounded, inner ones fma(fma(A + 2, x, -(A + 3)) * x, x, 1);
+ *                          row = fma(p0, c0, p1 c1) + p2 c2 + p3 c3; column = fma chain over fma(r1, d1, r0 d0)
+ * The integer global translation acts on the reference first (border replicate): two clamps per tap, as above. */
+static float lin_coord(int i, int n) {
+    if (n == 1) return -1.0f;
+    const float step = 2.0f / (float)(n - 1);
+    return i < n / 2 ? fmaf(step, (float)i, -1.0f) : fmaf(-step, (float)(n - 1 - i), 1.0f);
+}
+static float cubic_inner(float x) { /* |x| <= 1 */
+    const float A = -0.75f;
+    const float t = fmaf(A + 2.0f, x, -(A + 3.0f)) * x;
+    return fmaf(t, x, 1.0f);
+}
+static float cubic_outer(float x) { /* 1 < |x| < 2 */
+    const float A = -0.75f;
+    float t = A * x;
+    t = t - 5.0f * A;
+    t = t * x;
+    t = t + 8.0f * A;
+    t = t * x;
+    return t - 4.0f * A;
+}
+static void warp_pixel_native(const float* ref, int H, int W, int gx, int gy, int n_taps, float fx, float fy, int y, int x, float out[3]) {
+    const float sx = (float)((W - 1.0) / 2.0), sy = (float)((H - 1.0) / 2.0);
+    const float gxn = lin_coord(x, W) + fx / sx, gyn = lin_coord(y, H) + fy / sy;
+    float ix = (gxn + 1.0f) * sx, iy = (gyn + 1.0f) * sy;
+    const size_t plane = (size_t)H * W;
+    if (n_taps == 2) {
+        ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
+        iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+        const float x0f = floorf(ix), y0f = floorf(iy);
+        const float w = ix - x0f, e = 1.0f - w, n = iy - y0f, s = 1.0f - n;
+        const float w_nw = s * e, w_ne = s * w, w_sw = n * e, w_se = n * w;
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const int xa = clip_i(clip_i(x0, 0, W - 1) + gx, 0, W - 1), xb = clip_i(clip_i(x0 + 1, 0, W - 1) + gx, 0, W - 1);
+        const int ya = clip_i(clip_i(y0, 0, H - 1) + gy, 0, H - 1), yb = clip_i(clip_i(y0 + 1, 0, H - 1) + gy, 0, H - 1);
+        for (int c = 0; c < 3; ++c) {
+            const float* r = ref + c * plane;
+            float acc = r[(size_t)ya * W + xa] * w_nw;
+            acc = fmaf(r[(size_t)ya * W + xb], w_ne, acc);
+            acc = fmaf(r[(size_t)yb * W + xa], w_sw, acc);
+            acc = fmaf(r[(size_t)yb * W + xb], w_se, acc);
+            out[c] = acc;
+        }
+        return;
+    }
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float tx = ix - x0f, ty = iy - y0f;
+    const float cx[4] = {cubic_outer(tx + 1.0f), cubic_inner(tx), cubic_inner(1.0f - tx), cubic_outer(2.0f - tx)};
+    const float cy[4] = {cubic_outer(ty + 1.0f), cubic_inner(ty), cubic_inner(1.0f - ty), cubic_outer(2.0f - ty)};
+    /* the index is a float in the reference: far-away flows saturate instead of wrapping */
+    const int x0 = (int)fminf(fmaxf(x0f, -4.0f), (float)W + 4.0f), y0 = (int)fminf(fmaxf(y0f, -4.0f), (float)H + 4.0f);
+    int xs[4];
+    for (int j = 0; j < 4; ++j) xs[j] = clip_i(clip_i(x0 - 1 + j, 0, W - 1) + gx, 0, W - 1);
+    for (int c = 0; c < 3; ++c) {
+        float row[4];
+        for (int i = 0; i < 4; ++i) {
+            const int yy = clip_i(clip_i(y0 - 1 + i, 0, H - 1) + gy, 0, H - 1);
+            const float* r = ref + c * plane + (size_t)yy * W;
+            float acc = fmaf(r[xs[0]], cx[0], r[xs[1]] * cx[1]);
+            acc = acc + r[xs[2]] * cx[2];
+            acc = acc + r[xs[3]] * cx[3];
+            row[i] = acc;
+        }
+        float acc = fmaf(row[1], cy[1], row[0] * cy[0]);
+        acc = fmaf(row[2], cy[2], acc);
+        acc = fmaf(row[3], cy[3], acc);
+        out[c] = acc;
+    }
+}
+
 /* decode.py:156-189 for one P / B frame. residue [3+1(+1)][H][W], motion [2(+2)][H][W], refs [3][H][W] each. */
 static void reconstruct_inter(int frame_type, int H, int W, const float* residue, const float* motion, const float* ref0,
                               const float* ref1, const int* global_flow, int n_taps, float* out /* [3][H][W] */) {
@@ -1171,12 +1250,12 @@ static void reconstruct_inter(int frame_type, int H, int W, const float* residue
             float a = residue[3 * plane + p] + 0.5f;
             a = a < 0.0f ? 0.0f : (a > 1.0f ? 1.0f : a);
             float w0[3], pred[3];
-            warp_pixel(ref0, H, W, global_flow[0], global_flow[1], n_taps, motion[p], motion[plane + p], y, x, w0);
+            (n_taps < 6 ? warp_pixel_native : warp_pixel)(ref0, H, W, global_flow[0], global_flow[1], n_taps, motion[p], motion[plane + p], y, x, w0);
             if (frame_type == 2) {
                 float b = residue[4 * plane + p] + 0.5f;
                 b = b < 0.0f ? 0.0f : (b > 1.0f ? 1.0f : b);
                 float w1[3];
-                warp_pixel(ref1, H, W, global_flow[2], global_flow[3], n_taps, motion[2 * plane + p], motion[3 * plane + p], y, x, w1);
+                (n_taps < 6 ? warp_pixel_native : warp_pixel)(ref1, H, W, global_flow[2], global_flow[3], n_taps, motion[2 * plane + p], motion[3 * plane + p], y, x, w1);
                 for (int c = 0; c < 3; ++c) { const float t0 = b * w0[c], t1 = (1.0f - b) * w1[c]; pred[c] = t0 + t1; }
             } else {
                 for (int c = 0; c < 3; ++c) pred[c] = w0[c];
@@ -1298,7 +1377,7 @@ int ora_decode_video(const uint8_t* bs, size_t n, ora_video* v) {
             } else {
                 const int need_res = fh.frame_type == 1 ? 4 : 5, need_mot = fh.frame_type == 1 ? 2 : 4;
                 if (r[0].out_c < need_res || r[1].out_c < need_mot || r[1].out_h != H || r[1].out_w != W ||
-                    fh.warp_filter_size < 6 || fh.warp_filter_size > 16) rc = fh.warp_filter_size < 6 ? ORA_ERR_UNSUPPORTED : ORA_ERR_VALUE;
+                    fh.warp_filter_size < 2 || fh.warp_filter_size > 16 || (fh.warp_filter_size & 1)) rc = ORA_ERR_VALUE; /* warp.py:41-47 asserts */
                 float* refs[2] = {NULL, NULL};
                 for (int k = 0; k < fh.n_refs && rc == ORA_OK; ++k) {
                     const int ri = fh.index_references[k];

@@ -244,6 +244,9 @@ def main():
             entry["chan_mean"] = [float(x) for x in q.astype(np.float64).mean(axis=(1, 2))]
         rec["frames"][k] = entry
 
+    if len(sys.argv) > 3 and sys.argv[3] == "--planes-only":
+        # variants that differ from an existing fixture only after the cool-chics (e.g. the warp filter): keep the decoded planes
+        arrays = {k: v for k, v in arrays.items() if k.startswith("frame")}
     np.savez_compressed(os.path.join(out_dir, name + ".npz"), **arrays)
     with open(os.path.join(out_dir, name + ".json"), "w") as f:
         json.dump(rec, f, indent=1, default=lambda o: o if not hasattr(o, "tolist") else o.tolist())

@@ -100,11 +100,14 @@ def test_range_encoder_reproduces_shipped_payload(oracle):
     assert payload == lat
 
 
-def test_video_ipb_vs_reference(oracle):
-    """I/P/B video (sinc-8 warp, global translation, alpha/beta blending, 4:2:0): oracle vs the frames the
-    reference decoder produced. Bar: <= 1 LSB, <= 1e-4 of the samples (the reference's float warp is not
-    bit-reproducible across torch builds; 5 of 215 040 samples differ here)."""
-    bs, z, j = load_golden("vid5")
+@pytest.mark.parametrize("name", ["vid5", "vid5_w2", "vid5_w4"])
+def test_video_ipb_vs_reference(oracle, name):
+    """I/P/B video (global translation, alpha/beta blending, 4:2:0) with the sinc-8 warp (vid5) and with the Warper's
+    native grid_sample paths, 2 taps = bilinear and 4 taps = bicubic (vid5_w2 / vid5_w4: the same cool-chics, only the
+    frame headers' warp_filter_size differs): oracle vs the frames the reference decoder produced. Bar: <= 1 LSB,
+    <= 1e-4 of the samples (the reference's float pipeline is not bit-reproducible across torch builds; 5 / 0 / 2 of
+    215 040 samples differ here)."""
+    bs, z, j = load_golden(name)
     frames = oracle.decode_video(bs)
     assert [f["frame_type"] for f in frames] == ["I", "B", "B", "B", "P"]
     n_diff = n_tot = 0
