@@ -227,8 +227,8 @@ def test_python_surface(gpu, oracle, tmp_path):
         encode_decode_coolchic(ch, nn, "decode", dec_bytes_latent=None)
 
 
-@pytest.mark.parametrize("name", ["vid5", "vid5_w2", "vid5_w4"])
-def test_video_ipb_parity(gpu, oracle, tmp_path, name):
+@pytest.mark.parametrize("stream", ["vid5", "vid5_w2", "vid5_w4"])
+def test_video_ipb_parity(gpu, oracle, tmp_path, stream):
     """5-frame I/P/B YUV420 video encoded by the reference encoder (sinc-8 warp; _w2 / _w4: the same stream with the
     2-tap bilinear / 4-tap bicubic grid_sample warp): C ABI (ccd_decode_video) and the Python mirror (decode_video /
     decode_frame) against the oracle (bit-exact) and the reference fixture (<= 1 LSB)."""
@@ -238,7 +238,7 @@ def test_video_ipb_parity(gpu, oracle, tmp_path, name):
     from cool_chic_amd.bitstream.decode import decode_video
     from conftest import GOLDEN
 
-    bs, z, j = load_golden(name)
+    bs, z, j = load_golden(stream)
     want = oracle.decode_video(bs)
     v = Video()
     check(lib().ccd_decode_video(bs, len(bs), 0, C.byref(v)), "ccd_decode_video")
@@ -261,7 +261,7 @@ def test_video_ipb_parity(gpu, oracle, tmp_path, name):
         lib().ccd_video_free(C.byref(v))
     # Python surface: decode_video writes a planar YUV file, frames in display order
     out_yuv = str(tmp_path / "v.yuv")
-    frames = decode_video(os.path.join(GOLDEN, name + ".cool"), decoded_path=out_yuv)
+    frames = decode_video(os.path.join(GOLDEN, stream + ".cool"), decoded_path=out_yuv)
     assert list(frames) == ["0", "1", "2", "3", "4"]
     raw = np.fromfile(out_yuv, dtype=np.uint8)
     expect = np.concatenate([np.concatenate([p.astype(np.uint8).ravel() for p in want[i]["planes"]]) for i in range(5)])
