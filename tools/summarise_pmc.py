@@ -1,0 +1,70 @@
+"""gpurun_out/prof/{fetch,write} (tools/collect_profiles.sh: one rocprofv3 --pmc run per counter) -> profiles/<round>/kodak24_pmc_traffic.json
+
+    python tools/summarise_pmc.py [gpurun_out/prof] [profiles/r01]
+
+Bytes per launch = mean of the counter over the launches of a kernel (first launch of every kernel dropped: warm-up
+with cold caches), counter unit KiB.  Kernels launched several times per step (the six pyramid levels) also get a
+per-step figure."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+KERNELS = {  # short name -> (substring of the kernel name, launches per bench step or None)
+    "entropy_pipe_kernel": ("entropy_pipe_kernel", None),
+    "upsample_step_kernel": ("upsample_step_kernel", 6),
+    "syn_fused_kernel": ("syn_fused_kernel", None),
+    "png_filter_huff_kernel": ("png_filter_huff_kernel", None),
+    "png_emit_kernel": ("png_emit_kernel", None),
+    "png_crc_kernel": ("png_crc_kernel", None),
+}
+
+
+def read(dir_, counter):
+    vals = defaultdict(list)
+    for f in sorted(glob.glob(os.path.join(dir_, "**", "*counter_collection.csv"), recursive=True)):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r["Counter_Name"] == counter:
+                    vals[r["Kernel_Name"]].append(float(r["Counter_Value"]) * 1024.0)
+    return vals
+
+
+def main():
+    src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
+    dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01"
+    fetch, write = read(os.path.join(src, "fetch"), "FETCH_SIZE"), read(os.path.join(src, "write"), "WRITE_SIZE")
+    out = {}
+    for short, (sub, per_step) in KERNELS.items():
+        names = [n for n in fetch if sub in n]
+        if not names:
+            continue
+        name = names[0]
+        f, w = fetch[name][1:] or fetch[name], write.get(name, [0.0])[1:] or write.get(name, [0.0])
+        e = {"full_name": name, "launches": len(f)}
+        if per_step:
+            e["launches_per_step"] = per_step
+            e["fetch_bytes_per_step"] = sum(f) / len(f) * per_step
+            e["write_bytes_per_step"] = sum(w) / len(w) * per_step
+        else:
+            e["fetch_bytes"] = sum(f) / len(f)
+            e["write_bytes"] = sum(w) / len(w)
+        out[short] = e
+    doc = {
+        "command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline (tools/collect_profiles.sh; one rocprofv3 run per counter)",
+        "unit": "bytes per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB; raw values, no gfx950 correction applied)",
+        "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced reads by 2x; these kernels "
+                "read 4-byte and 1-byte elements, for which the guide gives no calibration - read FETCH_SIZE as a lower bound "
+                "(x1) .. upper bound (x2).",
+        "kernels": out,
+    }
+    os.makedirs(dst, exist_ok=True)
+    with open(os.path.join(dst, "kodak24_pmc_traffic.json"), "w") as fh:
+        json.dump(doc, fh, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
