@@ -153,7 +153,7 @@ def test_device_png_full_size_round_trips(packer):
     """BASELINE sizes (4K, 2K portrait) through the size-independent property: an independent reader gets the pixels."""
     import torch
 
-    for h, w in ((2160, 3840), (2048, 1365)):
+    for h, w in ((2160, 3840), (2048, 1365), (2, 16383), (16383, 2), (3000, 1)):  # + the extreme aspect ratios of 14-bit sizes
         planes = _pictures(h, w)["photo"]
         png = packer.pack(torch.from_numpy(planes).cuda())
         assert len(png) <= packer.bound(h, w)
