@@ -248,6 +248,14 @@ def main():
             "parity": "bit-exact vs CPU oracle (tests/test_gpu_parity.py); <=1 LSB on <=2e-5 of samples vs reference fixture",
             "stage_ms_per_step": stage_ms,
             "entropy_msym_per_s": n_sym / (stage_ms["entropy"] / 1e3) / 1e6,
+            # what actually bounds the dominant kernel: every stream is ONE serial range-decoder recurrence; its bare symbol
+            # loop runs at 164 ticks of the 2.4 GHz shader clock (tools/ubench/dloop.hip), so n streams cannot
+            # exceed n * 2.4e9 / 164 symbols/s however many CUs idle.  The gap is per-batch hand-over and the producer
+            # latency chain on the short wavefront steps of the coarse grids.
+            "serial_chain_bound": {"achieved": n_sym / (stage_ms["entropy"] / 1e3) / 1e6,
+                                   "peak": n_frames * 2.4e9 / 164.0 / 1e6, "unit": "Msymbol/s",
+                                   "frac": (n_sym / (stage_ms["entropy"] / 1e3)) / (n_frames * 2.4e9 / 164.0),
+                                   "streams": n_frames, "ticks_per_symbol_floor": 164},
             # the dominant kernel (98 % of the step) is the serial range-decoder chain: one workgroup per stream, bound by
             # dependent-instruction latency, not by HBM or MFMA - its HBM fraction only shows how far from that roof it sits
             "roofline": line("entropy_pipe_kernel<5> (24 streams, one workgroup each)", ent_bytes, stage_ms["entropy"],
