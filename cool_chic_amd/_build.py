@@ -4,7 +4,7 @@ import shutil
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["ccd_format.cpp", "ccd_writer.cpp", "ccd_api.cpp", "ccd_entropy.hip", "ccd_entropy_pipe.hip", "ccd_float.hip", "ccd_synth_fused.hip", "ccd_inter.hip", "ccd_png.hip", "ccd_rate.hip"]
+SOURCES = ["ccd_format.cpp", "ccd_writer.cpp", "ccd_api.cpp", "ccd_entropy.hip", "ccd_entropy_pipe.hip", "ccd_float.hip", "ccd_synth_fused.hip", "ccd_fused.hip", "ccd_inter.hip", "ccd_png.hip", "ccd_rate.hip"]
 HEADERS = ["ccd_format.hpp", "ccd_device.hpp", "../../include/ccd.h", "../../include/ccd_scale_table.inc"]
 LIB = os.path.join(_HERE, "libccd.so")
 
@@ -64,6 +64,29 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return LIB
+
+
+def build_variant(name: str, extra_flags: str) -> str:
+    """A second copy of the library with extra compiler flags (e.g. -DCCD_FD_PROFILE), for tools: cool_chic_amd/libccd_<name>.so,
+    selected at run time with CCD_LIB=<path>."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    obj_dir = os.path.join(_HERE, "csrc", "_obj_" + name)
+    os.makedirs(obj_dir, exist_ok=True)
+    out = os.path.join(_HERE, f"libccd_{name}.so")
+
+    def compile_one(src):
+        path = os.path.join(_HERE, "csrc", src)
+        obj = os.path.join(obj_dir, src + ".o")
+        if os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), max(os.path.getmtime(os.path.join(_HERE, "csrc", h)) for h in HEADERS)):
+            return obj
+        subprocess.check_call([_hipcc()] + _flags() + extra_flags.split() + ["-c", path, "-o", obj])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        objs = list(pool.map(compile_one, SOURCES))
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
+    return out
 
 
 if __name__ == "__main__":

@@ -94,6 +94,8 @@ SIGNATURES = {
     "ccd_batch_slot_status": (C.c_int, [C.c_void_p, C.c_int]),
     "ccd_batch_slot_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ccd_batch_slot_kernels": (C.c_int, [C.c_void_p, C.c_int]),
+    "ccd_debug_fd_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "ccd_batch_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ccd_batch_output": (C.c_void_p, [C.c_void_p, C.c_int]),
     "ccd_batch_dense": (C.c_void_p, [C.c_void_p, C.c_int]),
     "ccd_batch_latent": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
@@ -138,7 +140,8 @@ def lib():
     """Loads (building first if needed) libccd.so. Raises if the HIP extension cannot be produced."""
     global _lib
     if _lib is None:
-        path = _build.build_lib()
+        # CCD_LIB: an alternative build of the same library (profiling variants made by _build.build_variant)
+        path = os.environ.get("CCD_LIB") or _build.build_lib()
         # PyTorch-ROCm bundles its own libamdhip64.so.7; load it FIRST so that libccd.so (same SONAME)
         # binds to that copy. Two HIP runtimes in one process cannot both own the device.
         import torch  # noqa: F401

@@ -26,10 +26,18 @@ class DecodeBatch:
     enqueues kernels on `stream` (a hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream).
     """
 
-    def __init__(self, device: int = 0):
+    OPT_FUSED_DEC, OPT_KEEP_FLOAT = 1, 2  # include/ccd.h
+
+    def __init__(self, device: int = 0, fused_dec: Optional[bool] = None, keep_float: Optional[bool] = None):
+        """fused_dec=False: unfused float path (materialises dense()); keep_float=False: rgb / yuv444 intra slots
+        write integer planes only (output() is then unavailable for them).  None = library default (both on)."""
         self._h = C.c_void_p()
         check(lib().ccd_batch_create(int(device), C.byref(self._h)), "ccd_batch_create")
         self.device = int(device)
+        if fused_dec is not None:
+            check(lib().ccd_batch_set_option(self._h, self.OPT_FUSED_DEC, int(bool(fused_dec))), "ccd_batch_set_option")
+        if keep_float is not None:
+            check(lib().ccd_batch_set_option(self._h, self.OPT_KEEP_FLOAT, int(bool(keep_float))), "ccd_batch_set_option")
         self._meta: List[Tuple[int, int]] = []
 
     def close(self):
@@ -73,7 +81,7 @@ class DecodeBatch:
 
     # ---- results -------------------------------------------------------------------------------
     def slot_kernels(self, slot: int) -> int:
-        """bit 0: pipelined entropy kernel, bit 1: fused synthesis kernel."""
+        """bit 0: pipelined entropy kernel, bit 1: fused synthesis kernel, bit 2: fused upsampling + synthesis kernel."""
         return check(lib().ccd_batch_slot_kernels(self._h, slot), "ccd_batch_slot_kernels")
 
     def latent(self, slot: int, grid: int) -> np.ndarray:

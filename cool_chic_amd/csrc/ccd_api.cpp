@@ -28,6 +28,11 @@ bool syn_fused_supports(int c_in, int c, int halo);
 void syn_fused_tiles(int h, int w, int halo, int* tiles_x, int* tiles_y);
 hipError_t launch_syn_fused(const SynthFused* d_frames, int n_frames, int c_in, int c, int max_tiles_x, int max_tiles_y,
                             hipStream_t stream);
+bool fused_dec_supports(int c_in, int c);
+size_t fused_dec_lds_bytes(int n_lv, int c, int n_conv, int n_params);
+void fused_dec_param_shape(int c_in, int c, int* nwv, int* nws, int* nwc, int* nwo);
+hipError_t launch_fused_dec(const FusedDec* d_frames, const void* d_work, int n_work, int c_in, int c, size_t lds_bytes, hipStream_t stream);
+int fused_dec_profile(unsigned long long* out16, int reset);
 hipError_t launch_resize_nearest(const float* in, float* out, int c, int h_in, int w_in, int h_out, int w_out,
                                  hipStream_t stream);
 hipError_t launch_resize_interp(const float* in, float* out, int c, int h_in, int w_in, int h_out, int w_out, int cubic,
@@ -92,6 +97,9 @@ struct Slot {
     float* d_syn_params = nullptr;
     bool use_fused_syn = false;      // whole synthesis in one kernel (ccd_synth_fused.hip)
     SynthFused fused;
+    bool use_fused_dec = false;      // upsampling + synthesis + integer samples in one kernel (ccd_fused.hip)
+    FusedDec fdec;
+    size_t fdec_lds = 0;
     std::vector<size_t> w_off, b_off;  // per main layer
     size_t stab_w = 0, stab_b = 0, out_w = 0, out_b = 0;
     float* d_tmp[2] = {nullptr, nullptr};
@@ -125,6 +133,13 @@ struct ccd_batch {
     struct FusedGroup { int cp, c, c_in, n, first, max_tx, max_ty; };
     std::vector<FusedGroup> fused_groups;
     SynthFused* d_fused = nullptr;
+    // fused float path (ccd_fused.hip): frames grouped by (latent levels, output channels); one workgroup per run of tiles
+    struct FdecGroup { int c_in, c, first_frame, first_work, n_work; size_t lds; };
+    std::vector<FdecGroup> fdec_groups;
+    FusedDec* d_fdec = nullptr;
+    void* d_fdec_work = nullptr;
+    int opt_fused_dec = 1;               // CCD_OPT_FUSED_DEC
+    int opt_keep_float = 1;              // CCD_OPT_KEEP_FLOAT
     // upsampling: step k of every slot's pyramid in one launch
     struct UpsStep { int first_z, n_z, max_w, max_h; };
     std::vector<UpsStep> ups_steps;
@@ -168,6 +183,7 @@ int ccd_batch_create(int device, ccd_batch** out) {
     if (!b) return CCD_ERR_NOMEM;
     b->device = device;
     if (const char* e = std::getenv("CCD_FORCE_GENERIC")) b->force_generic = std::atoi(e);
+    if (const char* e = std::getenv("CCD_FUSED_DEC")) b->opt_fused_dec = std::atoi(e);
     if (hipMalloc(&b->d_scale_table, sizeof(kScaleBits)) != hipSuccess) { delete b; return CCD_ERR_NOMEM; }
     if (hipMemcpy(b->d_scale_table, kScaleBits, sizeof(kScaleBits), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(b->d_scale_table); delete b; return CCD_ERR_HIP;
@@ -194,6 +210,8 @@ void ccd_batch_destroy(ccd_batch* b) {
     for (auto& s : b->slots) s->arena.release();
     if (b->d_params) (void)hipFree(b->d_params);
     if (b->d_fused) (void)hipFree(b->d_fused);
+    if (b->d_fdec) (void)hipFree(b->d_fdec);
+    if (b->d_fdec_work) (void)hipFree(b->d_fdec_work);
     if (b->d_levels) (void)hipFree(b->d_levels);
     if (b->d_zmap) (void)hipFree(b->d_zmap);
     if (b->d_scale_table) (void)hipFree(b->d_scale_table);
@@ -282,7 +300,6 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     const size_t o_feat = A.reserve(feat_px * std::max(h.output_feature_ifce, 1) * 4);
     const size_t o_status = A.reserve(512);
     const size_t dense_elems = static_cast<size_t>(s.dense_c) * s.dense_h * s.dense_w;
-    const size_t o_stack_a = A.reserve(dense_elems * 4);
     size_t o_noise = 0, o_nstack[2] = {0, 0};
     if (s.cr) {
         size_t n_noise = 0;
@@ -305,7 +322,6 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
         const int g1 = lat_grids[1];
         stack_b_elems = static_cast<size_t>(n_levels - 1) * h.grid_h[g1] * h.grid_w[g1];
     }
-    const size_t o_stack_b = A.reserve(stack_b_elems * 4);
     // synthesis parameters blob
     std::vector<float> syn_blob;
     auto push = [&](const std::vector<float>& v) { size_t off = syn_blob.size(); syn_blob.insert(syn_blob.end(), v.begin(), v.end()); return off; };
@@ -354,11 +370,102 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
             s.use_fused_syn = true;
         }
     }
+    // ---- fused float path (ccd_fused.hip): parameters in MFMA order, appended to the blob ------------------------------
+    {
+        FusedDec& D = s.fdec;
+        std::memset(&D, 0, sizeof(D));
+        const auto& L = net.syn;
+        const int C = h.out_channels;
+        bool ok = b->opt_fused_dec && !b->force_generic && !s.cr && n_levels == s.dense_c && n_levels >= 2 && n_levels <= kFdMaxLevels &&
+                  fused_dec_supports(n_levels, C) && net.ups_k == 8 && net.pre_k == 7 && L.size() >= 2 &&
+                  L.size() <= 2 + static_cast<size_t>(kFdMaxConv) && L[0].k == 1 && L[1].k == 1 && !L[0].residual && !L[1].residual &&
+                  L[0].c_in == n_levels && L[1].c_in == L[0].c_out && L[1].c_out == C && (!net.syn_stab.c_out || net.syn_stab.c_in <= n_levels);
+        for (size_t l = 2; ok && l < L.size(); ++l) ok = L[l].k == 3 && L[l].c_in == C && L[l].c_out == C;
+        if (ok) {
+            const int CIN = n_levels, N = L[0].c_out, CT = (C + 3) / 4, NT = (N + 3) / 4;
+            int nwv, nws, nwc, nwo;
+            fused_dec_param_shape(CIN, C, &nwv, &nws, &nwc, &nwo);
+            while (syn_blob.size() % 4) syn_blob.push_back(0.0f);  // the kernel copies the block with 16-byte loads
+            const size_t base = syn_blob.size();
+            auto alloc = [&](size_t n) { const size_t off = syn_blob.size() - base; syn_blob.resize(syn_blob.size() + n, 0.0f); return static_cast<int32_t>(off); };
+            float* P = nullptr;
+            auto quad = [&](int32_t off, int q, int i) -> float& { return P[off + q * 4 + i]; };
+            D.n_tiles_hidden = NT;
+            D.wq_off = alloc(static_cast<size_t>(NT) * nwv * 64); D.b0_off = alloc(static_cast<size_t>(NT) * 4);
+            D.b1_off = alloc(static_cast<size_t>(CT) * 4);
+            D.stab_off = alloc(static_cast<size_t>(nws) * 64); D.stabb_off = alloc(static_cast<size_t>(CT) * 4);
+            D.n_conv = static_cast<int32_t>(L.size()) - 2;
+            for (int l = 0; l < D.n_conv; ++l) { D.conv_off[l] = alloc(static_cast<size_t>(nwc) * 64); D.convb_off[l] = alloc(static_cast<size_t>(CT) * 4); }
+            D.out_off = alloc(static_cast<size_t>(nwo) * 64); D.outb_off = alloc(static_cast<size_t>(CT) * 4);
+            D.n_params = static_cast<int32_t>(syn_blob.size() - base);
+            P = syn_blob.data() + base;
+            for (int n = 0; n < NT; ++n) {
+                const int32_t wq = D.wq_off + n * nwv * 64;
+                for (int i = 0; i < 4; ++i) {
+                    const int hu = 4 * n + i;  // hidden unit = row i of the tile
+                    if (hu >= N) continue;
+                    for (int c = 0; c < CIN; ++c) quad(wq, c, i) = L[0].w[static_cast<size_t>(hu) * CIN + c];
+                    P[D.b0_off + 4 * n + i] = L[0].b[hu];
+                }
+                for (int t = 0; t < CT; ++t)
+                    for (int r = 0; r < 4; ++r)
+                        for (int i = 0; i < 4; ++i) {
+                            const int oc = 4 * t + i, hu = 4 * n + r;
+                            if (oc < C && hu < N) quad(wq, CIN + t * 4 + r, i) = L[1].w[static_cast<size_t>(oc) * N + hu];
+                        }
+            }
+            for (int oc = 0; oc < C; ++oc) P[D.b1_off + oc] = L[1].b[oc];
+            D.has_stab = net.syn_stab.c_out ? 1 : 0;
+            if (D.has_stab)
+                for (int oc = 0; oc < C; ++oc) {
+                    for (int c = 0; c < net.syn_stab.c_in; ++c) quad(D.stab_off, c * CT + oc / 4, oc % 4) = net.syn_stab.w[static_cast<size_t>(oc) * net.syn_stab.c_in + c];
+                    P[D.stabb_off + oc] = net.syn_stab.b[oc];
+                }
+            for (int l = 0; l < D.n_conv; ++l) {
+                const SynLayerParams& Lc = L[l + 2];
+                D.conv_residual[l] = Lc.residual; D.conv_relu[l] = Lc.relu;
+                for (int oc = 0; oc < C; ++oc) {
+                    for (int k = 0; k < 9 * C; ++k) quad(D.conv_off[l], k * CT + oc / 4, oc % 4) = Lc.w[static_cast<size_t>(oc) * 9 * C + k];
+                    P[D.convb_off[l] + oc] = Lc.b[oc];
+                }
+            }
+            for (int oc = 0; oc < C; ++oc) {
+                for (int i = 0; i < C; ++i) quad(D.out_off, i * CT + oc / 4, oc % 4) = net.syn_out.w[static_cast<size_t>(oc) * C + i];
+                P[D.outb_off + oc] = net.syn_out.b[oc];
+            }
+            D.relu0 = L[0].relu; D.relu1 = L[1].relu;
+            D.n_lv = n_levels; D.c = C; D.h = s.dense_h; D.w = s.dense_w;
+            D.margin = D.n_conv == 0 ? 0 : (D.n_conv <= 2 ? 2 : 4);
+            D.tiles_x = (D.w + (64 - 2 * D.margin) - 1) / (64 - 2 * D.margin);
+            D.tiles_y = (D.h + (32 - 2 * D.margin) - 1) / (32 - 2 * D.margin);
+            // kron products of the symmetric 1-D filters (upsampling.py:42-64, 189-196, 312-325): level i is produced by step
+            // n_levels - 2 - i (coarsest first), whose filters are those of index step % n_ups
+            for (int i = 0; i + 1 < n_levels; ++i) {
+                const int kidx = (n_levels - 2 - i) % net.n_ups;
+                const float* uw = &net.ups_w[static_cast<size_t>(kidx) * net.ups_k];
+                const float* pw = &net.pre_w[static_cast<size_t>(kidx) * net.pre_k];
+                for (int a2 = 0; a2 < 4; ++a2)
+                    for (int b2 = a2; b2 < 4; ++b2) {
+                        volatile float pu = uw[a2] * uw[b2], pp = pw[a2] * pw[b2];  // rounded to f32 like the kernels' own products
+                        D.k2u[i][k2_index(a2, b2)] = pu; D.k2p[i][k2_index(a2, b2)] = pp;
+                    }
+            }
+            s.fdec_lds = fused_dec_lds_bytes(n_levels, C, D.n_conv, D.n_params);
+            s.use_fused_dec = s.fdec_lds <= 160 * 1024;
+            if (!s.use_fused_dec) syn_blob.resize(base);
+            else D.params = reinterpret_cast<const float*>(base);  // offset for now; becomes a pointer once the arena exists
+        }
+    }
     const size_t o_synp = A.reserve(syn_blob.size() * 4);
     const size_t plane_px = static_cast<size_t>(s.dense_h) * s.dense_w;
-    const size_t o_tmp0 = A.reserve(plane_px * max_c * 4);
-    const size_t o_tmp1 = A.reserve(plane_px * max_c * 4);
-    const size_t o_stab = A.reserve(plane_px * std::max(h.out_channels, 1) * 4);
+    // per-layer scratch of the generic synthesis path and the dense stacks of the unfused upsampling: only when that path runs
+    const bool need_dense = !s.use_fused_dec;
+    const bool need_layers = !s.use_fused_dec && !s.use_fused_syn;
+    const size_t o_stack_a = A.reserve(need_dense ? dense_elems * 4 : 16);
+    const size_t o_stack_b = A.reserve(need_dense ? stack_b_elems * 4 : 16);
+    const size_t o_tmp0 = A.reserve(need_layers ? plane_px * max_c * 4 : 16);
+    const size_t o_tmp1 = A.reserve(need_layers ? plane_px * max_c * 4 : 16);
+    const size_t o_stab = A.reserve(need_layers ? plane_px * std::max(h.out_channels, 1) * 4 : 16);
     const size_t o_synout = A.reserve(plane_px * std::max(h.out_channels, 1) * 4);
     const size_t o_out = need_resize ? A.reserve(static_cast<size_t>(H) * W * h.out_channels * 4) : o_synout;
     size_t o_plane[3] = {0, 0, 0};
@@ -376,7 +483,9 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
 
     // ---- uploads (inputs become resident in HBM here) ----------------------------------------------------
     auto fail = [&](int code) { A.release(); return code; };
-    if (hipMemset(A.at<char>(0), 0, A.total()) != hipSuccess) return fail(CCD_ERR_HIP);
+    // zeros where something is read before it is written: payload tail, status block (everything up to it is small);
+    // the float planes and integer planes are fully written by the kernels
+    if (hipMemset(A.at<char>(0), 0, o_status + 512) != hipSuccess) return fail(CCD_ERR_HIP);
     if (n_words && hipMemcpy(A.at<void>(o_words), bytes_latent, n_words * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(CCD_ERR_HIP);
     if (hipMemcpy(A.at<void>(o_arm), arm_blob.data(), arm_blob.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail(CCD_ERR_HIP);
     if (!ifce_blob.empty() && hipMemcpy(A.at<void>(o_ifce), ifce_blob.data(), ifce_blob.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail(CCD_ERR_HIP);
@@ -454,6 +563,18 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
         for (int p = 0; p < 3; ++p) F.plane[p] = s.d_plane[p];
     }
 
+    if (s.use_fused_dec) {
+        FusedDec& D = s.fdec;
+        D.params = s.d_syn_params + reinterpret_cast<size_t>(D.params);
+        for (int i = 0; i < n_levels; ++i) { D.lat[i] = E.latent[lat_grids[i]]; D.lh[i] = h.grid_h[lat_grids[i]]; D.lw[i] = h.grid_w[lat_grids[i]]; }
+        D.bitdepth = bitdepth ? bitdepth : 8;
+        D.write_planes = (bitdepth != 0 && frame_data_type != 1 && !need_resize) ? 1 : 0;
+        // float samples: always when nothing else is produced (or a later stage reads them); otherwise by CCD_OPT_KEEP_FLOAT
+        D.out = (!D.write_planes || b->opt_keep_float) ? s.d_syn_out : nullptr;
+        for (int p = 0; p < 3; ++p) D.plane[p] = s.d_plane[p];
+        s.levels.clear();  // no unfused pyramid steps for this slot
+        s.use_fused_syn = false;
+    }
     if (s.use_pipe) b->lds_pipe = std::max(b->lds_pipe, s.lds_pipe);
     else b->lds_generic = std::max(b->lds_generic, s.lds_generic);
     b->slots.push_back(std::move(sp));
@@ -504,6 +625,51 @@ static int upload_params(ccd_batch* b) {
     if (!fused.empty()) {
         if (hipMalloc(&b->d_fused, sizeof(SynthFused) * fused.size()) != hipSuccess) return CCD_ERR_NOMEM;
         if (hipMemcpy(b->d_fused, fused.data(), sizeof(SynthFused) * fused.size(), hipMemcpyHostToDevice) != hipSuccess) return CCD_ERR_HIP;
+    }
+    // fused float path: frames grouped by (levels, channels); a workgroup takes a run of `per_wg` tiles of one frame
+    if (b->d_fdec) { (void)hipFree(b->d_fdec); b->d_fdec = nullptr; }
+    if (b->d_fdec_work) { (void)hipFree(b->d_fdec_work); b->d_fdec_work = nullptr; }
+    b->fdec_groups.clear();
+    {
+        struct Work { int32_t frame, tile_first, tile_count, pad; };
+        std::vector<FusedDec> frames;
+        std::vector<Work> work;
+        for (int i = 0; i < n; ++i) {
+            const Slot& s = *b->slots[i];
+            if (!s.use_fused_dec) continue;
+            bool placed = false;
+            for (auto& g : b->fdec_groups) placed = placed || (g.c_in == s.fdec.n_lv && g.c == s.fdec.c);
+            if (!placed) b->fdec_groups.push_back({s.fdec.n_lv, s.fdec.c, 0, 0, 0, 0});
+        }
+        for (auto& g : b->fdec_groups) {
+            g.first_frame = static_cast<int>(frames.size());
+            g.first_work = static_cast<int>(work.size());
+            long total_tiles = 0;
+            for (int i = 0; i < n; ++i) {
+                const Slot& s = *b->slots[i];
+                if (s.use_fused_dec && s.fdec.n_lv == g.c_in && s.fdec.c == g.c) total_tiles += static_cast<long>(s.fdec.tiles_x) * s.fdec.tiles_y;
+            }
+            // ~8 workgroups per CU keep the tail short; a run of tiles amortises the parameter staging
+            const int per_wg = static_cast<int>(std::min<long>(8, std::max<long>(1, (total_tiles + 2047) / 2048)));
+            for (int i = 0; i < n; ++i) {
+                const Slot& s = *b->slots[i];
+                if (!s.use_fused_dec || s.fdec.n_lv != g.c_in || s.fdec.c != g.c) continue;
+                const int f = static_cast<int>(frames.size()) - g.first_frame;
+                frames.push_back(s.fdec);
+                g.lds = std::max(g.lds, s.fdec_lds);
+                const int nt = s.fdec.tiles_x * s.fdec.tiles_y;
+                for (int t0 = 0; t0 < nt; t0 += per_wg) work.push_back({f, t0, std::min(per_wg, nt - t0), 0});
+            }
+            g.n_work = static_cast<int>(work.size()) - g.first_work;
+        }
+        if (!frames.empty()) {
+            if (hipMalloc(&b->d_fdec, sizeof(FusedDec) * frames.size()) != hipSuccess ||
+                hipMalloc(&b->d_fdec_work, sizeof(Work) * work.size()) != hipSuccess)
+                return CCD_ERR_NOMEM;
+            if (hipMemcpy(b->d_fdec, frames.data(), sizeof(FusedDec) * frames.size(), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(b->d_fdec_work, work.data(), sizeof(Work) * work.size(), hipMemcpyHostToDevice) != hipSuccess)
+                return CCD_ERR_HIP;
+        }
     }
     // upsampling steps: step k (k-th from the coarsest level) of all slots together
     if (b->d_levels) { (void)hipFree(b->d_levels); b->d_levels = nullptr; }
@@ -569,6 +735,7 @@ static int run_common_randomness(Slot& s, hipStream_t st) {
 
 static int run_upsampling(Slot& s, hipStream_t st) {
     if (s.cr) { const int rc = run_common_randomness(s, st); if (rc < 0) return rc; }
+    if (s.use_fused_dec) return CCD_OK;  // the pyramid is evaluated inside the fused kernel (stage 2)
     if (s.levels.empty()) {
         const int g = [&] { for (int i = 0; i < s.hdr.n_grids; ++i) if (!s.hdr.is_hyperlatent[i]) return i; return 0; }();
         HIP_TRY(launch_i8_to_f32(s.ep.latent[g], s.d_dense, static_cast<size_t>(s.dense_h) * s.dense_w, st));
@@ -580,10 +747,10 @@ static int run_upsampling(Slot& s, hipStream_t st) {
 static int run_synthesis(Slot& s, hipStream_t st) {
     const Network& net = s.net;
     const int h = s.dense_h, w = s.dense_w;
-    if (s.use_fused_syn) {  // the fused kernel itself was launched for the whole group (ccd_batch_run_stage)
+    if (s.use_fused_syn || s.use_fused_dec) {  // the fused kernel itself was launched for the whole group (ccd_batch_run_stage)
         const int H = s.hdr.img_size[0], W = s.hdr.img_size[1];
         if (s.d_out != s.d_syn_out) HIP_TRY(launch_final_resize(s.d_syn_out, s.d_out, s.hdr.out_channels, h, w, H, W, s.hdr.final_upsampling_type, st));
-        if (s.bitdepth && !s.fused.write_planes)
+        if (s.bitdepth && !(s.use_fused_dec ? s.fdec.write_planes : s.fused.write_planes))
             HIP_TRY(launch_planes(s.d_out, s.d_plane[0], s.d_plane[1], s.d_plane[2], H, W, s.bitdepth, s.frame_data_type, st));
         return CCD_OK;
     }
@@ -626,9 +793,13 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
     if (stage == 1)
         for (const auto& u : b->ups_steps)
             HIP_TRY(launch_upsample_step(b->d_levels, b->d_zmap + u.first_z, u.n_z, u.max_w, u.max_h, st));
-    if (stage == 2)
+    if (stage == 2) {
         for (const auto& g : b->fused_groups)
             HIP_TRY(launch_syn_fused(b->d_fused + g.first, g.n, g.c_in, g.c, g.max_tx, g.max_ty, st));
+        for (const auto& g : b->fdec_groups)
+            HIP_TRY(launch_fused_dec(b->d_fdec + g.first_frame, static_cast<const char*>(b->d_fdec_work) + static_cast<size_t>(g.first_work) * 16,
+                                     g.n_work, g.c_in, g.c, g.lds, st));
+    }
     for (auto& sp : b->slots) {
         rc = (stage == 1) ? run_upsampling(*sp, st) : (stage == 2 ? run_synthesis(*sp, st) : CCD_ERR_ARG);
         if (rc < 0) return rc;
@@ -671,14 +842,26 @@ int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64) {
 int ccd_batch_slot_kernels(const ccd_batch* b, int slot) {
     if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
     const Slot& s = *b->slots[slot];
-    return (s.use_pipe ? 1 : 0) | (s.use_fused_syn ? 2 : 0);
+    return (s.use_pipe ? 1 : 0) | (s.use_fused_syn ? 2 : 0) | (s.use_fused_dec ? 4 : 0);
 }
 
 const float* ccd_batch_output(const ccd_batch* b, int slot) {
-    return (b && slot >= 0 && slot < static_cast<int>(b->slots.size())) ? b->slots[slot]->d_out : nullptr;
+    if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size())) return nullptr;
+    const Slot& s = *b->slots[slot];
+    if (s.use_fused_dec && !s.fdec.out) return nullptr;  // CCD_OPT_KEEP_FLOAT = 0: integer samples only
+    return s.d_out;
 }
 const float* ccd_batch_dense(const ccd_batch* b, int slot) {
-    return (b && slot >= 0 && slot < static_cast<int>(b->slots.size())) ? b->slots[slot]->d_dense : nullptr;
+    // the dense stack only exists on the unfused path (ccd_batch_set_option(b, CCD_OPT_FUSED_DEC, 0) before adding the slot)
+    return (b && slot >= 0 && slot < static_cast<int>(b->slots.size()) && !b->slots[slot]->use_fused_dec) ? b->slots[slot]->d_dense : nullptr;
+}
+int ccd_batch_set_option(ccd_batch* b, int option, int value) {
+    if (!b) return CCD_ERR_ARG;
+    switch (option) {
+        case CCD_OPT_FUSED_DEC: b->opt_fused_dec = value; return CCD_OK;
+        case CCD_OPT_KEEP_FLOAT: b->opt_keep_float = value; return CCD_OK;
+        default: return CCD_ERR_ARG;
+    }
 }
 const int8_t* ccd_batch_latent(const ccd_batch* b, int slot, int grid) {
     if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size())) return nullptr;
@@ -887,6 +1070,10 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
         if (d.owned) for (int p = 0; p < 3; ++p) if (d.plane[p]) (void)hipFree(d.plane[p]);
     ccd_batch_destroy(b);
     return rc < 0 ? rc : CCD_OK;
+}
+
+int ccd_debug_fd_profile(uint64_t* out16, int reset) {
+    return out16 ? fused_dec_profile(reinterpret_cast<unsigned long long*>(out16), reset) : CCD_ERR_ARG;
 }
 
 int ccd_debug_laplace_bounds(int device, const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* s, int64_t n,

@@ -67,4 +67,40 @@ struct SynthFused {
     int32_t bitdepth, write_planes;
 };
 
+// Whole float path of a cool-chic in ONE kernel (ccd_fused.hip): int8 latent pyramid -> learned upsampling ->
+// synthesis -> float and / or integer samples.  Nothing but the int8 grids is read from HBM.
+constexpr int kFdMaxLevels = 12;     // latent levels (4K "auto" rule: 9)
+constexpr int kFdMaxConv = 3;
+// index of the kron product w[a] * w[b] (a, b = position folded onto the first half of the symmetric 1-D filter)
+__host__ __device__ constexpr int k2_index(int a, int b) {
+    return a <= b ? a * 4 - a * (a - 1) / 2 + (b - a) : b * 4 - b * (b - 1) / 2 + (a - b);
+}
+struct FusedDec {
+    const int8_t* lat[kFdMaxLevels];  // latent (non-hyper) grids, finest first
+    int32_t lh[kFdMaxLevels], lw[kFdMaxLevels];
+    int32_t n_lv;
+    // products of the symmetric 1-D filters, f32-rounded like the 2-D kron kernel the reference materialises
+    // (upsampling.py:189-196, 312-325): k2u[i] = x2 transposed conv from level i + 1 to level i, k2p[i] = pre-concatenation
+    // conv applied at level i.  10 distinct values each for k = 8 / k = 7 (k2_index).
+    float k2u[kFdMaxLevels][10], k2p[kFdMaxLevels][10];
+    // synthesis parameters in MFMA order (one "quad" = the 4 output-row weights of one multiply-add step), all offsets
+    // in floats into `params`; the whole block [0, n_params) is staged in LDS
+    const float* params;
+    int32_t n_params;
+    int32_t n_tiles_hidden;           // hidden units / 4 (rounded up)
+    int32_t wq_off, b0_off;           // [n_tiles_hidden][NWV * 64], [n_tiles_hidden][4]
+    int32_t b1_off;                   // [CT][4]
+    int32_t stab_off, stabb_off;      // [NWS * 64], [CT][4]
+    int32_t conv_off[kFdMaxConv], convb_off[kFdMaxConv];  // [NWC * 64], [CT][4]
+    int32_t out_off, outb_off;        // [NWO * 64], [CT][4]
+    int32_t h, w;                     // size of the finest latent level = size of the synthesis output
+    int32_t c;                        // output channels
+    int32_t relu0, relu1, n_conv, conv_residual[kFdMaxConv], conv_relu[kFdMaxConv], has_stab;
+    int32_t margin;                   // halo of the tile, even, >= n_conv
+    int32_t tiles_x, tiles_y;
+    float* out;                       // [c][h][w] f32 or null
+    void* plane[3];
+    int32_t bitdepth, write_planes;
+};
+
 }  // namespace ccd

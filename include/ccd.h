@@ -136,12 +136,22 @@ int ccd_batch_slot_status(const ccd_batch* b, int slot);
  * `out64` receives 64 words. */
 int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64);
 /* Which kernels serve this slot: bit 0 = pipelined entropy kernel (else the generic int64 one),
- * bit 1 = fused synthesis kernel (else one launch per layer). */
+ * bit 1 = fused synthesis kernel (else one launch per layer), bit 2 = the whole float path (upsampling +
+ * synthesis + integer samples) in one kernel, ccd_fused.hip. */
 int ccd_batch_slot_kernels(const ccd_batch* b, int slot);
+
+/* Batch options, to be set before the slots they concern are added:
+ *   CCD_OPT_FUSED_DEC   1 (default): slots whose architecture the fused float kernel covers (every decoder preset of
+ *                       the reference, cfg/dec) run it; 0: unfused path (per-level upsampling launches + synthesis
+ *                       kernel), which materialises the dense stack ccd_batch_dense() returns.
+ *   CCD_OPT_KEEP_FLOAT  1 (default): the f32 synthesis output is always written (ccd_batch_output);
+ *                       0: slots that produce integer planes directly (rgb / yuv444 intra frames) write only those. */
+enum { CCD_OPT_FUSED_DEC = 1, CCD_OPT_KEEP_FLOAT = 2 };
+int ccd_batch_set_option(ccd_batch* b, int option, int value);
 
 /* Device pointers of a slot's results (valid until the batch is destroyed / re-run): */
 const float* ccd_batch_output(const ccd_batch* b, int slot);    /* [C][H][W] f32, synthesis output */
-const float* ccd_batch_dense(const ccd_batch* b, int slot);     /* [L][H0][W0] f32, Upsampling.forward */
+const float* ccd_batch_dense(const ccd_batch* b, int slot);     /* [L][H0][W0] f32, Upsampling.forward; NULL on the fused path */
 const int8_t* ccd_batch_latent(const ccd_batch* b, int slot, int grid); /* [h][w] int8 */
 /* Integer planes (value = round(x * (2^bitdepth-1)) after the reference's clamp/round/420 chain):
  * plane p of the frame, uint8 if bitdepth == 8 else uint16; chroma planes are half size for yuv420. */
@@ -245,6 +255,10 @@ int ccd_compute_rate(int device, void* stream, const float* x, const float* mu, 
  * left[i], right[i] as the entropy kernel sees them (exhaustive parity tests of the f64 CDF). */
 int ccd_debug_laplace_bounds(int device, const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* s,
                              int64_t n, uint32_t* left, uint32_t* right);
+
+/* Profile builds only (-DCCD_FD_PROFILE): cycles per phase of the fused float kernel, summed over wave 0 of every
+ * workgroup since the last reset; returns 1 with out16 filled, 0 when the library was built without the counters. */
+int ccd_debug_fd_profile(uint64_t* out16, int reset);
 
 #ifdef __cplusplus
 }
