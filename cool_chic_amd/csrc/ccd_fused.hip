@@ -9,28 +9,32 @@
 //   bitstream/decode.py:191-206, io/format/png.py:57        rounding / clamping to integer samples
 //
 // Numerics contract (unchanged from ccd_float.hip / ccd_synth_fused.hip): every output is the oracle's fmaf chain in
-// the oracle's order (oracle/cc_oracle.c sections 8-9).  The synthesis chains run on the matrix cores:
+// the oracle's order (oracle/cc_oracle.c sections 8-9).  ALL chains run on the matrix cores:
 // v_mfma_f32_4x4x1_16b_f32 computes D[i] = fma(A[i], B, C[i]) per lane with ONE rounding per product and accumulates in
 // issue order (tools/ubench/mfma_probe.hip: 0 of 51 200 words differ from the __fmaf_rn chain), so a chain of such
-// instructions IS the fmaf chain, four output channels at a time.  The upsampling chains are explicit __fmaf_rn on the
-// vector ALU.  The file is compiled with -ffp-contract=off.
+// instructions IS the fmaf chain, four outputs at a time.  The file is compiled with -ffp-contract=off.
+//
+// Why the matrix cores for a ~1 kMAC/pixel network: a wave issues one instruction every ~5-7 cycles here whatever its
+// type, so the kernel is bound by its INSTRUCTION COUNT; one 4x4x1 MFMA step replaces four v_fma of four different
+// outputs, and its weights come from a register that holds 16 steps (CBSZ / ABID broadcast), not from loads.
 //
 // Structure.  A 256-thread workgroup owns a 64 x 32 "extended" tile of the finest level (interior + an even halo margin
-// >= the number of 3x3 layers) and walks the pyramid coarse -> fine inside LDS:
-//   S1  the int8 latents of every level's footprint -> f32 tiles in LDS (zero outside the grid: the pre-concatenation
-//       conv pads with zeros);
-//   S2  level i = L-2 .. 1: every channel c >= i on the level's footprint from level i + 1 (x2 transposed conv, replicate
-//       padding = clamped coordinates) and the level's own latent (7x7 conv + residual), ping-pong between two LDS stacks.
-//       A level needs rows [q - 2, q + 2] of the level below for its quad rows q, so footprints shrink by half and stop
-//       at ~10 x 10: recomputing the coarse levels per tile costs a few % of the tile;
-//   S3  level 0: a lane owns a 2 x 2 quad of pixels (= 4 "sets" of 64 pixels per wave, lane = pixel in each set) and
-//       computes its L dense values per pixel in registers; they go straight into the matrix cores as B operands:
-//       first 1x1 layer (hidden units in tiles of 4 = the 4 rows of the MFMA), ReLU, second 1x1 layer and the
-//       stabiliser, all in registers.  The A operands (weights) are one VGPR per 16 multiply-add steps: CBSZ / ABID
-//       broadcast one of the 16 blocks' A rows to all blocks, so the 4 weights of step q sit in lanes 4 (q % 16) .. + 3;
-//   S4  the 3x3 layers ping-pong between two LDS tiles; each tap is one MFMA step whose B operand is a register of the
-//       lane's 4 x 4 window; the last layer continues into the stabiliser add, the output transform (MFMA again) and
-//       the stores.
+// >= the number of 3x3 layers) and walks the pyramid coarse -> fine inside LDS.  Level i's footprint is rows / columns
+// [q0 - 2, q1 + 2] of the quads (2 x 2 outputs) the level above needs; footprints shrink by half per level and stop at
+// ~10 x 10, so recomputing the coarse levels per tile costs a few % of the tile.  Every LDS buffer has a compile-time
+// pitch and holds its footprint UNCLIPPED: positions outside the grid carry what the reference's padding gives them
+// (replicate for the x2 filters and the 3x3 layers, zero for the 7x7 filter's input), written by the producer.  So a
+// consumer's window is ONE base address plus immediate offsets - no clamps, no per-sample address arithmetic:
+//   S1  the int8 latents of every level's footprint (+ 4) -> f32 tiles in LDS, zero outside the grid;
+//   S2  phase A: channel i of level i = the level's own latent through the 7x7 pre-concatenation filter (the plain latent at
+//       the coarsest level), all levels at once; phase B: level i = L-2 .. 1, channels > i from level i + 1 (x2 filter).
+//       A lane owns a 2 x 2 output quad = the 4 rows of the MFMA, one step per sample of its source window;
+//   S3  level 0: the lane's L dense values per pixel stay in registers and feed the first 1x1 layer (hidden units in tiles
+//       of 4 = the 4 rows), ReLU, second 1x1 layer and the stabiliser, all in registers (4 "sets" of 64 pixels per wave);
+//   S4  the 3x3 layers ping-pong between two LDS tiles; each tap is one step whose B operand is a register of the lane's
+//       4 x 4 window; the last layer continues into the stabiliser add, the output transform and the stores.
+// A quad outside the grid is evaluated at the clamped quad and each of its positions takes the output of the clamped
+// position (replicate), only in tiles that touch the border.
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -40,55 +44,46 @@
 namespace ccd {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kFdThreads = 256;
-constexpr int kFdEW = 64, kFdEH = 32;  // extended tile of the finest level
-constexpr int kFdTilePx = kFdEW * kFdEH;
+constexpr int kFdEW = 64, kFdEH = 32;            // extended tile of the finest level
+constexpr int kFdTP = 68, kFdTRows = 34;         // 3x3-layer tiles: pitch / rows incl. one guard row + column on every side
+constexpr int kFdTileCh = kFdTP * kFdTRows;      // words per channel
 
-// Largest footprint of level i for a 64 x 32 tile whose origin is even (rows, cols); see the header comment.
+// Largest footprint of level i for a 64 x 32 tile whose origin is even (rows, cols): 32 -> 16 quads + 4 = 20 -> <= 11 + 4 ...
 __host__ __device__ constexpr int fd_reg_h(int i) { return i == 0 ? 32 : i == 1 ? 20 : i == 2 ? 15 : i == 3 ? 12 : i == 4 ? 11 : 10; }
 __host__ __device__ constexpr int fd_reg_w(int i) { return i == 0 ? 64 : i == 1 ? 36 : i == 2 ? 23 : i == 3 ? 16 : i == 4 ? 13 : i == 5 ? 11 : 10; }
-__host__ __device__ constexpr int fd_lat_elems(int i) { return ((fd_reg_h(i) + 6) * (fd_reg_w(i) + 6) + 3) & ~3; }
+__host__ __device__ constexpr int fd_pl(int i) { return fd_reg_h(i) * fd_reg_w(i); }  // plane of a level's channel (pitch fd_reg_w)
+// latent tiles: footprint + 4 on every side (3 for the 7x7 filter, 1 because a quad may start one row above the footprint),
+// origin column moved left to an odd coordinate so that 7x7 windows start 8-byte aligned; even pitch
+__host__ __device__ constexpr int fd_lat_h(int i) { return fd_reg_h(i) + 8; }
+__host__ __device__ constexpr int fd_lat_p(int i) { return (fd_reg_w(i) + 9 + 1) & ~1; }
+__host__ __device__ constexpr int fd_lat_elems(int i) { return fd_lat_h(i) * fd_lat_p(i); }
+// most quads of level i (S2 wave-items of 64 quads)
+__host__ __device__ constexpr int fd_max_q(int i) { return (fd_reg_h(i) / 2 + 1) * (fd_reg_w(i) / 2 + 1); }
 
-__host__ __device__ constexpr int fd_lat_prefix(int i) { int n = 0; for (int j = 1; j < i; ++j) n += fd_lat_elems(j); return n; }  // levels 1 .. i - 1
-
-struct FdLayout {  // offsets in 4-byte words into the workgroup's dynamic LDS (scalars only: no dynamically indexed arrays)
-    int geom, k2, params, lat0, lat_rest, va, vb, pc, tile_a, tile_b, total;
-};
-// Channel i of level i (the level's own pre-concatenation conv, or the latent itself at the coarsest level) has its own
-// slot per level: all of them are produced up front in one phase.
-__host__ __device__ constexpr int fd_pc_prefix(int i) { int n = 0; for (int j = 1; j < i; ++j) n += fd_reg_h(j) * fd_reg_w(j); return n; }
-
-__host__ __device__ inline FdLayout fd_layout(int n_lv, int c, int n_conv, int n_params) {
-    FdLayout L;
+// LDS layout in 4-byte words; everything but the total is a compile-time function of (levels, channels)
+struct FdLayout { int k2, lat0, va, pc1, rest, vb, tile_a, tile_b, par; };
+__host__ __device__ constexpr int fd_lat_off_rel(int i) { int n = 0; for (int j = 1; j < i; ++j) n += fd_lat_elems(j); return n; }  // levels >= 1, from `rest`
+__host__ __device__ constexpr int fd_pc_off_rel(int cin, int i) { int n = fd_lat_off_rel(cin); for (int j = 2; j < i; ++j) n += fd_pl(j); return n; }  // levels >= 2
+__host__ __device__ constexpr FdLayout fd_layout(int cin, int c) {
+    FdLayout L{};
     int o = 0;
-    L.geom = o; o += 2 * 8 * kFdMaxLevels;
-    L.k2 = o; o += 2 * 10 * kFdMaxLevels;
-    L.params = o; o += (n_params + 3) & ~3;
+    L.k2 = o; o += 24 * cin;                                  // [level][x2 | 7x7][12]: 10 kron products, then zeros
     L.lat0 = o; o += fd_lat_elems(0);
-    L.va = o; o += (n_lv > 2 ? n_lv - 2 : 0) * fd_reg_h(1) * fd_reg_w(1);   // level 1 (3, 5, ..): channels 2 .. L-1
-    L.pc = o; o += fd_pc_prefix(n_lv);
-    const int mid = o;
-    L.lat_rest = o; o += fd_lat_prefix(n_lv);
-    L.vb = o; o += (n_lv > 3 ? n_lv - 3 : 0) * fd_reg_h(2) * fd_reg_w(2);   // level 2 (4, 6, ..): channels 3 .. L-1
-    // conv tiles alias the pyramid: A is written at the end of S3 (the coarse levels are dead), B only in S4
-    const int tile = c * kFdTilePx;
-    L.tile_a = mid; L.tile_b = L.lat0;
-    if (n_conv >= 2 && mid - L.lat0 < tile) L.tile_a = L.lat0 + tile;
-    if (n_conv >= 1 && L.tile_a + tile > o) o = L.tile_a + tile;
-    L.total = o;
+    L.va = o; o += (cin > 2 ? cin - 2 : 0) * fd_pl(1);       // levels 1, 3, ..: channels level + 1 .. L - 1
+    L.pc1 = o; o += fd_pl(1);
+    L.rest = o;                                               // latent tiles of levels >= 1, own channels of levels >= 2, stack B
+    L.vb = o + fd_pc_off_rel(cin, cin);
+    o = L.vb + (cin > 3 ? cin - 3 : 0) * fd_pl(2);           // levels 2, 4, ..
+    // 3x3-layer tiles alias the pyramid: A is written at the end of S3 (only lat0 / va / pc1 are still read), B in S4
+    const int tile = c * kFdTileCh;
+    L.tile_b = L.lat0; L.tile_a = L.rest;
+    if (L.rest - L.lat0 < tile) L.tile_a = L.lat0 + tile;
+    if (L.tile_a + tile > o) o = L.tile_a + tile;
+    L.par = (o + 3) & ~3;
     return L;
-}
-__host__ __device__ inline int fd_pc_off(const FdLayout& L, int i) {  // LDS offset of channel i of level i (i >= 1)
-    int n = 0;
-    for (int j = 1; j < kFdMaxLevels; ++j) n += j < i ? fd_reg_h(j) * fd_reg_w(j) : 0;
-    return L.pc + n;
-}
-__host__ __device__ inline int fd_lat_off(const FdLayout& L, int i) {  // LDS offset of level i's latent tile
-    if (i == 0) return L.lat0;
-    int n = 0;
-    for (int j = 1; j < kFdMaxLevels; ++j) n += j < i ? fd_lat_elems(j) : 0;
-    return L.lat_rest + n;
 }
 
 extern __shared__ __attribute__((aligned(16))) float fd_smem[];
@@ -98,6 +93,13 @@ __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
         f(std::integral_constant<int, I>{});
         static_for<I + 1, N>(f);
+    }
+}
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_down(F&& f) {  // I, I - 1, .., N
+    if constexpr (I >= N) {
+        f(std::integral_constant<int, I>{});
+        static_for_down<I - 1, N>(f);
     }
 }
 
@@ -122,28 +124,58 @@ __device__ __forceinline__ unsigned fd_quantise(float x, float maxv) {
     return static_cast<unsigned>(r);
 }
 
-
-// The upsampling filters run on the matrix cores too: a lane owns a 2 x 2 output quad, the 4 rows of the MFMA are the 4
-// outputs (row = 2 dy + dx), one step per sample of the lane's source window.  A sample that an output does not use has
-// weight 0 for that row: fma(v, 0, acc) == acc bit for bit (v is finite, acc is never -0), so every output still sees
-// exactly its own taps, in its own order.
+// The upsampling filters as MFMA steps: the 4 rows are the 4 outputs of the lane's quad (row = 2 dy + dx), one step per
+// sample of the lane's source window.  A sample that an output does not use has weight 0 for that row:
+// fma(v, 0, acc) == acc bit for bit (v is finite, acc is never -0), so every output sees exactly its own taps in its own order.
 //
 // x2 transposed conv (k = 8, replicate pad 4, crop 11): 5 x 5 window v[a][b] = source (qy - 2 + a, qx - 2 + b).  Output row
 // 2 qy uses ky = 1, 3, 5, 7 on window rows 3, 2, 1, 0, output row 2 qy + 1 uses ky = 0, 2, 4, 6 on rows 4, 3, 2, 1 (same
 // for columns): taps in ky, kx ascending order = window rows and columns DESCENDING.  Step s <-> (a, b) = (4 - s / 5, 4 - s % 5).
-__device__ __forceinline__ void fd_tconv_weights(const float* k2 /*10 kron products, LDS*/, int lane, float (&wt)[2]) {
+// Pre-concatenation 7x7 conv (zero padding, + residual): 8 x 8 window v[a][b] = latent (2 qy - 3 + a, 2 qx - 3 + b), zeros
+// outside the grid (a zero sample contributes nothing, which is the oracle's skipping of those taps).  Output (dy, dx)
+// uses tap (ky, kx) = (a - dy, b - dx); step s <-> (a, b) = (s / 8, s % 8), ascending.
+//
+// The weight of (lane, step) is one of the 10 kron products of the level's filter (k2_index) or zero; WHICH one depends on
+// the lane and the step only: 4-bit table indices for the 2 + 4 weight registers, packed once per kernel.
+__device__ __forceinline__ uint32_t fd_weight_indices(int lane) {
     const int ph = lane & 3, dy = ph >> 1, dx = ph & 1;
+    uint32_t pack = 0;
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
         const int st = 16 * v + (lane >> 2);
         const int a = 4 - st / 5, b = 4 - st % 5;
         const int ky = dy == 0 ? 2 * (3 - a) + 1 : 2 * (4 - a), kx = dx == 0 ? 2 * (3 - b) + 1 : 2 * (4 - b);
         const bool ok = st < 25 && ky >= 0 && ky < 8 && kx >= 0 && kx < 8;
-        const int fy = ky < 4 ? ky : 7 - ky, fx = kx < 4 ? kx : 7 - kx;  // symmetric filter (a b c d d c b a)
-        wt[v] = ok ? k2[k2_index(fy & 3, fx & 3)] : 0.0f;
+        const int fy = ky < 4 ? ky : 7 - ky, fx = kx < 4 ? kx : 7 - kx;  // symmetric filter (a b c d d c b a), upsampling.py:42-64
+        pack |= static_cast<uint32_t>(ok ? k2_index(fy & 3, fx & 3) : 10) << (4 * v);
     }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int st = 16 * v + (lane >> 2);
+        const int ky = st / 8 - dy, kx = st % 8 - dx;
+        const bool ok = ky >= 0 && ky < 7 && kx >= 0 && kx < 7;
+        const int fy = ky < 4 ? ky : 6 - ky, fx = kx < 4 ? kx : 6 - kx;  // symmetric filter (a b c d c b a)
+        pack |= static_cast<uint32_t>(ok ? k2_index(fy & 3, fx & 3) : 10) << (4 * (2 + v));
+    }
+    return pack;
 }
-__device__ __forceinline__ f32x4 fd_tconv_quad(const float (&v)[5][5], const float (&wt)[2]) {
+__device__ __forceinline__ void fd_tconv_weights(const float* k2 /*12-entry table, LDS*/, uint32_t pack, float (&wt)[2]) {
+#pragma unroll
+    for (int v = 0; v < 2; ++v) wt[v] = k2[(pack >> (4 * v)) & 15u];
+}
+__device__ __forceinline__ void fd_preconv_weights(const float* k2, uint32_t pack, float (&wt)[4]) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) wt[v] = k2[(pack >> (4 * (2 + v))) & 15u];
+}
+
+// 5 x 5 window at `base` (pitch P words) -> the quad's 4 outputs
+template <int P>
+__device__ __forceinline__ f32x4 fd_tconv_quad(const float* base, const float (&wt)[2]) {
+    float v[5][5];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b) v[a][b] = base[a * P + b];
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     static_for<0, 25>([&](auto ss) {
         constexpr int st = decltype(ss)::value;
@@ -151,21 +183,33 @@ __device__ __forceinline__ f32x4 fd_tconv_quad(const float (&v)[5][5], const flo
     });
     return acc;
 }
-// Pre-concatenation 7x7 conv (zero padding, + residual): 8 x 8 window v[a][b] = latent (2 qy - 3 + a, 2 qx - 3 + b), zeros
-// outside the grid (a zero sample contributes nothing, which is the oracle's skipping of those taps).  Output (dy, dx)
-// uses tap (ky, kx) = (a - dy, b - dx); step s <-> (a, b) = (s / 8, s % 8), ascending.
-__device__ __forceinline__ void fd_preconv_weights(const float* k2 /*10 kron products, LDS*/, int lane, float (&wt)[4]) {
-    const int ph = lane & 3, dy = ph >> 1, dx = ph & 1;
+// two independent quads interleaved: the 13-cycle dependent-accumulator latency hides behind the 9-cycle issue interval
+template <int P>
+__device__ __forceinline__ void fd_tconv_quad2(const float* base0, const float* base1, const float (&wt)[2], f32x4& r0, f32x4& r1) {
+    float v0[5][5], v1[5][5];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int st = 16 * v + (lane >> 2);
-        const int ky = st / 8 - dy, kx = st % 8 - dx;
-        const bool ok = ky >= 0 && ky < 7 && kx >= 0 && kx < 7;
-        const int fy = ky < 4 ? ky : 6 - ky, fx = kx < 4 ? kx : 6 - kx;  // symmetric filter (a b c d c b a)
-        wt[v] = ok ? k2[k2_index(fy & 3, fx & 3)] : 0.0f;
-    }
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int b = 0; b < 5; ++b) { v0[a][b] = base0[a * P + b]; v1[a][b] = base1[a * P + b]; }
+    f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0;
+    static_for<0, 25>([&](auto ss) {
+        constexpr int st = decltype(ss)::value;
+        a0 = mstep<st>(wt, v0[4 - st / 5][4 - st % 5], a0);
+        a1 = mstep<st>(wt, v1[4 - st / 5][4 - st % 5], a1);
+    });
+    r0 = a0; r1 = a1;
 }
-__device__ __forceinline__ f32x4 fd_preconv_quad(const float (&v)[8][8], const float (&wt)[4]) {
+// 8 x 8 window at `base` (8-byte aligned, even pitch P) -> the quad's 4 outputs incl. the residual
+template <int P>
+__device__ __forceinline__ f32x4 fd_preconv_quad(const float* base, const float (&wt)[4]) {
+    float v[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const f32x2 t = *reinterpret_cast<const f32x2*>(base + a * P + 2 * b);
+            v[a][2 * b] = t[0]; v[a][2 * b + 1] = t[1];
+        }
     f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
     static_for<0, 64>([&](auto ss) {
         constexpr int st = decltype(ss)::value;
@@ -175,12 +219,21 @@ __device__ __forceinline__ f32x4 fd_preconv_quad(const float (&v)[8][8], const f
     for (int ph = 0; ph < 4; ++ph) acc[ph] = acc[ph] + v[(ph >> 1) + 3][(ph & 1) + 3];
     return acc;
 }
+// output of the (clamped) position (cy, cx) among the 4 outputs of the quad that holds it
+__device__ __forceinline__ float fd_pick(f32x4 r, int cy, int cx) {
+    const int i = ((cy & 1) << 1) | (cx & 1);
+    return i == 0 ? r[0] : (i == 1 ? r[1] : (i == 2 ? r[2] : r[3]));
+}
 
-// S1 maps the threads of the workgroup onto a level's latent tile with a power-of-two row pitch: level 0 (tile <= 38 x 70)
-// 2 rows x 128 columns per round, level 1 (<= 26 x 42) 4 x 64, levels 2 .. 5 8 x 32, deeper levels 16 x 16.
-__host__ __device__ constexpr int fd_s1_shift(int i) { return i == 0 ? 7 : i == 1 ? 6 : i <= 5 ? 5 : 4; }
-__host__ __device__ constexpr int fd_s1_rounds(int i) { return ((fd_reg_h(i) + 6) * (1 << fd_s1_shift(i)) + 255) / 256; }
+// S1 maps the workgroup onto a level's latent tile with a power-of-two row pitch: level 0 (40 x 74) 2 rows x 128 columns
+// per round, level 1 (28 x 46) 4 x 64, deeper levels 8 x 32.
+__host__ __device__ constexpr int fd_s1_shift(int i) { return i == 0 ? 7 : i == 1 ? 6 : 5; }
+__host__ __device__ constexpr int fd_s1_rounds(int i) { return (fd_lat_h(i) + (kFdThreads >> fd_s1_shift(i)) - 1) / (kFdThreads >> fd_s1_shift(i)); }
 __host__ __device__ constexpr int fd_s1_slot(int i) { int n = 0; for (int j = 0; j < i; ++j) n += fd_s1_rounds(j); return n; }
+// S2 wave-items (64 quads / samples) of level i in phase A and per channel in phase B, and the wave that takes the first one
+__host__ __device__ constexpr int fd_wi_a(int cin, int i) { return ((i == cin - 1 ? fd_pl(i) : fd_max_q(i)) + 63) / 64; }
+__host__ __device__ constexpr int fd_rot_a(int cin, int i) { int n = 0; for (int j = 1; j < i; ++j) n += fd_wi_a(cin, j); return n & 3; }
+__host__ __device__ constexpr int fd_wi_q(int i) { return (fd_max_q(i) + 63) / 64; }
 
 struct FdWork { int32_t frame, tile_first, tile_count, pad; };
 
@@ -194,29 +247,28 @@ __device__ unsigned long long fd_prof[16];
 #define FDP_ADD(slot, t0) (void)(t0)
 #endif
 
-// CIN = latent levels = input channels of the synthesis, C = its output channels (both fix register arrays and the
-// immediate operands of the MFMA steps).
+// CIN = latent levels = input channels of the synthesis, C = its output channels (both fix register arrays, LDS layout
+// and the immediate operands of the MFMA steps).
 template <int CIN, int C>
 __global__ __launch_bounds__(kFdThreads, 2) void decode_fused_kernel(const FusedDec* __restrict__ frames, const FdWork* __restrict__ work) {
+    static_assert(CIN >= 2 && CIN <= kFdMaxLevels, "levels");
     constexpr int CT = (C + 3) / 4;                  // output-channel tiles of 4
     constexpr int NWV = (CIN + 4 * CT + 15) / 16;    // weight registers per hidden tile: CIN first-layer steps + 4 CT second-layer steps
     constexpr int NWS = (CIN * CT + 15) / 16;        // stabiliser
     constexpr int NWC = (9 * C * CT + 15) / 16;      // one 3x3 layer
     constexpr int NWO = (C * CT + 15) / 16;          // output transform
+    constexpr FdLayout L = fd_layout(CIN, C);
     typedef const float __attribute__((address_space(1)))* gcf_t;
     typedef const int8_t __attribute__((address_space(1)))* gci8_t;
 
     const FdWork wk = work[blockIdx.x];
     const FusedDec& p = frames[wk.frame];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n_lv = p.n_lv;
     const int H = p.h, W = p.w;
-    const FdLayout L = fd_layout(n_lv, C, p.n_conv, p.n_params);
-    int* const s_geom2 = reinterpret_cast<int*>(fd_smem + L.geom);
-    float* const s_k2 = fd_smem + L.k2;       // [level][x2 filter | pre-concatenation filter][10]
-    float* const s_par = fd_smem + L.params;
+    float* const s_k2 = fd_smem + L.k2;
+    float* const s_par = fd_smem + L.par;
 
-    // ---- parameters -> LDS once per workgroup (MFMA order, see FusedDec) --------------------------------------------
+    // ---- once per workgroup: parameters (MFMA order, see FusedDec) and filter tables -> LDS ----------------------------
     const unsigned long long tp0 = FDP_T();
     {
         const gcf_t src = (gcf_t)p.params;
@@ -224,11 +276,12 @@ __global__ __launch_bounds__(kFdThreads, 2) void decode_fused_kernel(const Fused
             const f32x4 v = *reinterpret_cast<const f32x4 __attribute__((address_space(1)))*>(src + i);
             *reinterpret_cast<f32x4*>(s_par + i) = v;
         }
+        for (int i = tid; i < CIN * 24; i += kFdThreads) {
+            const int lvl = i / 24, j = i - lvl * 24;
+            s_k2[i] = j < 10 ? p.k2u[lvl][j] : (j >= 12 && j < 22 ? p.k2p[lvl][j - 12] : 0.0f);
+        }
     }
-    for (int i = tid; i < n_lv * 20; i += kFdThreads) {
-        const int lvl = i / 20, j = i - lvl * 20;
-        s_k2[i] = j < 10 ? p.k2u[lvl][j] : p.k2p[lvl][j - 10];
-    }
+    const uint32_t wpack = fd_weight_indices(lane);
     FDP_ADD(0, tp0);
     const int RM = p.margin;
     const int iw = kFdEW - 2 * RM, ih = kFdEH - 2 * RM;
@@ -239,79 +292,66 @@ __global__ __launch_bounds__(kFdThreads, 2) void decode_fused_kernel(const Fused
     float* const out_f32 = p.out;
     void* const plane_ptr[3] = {p.plane[0], p.plane[1], p.plane[2]};
     const float maxv = static_cast<float>((1 << bitdepth) - 1);
+    const int qxl = lane & 31, qyl = lane >> 5;   // S3 / S4: a wave-pass is 32 x 2 quads (64 x 4 pixels)
 
     for (int tile = wk.tile_first; tile < wk.tile_first + wk.tile_count; ++tile) {
         const int by = tile / p.tiles_x, bx = tile - by * p.tiles_x;
         const int tx0 = bx * iw - RM, ty0 = by * ih - RM;  // image coordinate of extended (0, 0); both even
         const unsigned long long tp1 = FDP_T();
-        int* const s_geom = s_geom2 + (tile & 1) * (8 * kFdMaxLevels);  // double-buffered: written before the barrier below
-        // ---- footprints + S1 loads.  Level 0 = the tile clipped to the image; level i + 1 = rows / cols [q0 - 2, q1 + 2]
-        // clipped to the grid (grid i = ceil(grid 0 / 2^i)).  The footprints are wave-uniform scalar arithmetic; the latent
-        // bytes of every level's footprint (+ 3 on every side for the 7x7 conv, zero outside the grid) are requested
-        // back-to-back from clamped addresses (a conditional load makes the compiler wait at every join) and stored as f32
-        // after ONE wait.
-        int lv_th[kFdMaxLevels], lv_tw[kFdMaxLevels];      // tile size per level (static indices only)
-        int wi_off[kFdMaxLevels + 1];                       // first phase-A wave-item of level i (levels 1 .. n_lv - 1)
-        int ld_val[fd_s1_slot(kFdMaxLevels)];
-        unsigned long long ld_ok = 0;  // bit s: load slot s lies inside its grid (else the tile holds the zero padding)
-        static_assert(fd_s1_slot(kFdMaxLevels) <= 64, "one validity bit per load slot");
+        // S1 / S2 are chains of short dependent steps; S3 / S4 are long MFMA streams.  The two workgroups of a CU share each
+        // SIMD's issue slots and matrix pipe "by priority, then age": the latency-bound phases go first.
+        __builtin_amdgcn_s_setprio(2);
+        // ---- footprints (wave-uniform scalars, static indices): level 0 = the extended tile, level i + 1 = [q0 - 2, q1 + 2]
+        int ay[CIN], ax[CIN], fh[CIN], fw[CIN], gh[CIN], gw[CIN];
+        bool bord[CIN];  // the footprint leaves the grid: replicate handling needed at this level
         {
-            int y0 = max(ty0, 0), y1 = min(ty0 + kFdEH - 1, H - 1), x0 = max(tx0, 0), x1 = min(tx0 + kFdEW - 1, W - 1);
-            int n_wi = 0;
-            static_for<0, kFdMaxLevels>([&](auto ll) {
-                constexpr int lvl = decltype(ll)::value;
-                constexpr int SH = fd_s1_shift(lvl);
-                wi_off[lvl] = n_wi;
-                lv_th[lvl] = 0; lv_tw[lvl] = 1;
-                if (lvl < n_lv) {
-                    const int gh = (H + (1 << lvl) - 1) >> lvl, gw = (W + (1 << lvl) - 1) >> lvl;
-                    const int rh = y1 - y0 + 1, rw = x1 - x0 + 1, th = rh + 6, tw = rw + 6;
-                    const int qy0 = y0 >> 1, qx0 = x0 >> 1, nqy = (y1 >> 1) - qy0 + 1, nqx = (x1 >> 1) - qx0 + 1;
-                    if (tid == 0) {
-                        int* g = s_geom + 8 * lvl;
-                        g[0] = y0; g[1] = rh; g[2] = x0; g[3] = rw; g[4] = qy0; g[5] = nqx; g[6] = qx0; g[7] = nqy * nqx;
-                    }
-                    // phase A of S2 in wave-items of 64: pre-concatenation conv quads of levels 1 .. n_lv - 2, samples of the coarsest
-                    if (lvl >= 1) n_wi += ((lvl == n_lv - 1 ? rh * rw : nqy * nqx) + 63) >> 6;
-                    lv_th[lvl] = th; lv_tw[lvl] = tw;
-                    const gci8_t src = (gci8_t)p.lat[lvl];
-                    const int c = tid & ((1 << SH) - 1), rb = tid >> SH;
-                    const int x = x0 - 3 + c;
-                    const bool col_ok = c < tw && x >= 0 && x < gw;
-                    const int xc = fd_clamp(x, 0, gw - 1);
-                    static_for<0, fd_s1_rounds(lvl)>([&](auto kk) {
-                        constexpr int k = decltype(kk)::value;
-                        const int r = k * (kFdThreads >> SH) + rb, y = y0 - 3 + r;
-                        if (col_ok && r < th && y >= 0 && y < gh) ld_ok |= 1ull << (fd_s1_slot(lvl) + k);
-                        ld_val[fd_s1_slot(lvl) + k] = src[static_cast<size_t>(fd_clamp(y, 0, gh - 1)) * gw + xc];
-                    });
-                    if (lvl + 1 < n_lv) {
-                        const int hn = (H + (2 << lvl) - 1) >> (lvl + 1), wn = (W + (2 << lvl) - 1) >> (lvl + 1);
-                        y0 = max((y0 >> 1) - 2, 0); y1 = min((y1 >> 1) + 2, hn - 1);
-                        x0 = max((x0 >> 1) - 2, 0); x1 = min((x1 >> 1) + 2, wn - 1);
-                    }
-                }
+            int y0 = ty0, y1 = ty0 + kFdEH - 1, x0 = tx0, x1 = tx0 + kFdEW - 1;
+            static_for<0, CIN>([&](auto ll) {
+                constexpr int i = decltype(ll)::value;
+                ay[i] = y0; ax[i] = x0; fh[i] = y1 - y0 + 1; fw[i] = x1 - x0 + 1;
+                gh[i] = (H + (1 << i) - 1) >> i; gw[i] = (W + (1 << i) - 1) >> i;  // grid i = ceil(grid 0 / 2^i)
+                bord[i] = y0 < 0 || x0 < 0 || y1 > gh[i] - 1 || x1 > gw[i] - 1;
+                y0 = (y0 >> 1) - 2; y1 = (y1 >> 1) + 2; x0 = (x0 >> 1) - 2; x1 = (x1 >> 1) + 2;
             });
-            wi_off[kFdMaxLevels] = n_wi;
         }
+        // ---- S1: the latent bytes of every level's tile are requested back-to-back from clamped addresses (a conditional load
+        // makes the compiler wait at every join) and stored as f32 after ONE wait; zero outside the grid
+        int ld_val[fd_s1_slot(CIN)];
+        unsigned long long ld_ok = 0;  // bit s: slot s is a sample of the grid
+        static_assert(fd_s1_slot(CIN) <= 64, "one validity bit per load slot");
+        static_for<0, CIN>([&](auto ll) {
+            constexpr int i = decltype(ll)::value;
+            constexpr int SH = fd_s1_shift(i), RPR = kFdThreads >> SH;
+            const int oy = ay[i] - 4, ox = (ax[i] - 5) | 1;
+            const gci8_t src = (gci8_t)p.lat[i];
+            const int c = tid & ((1 << SH) - 1);
+            const int rb = SH == 7 ? (wave >> 1) : (SH == 6 ? wave : (tid >> SH));  // wave-uniform for the two big levels
+            const int x = ox + c;
+            const bool col_ok = c < fd_lat_p(i) && x >= 0 && x < gw[i];
+            const int xc = fd_clamp(x, 0, gw[i] - 1);
+            static_for<0, fd_s1_rounds(i)>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                const int r = k * RPR + rb, y = oy + r;
+                if (col_ok && r < fd_lat_h(i) && y >= 0 && y < gh[i]) ld_ok |= 1ull << (fd_s1_slot(i) + k);
+                ld_val[fd_s1_slot(i) + k] = src[static_cast<size_t>(fd_clamp(y, 0, gh[i] - 1)) * gw[i] + xc];
+            });
+        });
         FDP_ADD(10, tp1);
         const unsigned long long tq1 = FDP_T();
-        __syncthreads();  // the previous tile's LDS is dead (and the parameter block / this tile's footprints are visible)
+        __syncthreads();  // the previous tile's LDS is dead (and the parameter block is visible)
         FDP_ADD(11, tq1);
         const unsigned long long tq2 = FDP_T();
-        static_for<0, kFdMaxLevels>([&](auto ll) {
-            constexpr int lvl = decltype(ll)::value;
-            constexpr int SH = fd_s1_shift(lvl);
-            if (lvl < n_lv) {
-                float* const dst = fd_smem + fd_lat_off(L, lvl);
-                const int c = tid & ((1 << SH) - 1), rb = tid >> SH;
-                static_for<0, fd_s1_rounds(lvl)>([&](auto kk) {
-                    constexpr int k = decltype(kk)::value;
-                    const int r = k * (kFdThreads >> SH) + rb;
-                    if (c < lv_tw[lvl] && r < lv_th[lvl])
-                        dst[r * lv_tw[lvl] + c] = ((ld_ok >> (fd_s1_slot(lvl) + k)) & 1ull) ? static_cast<float>(ld_val[fd_s1_slot(lvl) + k]) : 0.0f;
-                });
-            }
+        static_for<0, CIN>([&](auto ll) {
+            constexpr int i = decltype(ll)::value;
+            constexpr int SH = fd_s1_shift(i), RPR = kFdThreads >> SH, P = fd_lat_p(i);
+            float* const dst = fd_smem + (i == 0 ? L.lat0 : L.rest + fd_lat_off_rel(i));
+            const int c = tid & ((1 << SH) - 1), rb = tid >> SH;
+            static_for<0, fd_s1_rounds(i)>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                const int r = k * RPR + rb;
+                if (c < P && r < fd_lat_h(i))
+                    dst[r * P + c] = ((ld_ok >> (fd_s1_slot(i) + k)) & 1ull) ? static_cast<float>(ld_val[fd_s1_slot(i) + k]) : 0.0f;
+            });
         });
         FDP_ADD(12, tq2);
         const unsigned long long tq3 = FDP_T();
@@ -319,124 +359,102 @@ __global__ __launch_bounds__(kFdThreads, 2) void decode_fused_kernel(const Fused
         FDP_ADD(13, tq3);
         FDP_ADD(1, tp1);
         const unsigned long long tp2 = FDP_T();
-        // ---- S2: the coarse levels.  Level i holds channels i .. L-1 on footprint i: channel i in its own slot, channels > i in
-        // stack A (odd levels) or B (even levels).  A lane owns a 2 x 2 quad; a wave-item = 64 quads of ONE level (the filter is
-        // the A operand of the MFMA, shared by the wave); surplus lanes recompute the last quad and store nothing.
-        // Phase A: channel i of every level i >= 1 depends on the level's own latent only: pre-concatenation conv (7x7 + residual)
-        // for i <= L-2, the latent itself at the coarsest level (upsampling.py:486-498).
-        {
-            const int total = wi_off[kFdMaxLevels];
-#pragma unroll 1
-            for (int wi = wave; wi < total; wi += kFdThreads / 64) {
-                int lvl = 1;
-                static_for<2, kFdMaxLevels>([&](auto ll) { constexpr int l2 = decltype(ll)::value; lvl += (l2 < n_lv && wi >= wi_off[l2]) ? 1 : 0; });
-                int wi0 = 0;
-                static_for<1, kFdMaxLevels>([&](auto ll) { constexpr int l2 = decltype(ll)::value; wi0 = l2 == lvl ? wi_off[l2] : wi0; });
-                lvl = __builtin_amdgcn_readfirstlane(lvl);
-                const int* g = s_geom + 8 * lvl;
-                const int ry0 = g[0], rh = g[1], rx0 = g[2], rw = g[3], qy0 = g[4], nqx = g[5], qx0 = g[6], nq = g[7];
-                const float* const lat = fd_smem + fd_lat_off(L, lvl);
-                float* const dst = fd_smem + fd_pc_off(L, lvl);
-                const int ltw = rw + 6;
-                const int q_raw = (wi - wi0) * 64 + lane;
-                if (lvl == n_lv - 1) {
-                    if (q_raw < rh * rw) {
-                        int r = static_cast<int>((static_cast<float>(q_raw) + 0.5f) / static_cast<float>(rw)), c = q_raw - r * rw;
-                        if (c < 0) { --r; c += rw; }
-                        if (c >= rw) { ++r; c -= rw; }
-                        dst[q_raw] = lat[(r + 3) * ltw + c + 3];
-                    }
-                    continue;
+
+        // ---- S2 phase A: channel i of level i on footprint i, levels 1 .. L-1 (upsampling.py:486-498) ------------------------
+        static_for<1, CIN>([&](auto ll) {
+            constexpr int i = decltype(ll)::value;
+            constexpr int PL = fd_lat_p(i), PD = fd_reg_w(i);
+            const float* const lat = fd_smem + L.rest + fd_lat_off_rel(i);
+            float* const dst = fd_smem + (i == 1 ? L.pc1 : L.rest + fd_pc_off_rel(CIN, i));
+            const int oy = ay[i] - 4, ox = (ax[i] - 5) | 1;
+            if constexpr (i == CIN - 1) {
+                // the coarsest level enters the pyramid as it is; replicate outside the grid
+                const float inv_fw = 1.0f / static_cast<float>(fw[i]);
+                for (int j = (wave - fd_rot_a(CIN, i)) & 3; j < fd_wi_a(CIN, i); j += 4) {
+                    const int e = j * 64 + lane;
+                    int r = static_cast<int>((static_cast<float>(e) + 0.5f) * inv_fw), c = e - r * fw[i];
+                    if (c < 0) { --r; c += fw[i]; }
+                    if (c >= fw[i]) { ++r; c -= fw[i]; }
+                    const int cy = fd_clamp(ay[i] + r, 0, gh[i] - 1), cx = fd_clamp(ax[i] + c, 0, gw[i] - 1);
+                    if (e < fh[i] * fw[i]) dst[r * PD + c] = lat[(cy - oy) * PL + (cx - ox)];
                 }
-                const int q = min(q_raw, nq - 1);
-                int qr = static_cast<int>((static_cast<float>(q) + 0.5f) / static_cast<float>(nqx)), qc = q - qr * nqx;
-                if (qc < 0) { --qr; qc += nqx; }
-                if (qc >= nqx) { ++qr; qc -= nqx; }
-                const int qy = qy0 + qr, qx = qx0 + qc;
+            } else {
+                const int qy0 = ay[i] >> 1, qx0 = ax[i] >> 1;
+                const int nqy = ((ay[i] + fh[i] - 1) >> 1) - qy0 + 1, nqx = ((ax[i] + fw[i] - 1) >> 1) - qx0 + 1, nq = nqy * nqx;
+                const float inv_nqx = 1.0f / static_cast<float>(nqx);
                 float wt[4];
-                fd_preconv_weights(s_k2 + (lvl * 2 + 1) * 10, lane, wt);
-                float v[8][8];
-                const int wy = 2 * qy - ry0, wx = 2 * qx - rx0;  // window origin (2 qy - 3, 2 qx - 3) in tile coordinates
-                // a quad's first / last row or column may lie outside the footprint: the clamped reads only feed outputs
-                // that are not stored
+                bool have_wt = false;
+                for (int j = (wave - fd_rot_a(CIN, i)) & 3; j < fd_wi_a(CIN, i); j += 4) {
+                    if (j * 64 >= nq) break;
+                    if (!have_wt) { fd_preconv_weights(s_k2 + (i * 2 + 1) * 12, wpack, wt); have_wt = true; }
+                    const int q_raw = j * 64 + lane, q = min(q_raw, nq - 1);  // surplus lanes recompute the last quad and store nothing
+                    int qr = static_cast<int>((static_cast<float>(q) + 0.5f) * inv_nqx), qc = q - qr * nqx;
+                    if (qc < 0) { --qr; qc += nqx; }
+                    if (qc >= nqx) { ++qr; qc -= nqx; }
+                    const int qy = qy0 + qr, qx = qx0 + qc;
+                    const int cqy = bord[i] ? fd_clamp(qy, 0, (gh[i] - 1) >> 1) : qy, cqx = bord[i] ? fd_clamp(qx, 0, (gw[i] - 1) >> 1) : qx;
+                    const f32x4 o4 = fd_preconv_quad<PL>(lat + (2 * cqy - 3 - oy) * PL + (2 * cqx - 3 - ox), wt);
 #pragma unroll
-                for (int a = 0; a < 8; ++a) {
-                    const int ra = fd_clamp(wy + a, 0, rh + 5) * ltw;
+                    for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) v[a][b] = lat[ra + fd_clamp(wx + b, 0, rw + 5)];
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int y = 2 * qy + dy, x = 2 * qx + dx, r = y - ay[i], c = x - ax[i];
+                            if (q_raw < nq && r >= 0 && r < fh[i] && c >= 0 && c < fw[i])
+                                dst[r * PD + c] = bord[i] ? fd_pick(o4, fd_clamp(y, 0, gh[i] - 1), fd_clamp(x, 0, gw[i] - 1)) : o4[dy * 2 + dx];
+                        }
                 }
-                const f32x4 o4 = fd_preconv_quad(v, wt);
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        const int r = 2 * qy + dy - ry0, cidx = 2 * qx + dx - rx0;
-                        if (q_raw < nq && r >= 0 && r < rh && cidx >= 0 && cidx < rw) dst[r * rw + cidx] = o4[dy * 2 + dx];
-                    }
             }
-        }
+        });
         FDP_ADD(14, tp2);
-        // Phase B: level i = L-2 .. 1: channels c > i from level i + 1 (x2 transposed conv at clamped coordinates);
-        // wave-item = (channel, 64 quads)
-        for (int i = n_lv - 2; i >= 1; --i) {
+        // ---- S2 phase B: level i = L-2 .. 1: channels > i from level i + 1 through the x2 filter; wave-item = (channel, 64 quads).
+        // Level i holds channel i in its own slot and channels > i in stack A (odd levels) or B (even levels).
+        static_for_down<CIN - 2, 1>([&](auto ll) {
+            constexpr int i = decltype(ll)::value;
+            constexpr int PS = fd_reg_w(i + 1), PD = fd_reg_w(i), NCH = CIN - 1 - i, WQ = fd_wi_q(i);
             __syncthreads();
-            const int* g = s_geom + 8 * i;
-            const int ry0 = g[0], rh = g[1], rx0 = g[2], rw = g[3], qy0 = g[4], nqx = g[5], qx0 = g[6], nq = g[7];
-            const int sy0 = g[8], sh = g[9], sx0 = g[10], sw = g[11];
             float* const dst = fd_smem + ((i & 1) ? L.va : L.vb);
-            const float* const src = fd_smem + ((i & 1) ? L.vb : L.va);
-            const float* const src_pc = fd_smem + fd_pc_off(L, i + 1);
-            const int hs = (H + (2 << i) - 1) >> (i + 1), ws = (W + (2 << i) - 1) >> (i + 1);
-            float wt[2];
-            fd_tconv_weights(s_k2 + (i * 2) * 10, lane, wt);
-            const int n_ch = n_lv - 1 - i, wpc = (nq + 63) >> 6;  // wave-items per channel
-            const int plane_d = rh * rw, plane_s = sh * sw;
+            const float* const src_stack = fd_smem + ((i & 1) ? L.vb : L.va);
+            const float* const src_own = fd_smem + (i + 1 == 1 ? L.pc1 : L.rest + fd_pc_off_rel(CIN, i + 1));
+            const int qy0 = ay[i] >> 1, qx0 = ax[i] >> 1;
+            const int nqy = ((ay[i] + fh[i] - 1) >> 1) - qy0 + 1, nqx = ((ax[i] + fw[i] - 1) >> 1) - qx0 + 1, nq = nqy * nqx;
             const float inv_nqx = 1.0f / static_cast<float>(nqx);
+            float wt[2];
+            fd_tconv_weights(s_k2 + (i * 2) * 12, wpack, wt);
 #pragma unroll 1
-            for (int wi = wave; wi < wpc * n_ch; wi += kFdThreads / 64) {
-                const int ch = wi / wpc, q_raw = (wi - ch * wpc) * 64 + lane;
-                const int q = min(q_raw, nq - 1);
+            for (int t = (wave + i) & 3; t < NCH * WQ; t += 4) {
+                const int ch = t / WQ, j = t - ch * WQ;
+                if (j * 64 >= nq) continue;
+                const int q_raw = j * 64 + lane, q = min(q_raw, nq - 1);
                 int qr = static_cast<int>((static_cast<float>(q) + 0.5f) * inv_nqx), qc = q - qr * nqx;
                 if (qc < 0) { --qr; qc += nqx; }
                 if (qc >= nqx) { ++qr; qc -= nqx; }
                 const int qy = qy0 + qr, qx = qx0 + qc;
-                float v[5][5];
+                const int cqy = bord[i] ? fd_clamp(qy, 0, (gh[i] - 1) >> 1) : qy, cqx = bord[i] ? fd_clamp(qx, 0, (gw[i] - 1) >> 1) : qx;
                 // channel i + 1 + ch of level i + 1 (its own slot for ch == 0, else entry ch - 1 of the other stack) -> entry ch of this stack
-                const float* sp = ch == 0 ? src_pc : src + (ch - 1) * plane_s;
-                int ro[5], co[5];
-#pragma unroll
-                for (int d = 0; d < 5; ++d) {
-                    ro[d] = fd_clamp(fd_clamp(qy - 2 + d, 0, hs - 1) - sy0, 0, sh - 1) * sw;
-                    co[d] = fd_clamp(fd_clamp(qx - 2 + d, 0, ws - 1) - sx0, 0, sw - 1);
-                }
-#pragma unroll
-                for (int a = 0; a < 5; ++a)
-#pragma unroll
-                    for (int b = 0; b < 5; ++b) v[a][b] = sp[ro[a] + co[b]];
-                const f32x4 o4 = fd_tconv_quad(v, wt);
-                float* dp = dst + ch * plane_d;
+                const float* sp = (ch == 0 ? src_own : src_stack + (ch - 1) * fd_pl(i + 1)) + (cqy - 2 - ay[i + 1]) * PS + (cqx - 2 - ax[i + 1]);
+                const f32x4 o4 = fd_tconv_quad<PS>(sp, wt);
+                float* dp = dst + ch * fd_pl(i);
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 2; ++dx) {
-                        const int r = 2 * qy + dy - ry0, cidx = 2 * qx + dx - rx0;
-                        if (q_raw < nq && r >= 0 && r < rh && cidx >= 0 && cidx < rw) dp[r * rw + cidx] = o4[dy * 2 + dx];
+                        const int y = 2 * qy + dy, x = 2 * qx + dx, r = y - ay[i], c = x - ax[i];
+                        if (q_raw < nq && r >= 0 && r < fh[i] && c >= 0 && c < fw[i])
+                            dp[r * PD + c] = bord[i] ? fd_pick(o4, fd_clamp(y, 0, gh[i] - 1), fd_clamp(x, 0, gw[i] - 1)) : o4[dy * 2 + dx];
                     }
             }
-        }
+        });
         __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
         FDP_ADD(2, tp2);
         const unsigned long long tp3 = FDP_T();
 
-        // ---- S3: level 0 in registers + the 1x1 layers on the matrix cores -------------------------------------------
+        // ---- S3: level 0 in registers + the 1x1 layers -------------------------------------------------------------------
         // wave-pass = 32 x 2 quads (64 x 4 pixels); 8 passes per tile, wave w takes passes w and w + 4
         f32x4 stab[2][4][CT];  // stabiliser sums of the lane's pixels, kept for the epilogue
-        const int qxl = lane & 31, qyl = lane >> 5;
-        const int ry0_0 = s_geom[0], rh_0 = s_geom[1], rx0_0 = s_geom[2], rw_0 = s_geom[3];
-        const int lat0_w = rw_0 + 6;
-        const int sy1 = s_geom[8], sh1 = s_geom[9], sx1 = s_geom[10], sw1 = s_geom[11];
         float* const tile_a = fd_smem + L.tile_a;
         float* const tile_b = fd_smem + L.tile_b;
+        const bool bord0 = bord[0];
 
         // + stabiliser, output transform (synthesis.py:286-294), stores of the lane's 2 x 2 pixels
         auto epilogue = [&](int pass, f32x4 (&y)[4][CT], int ey, int ex) {
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(kFdThreads, 2) void decode_fused_kernel(const Fused
             });
             const int gy = ty0 + ey, gx = tx0 + ex;
             // interior of the tile and inside the image only
-            if (ey < RM || ey >= kFdEH - RM || ex < RM || ex >= kFdEW - RM || gy >= H || gx >= W) return;
+            if (ey < RM || ey >= kFdEH - RM || ex < RM || ex >= kFdEW - RM || gy < 0 || gx < 0 || gy >= H || gx >= W) return;
             const size_t plane = static_cast<size_t>(H) * W;
             const bool two_cols = gx + 1 < W, two_rows = gy + 1 < H;
             if (out_f32) {
@@ -496,10 +514,27 @@ __global__ __launch_bounds__(kFdThreads, 2) void decode_fused_kernel(const Fused
                     }
             }
         };
+        // values of the lane's quad -> a 3x3-layer tile; a position outside the image takes the value of its clamped position
+        auto store_tile = [&](float* tl, const f32x4 (&y)[4][CT], int ey, int ex) {
+            const int gy = ty0 + ey, gx = tx0 + ex;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int cy = fd_clamp(gy + (s >> 1), 0, H - 1), cx = fd_clamp(gx + (s & 1), 0, W - 1);
+#pragma unroll
+                for (int j = 0; j < C; ++j) {
+                    float v = y[s][j / 4][j % 4];
+                    if (bord0) {
+                        const int i4 = ((cy & 1) << 1) | (cx & 1);
+                        v = i4 == 0 ? y[0][j / 4][j % 4] : (i4 == 1 ? y[1][j / 4][j % 4] : (i4 == 2 ? y[2][j / 4][j % 4] : y[3][j / 4][j % 4]));
+                    }
+                    tl[j * kFdTileCh + (ey + (s >> 1) + 1) * kFdTP + ex + (s & 1) + 1] = v;
+                }
+            }
+        };
 
         float wt_u0[2], wt_p0[4];  // A operands of the level-0 filters
-        fd_tconv_weights(s_k2, lane, wt_u0);
-        fd_preconv_weights(s_k2 + 10, lane, wt_p0);
+        fd_tconv_weights(s_k2, wpack, wt_u0);
+        fd_preconv_weights(s_k2 + 12, wpack, wt_p0);
         unsigned long long tp3b = 0, tp4 = 0;
         (void)tp3b; (void)tp4;
 #pragma unroll
@@ -508,48 +543,31 @@ __global__ __launch_bounds__(kFdThreads, 2) void decode_fused_kernel(const Fused
             const int ey = 2 * qrow, ex = 2 * qxl;
             float x[CIN][4];                                   // dense values of the lane's 4 pixels
             {
-                // image quad coordinates (clamped in the halo outside the image: nothing reads those results back)
-                const int QY = fd_clamp((ty0 >> 1) + qrow, 0, (H - 1) >> 1), QX = fd_clamp((tx0 >> 1) + qxl, 0, (W - 1) >> 1);
-                const float* const lat0 = fd_smem + L.lat0;
-                if constexpr (CIN > 1) {
-                    const int hs = (H + 1) >> 1, ws = (W + 1) >> 1;
-                    int ro[5], co[5];
+                // the quad, clamped into the image in border tiles (replicate padding of the 3x3 layers: see store_tile)
+                const int QY0 = (ty0 >> 1) + qrow, QX0 = (tx0 >> 1) + qxl;
+                const int QY = bord0 ? fd_clamp(QY0, 0, (H - 1) >> 1) : QY0, QX = bord0 ? fd_clamp(QX0, 0, (W - 1) >> 1) : QX0;
+                const int base1 = (QY - 2 - ay[1]) * fd_reg_w(1) + (QX - 2 - ax[1]);
+                const float* const own1 = fd_smem + L.pc1 + base1;
+                const float* const st1 = fd_smem + L.va + base1;
+                // channels 1 .. CIN-1: level 1 through the x2 filter, two channels at a time
+                static_for<0, (CIN - 1) / 2>([&](auto gg) {
+                    constexpr int c0 = 1 + 2 * decltype(gg)::value, c1 = c0 + 1;
+                    f32x4 r0, r1;
+                    fd_tconv_quad2<fd_reg_w(1)>(c0 == 1 ? own1 : st1 + (c0 - 2) * fd_pl(1), st1 + (c1 - 2) * fd_pl(1), wt_u0, r0, r1);
 #pragma unroll
-                    for (int d = 0; d < 5; ++d) {
-                        ro[d] = fd_clamp(fd_clamp(QY - 2 + d, 0, hs - 1) - sy1, 0, sh1 - 1) * sw1;
-                        co[d] = fd_clamp(fd_clamp(QX - 2 + d, 0, ws - 1) - sx1, 0, sw1 - 1);
-                    }
-                    const float* const v1 = fd_smem + L.va;
-                    const float* const pc1 = fd_smem + L.pc;
-                    static_for<1, CIN>([&](auto cc) {
-                        constexpr int c = decltype(cc)::value;
-                        float v[5][5];
-                        const float* sp = c == 1 ? pc1 : v1 + (c - 2) * (sh1 * sw1);
+                    for (int s4 = 0; s4 < 4; ++s4) { x[c0][s4] = r0[s4]; x[c1][s4] = r1[s4]; }
+                });
+                if constexpr ((CIN - 1) % 2 == 1) {
+                    constexpr int c0 = CIN - 1;
+                    const f32x4 r0 = fd_tconv_quad<fd_reg_w(1)>(c0 == 1 ? own1 : st1 + (c0 - 2) * fd_pl(1), wt_u0);
 #pragma unroll
-                        for (int a = 0; a < 5; ++a)
-#pragma unroll
-                            for (int b = 0; b < 5; ++b) v[a][b] = sp[ro[a] + co[b]];
-                        const f32x4 o4 = fd_tconv_quad(v, wt_u0);
-#pragma unroll
-                        for (int s4 = 0; s4 < 4; ++s4) x[c][s4] = o4[s4];
-                    });
-                    float v[8][8];
-                    const int wy = 2 * QY - ry0_0, wx = 2 * QX - rx0_0;  // window origin (2 QY - 3, 2 QX - 3) in tile coordinates
-#pragma unroll
-                    for (int a = 0; a < 8; ++a) {
-                        const int ra = fd_clamp(wy + a, 0, rh_0 + 5) * lat0_w;
-#pragma unroll
-                        for (int b = 0; b < 8; ++b) v[a][b] = lat0[ra + fd_clamp(wx + b, 0, rw_0 + 5)];
-                    }
-                    const f32x4 o4 = fd_preconv_quad(v, wt_p0);
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) x[0][s4] = o4[s4];
-                } else {
-                    // a single level: dense = float(latent) (coolchic.py:175-177 with nothing to upsample)
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-                        x[0][s] = lat0[fd_clamp(2 * QY + (s >> 1) - ry0_0 + 3, 0, rh_0 + 5) * lat0_w + fd_clamp(2 * QX + (s & 1) - rx0_0 + 3, 0, rw_0 + 5)];
+                    for (int s4 = 0; s4 < 4; ++s4) x[c0][s4] = r0[s4];
                 }
+                // channel 0: the finest latent through the 7x7 filter
+                const int oy = ay[0] - 4, ox = (ax[0] - 5) | 1;
+                const f32x4 r0 = fd_preconv_quad<fd_lat_p(0)>(fd_smem + L.lat0 + (2 * QY - 3 - oy) * fd_lat_p(0) + (2 * QX - 3 - ox), wt_p0);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) x[0][s4] = r0[s4];
             }
             FDP_ADD(3 + pass, pass == 0 ? tp3 : tp3b);
             tp4 = FDP_T();
@@ -610,20 +628,14 @@ __global__ __launch_bounds__(kFdThreads, 2) void decode_fused_kernel(const Fused
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[s][t][r] = fd_relu(o[s][t][r]);
             }
-            if (n_conv > 0) {
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int j = 0; j < C; ++j) tile_a[j * kFdTilePx + (ey + (s >> 1)) * kFdEW + ex + (s & 1)] = o[s][j / 4][j % 4];
-            } else {
-                epilogue(pass, o, ey, ex);
-            }
+            if (n_conv > 0) store_tile(tile_a, o, ey, ex);
+            else epilogue(pass, o, ey, ex);
             FDP_ADD(5 + pass, tp4);
             tp3b = FDP_T();
         }
         const unsigned long long tp7 = FDP_T();
 
-        // ---- S4: 3x3 layers on the LDS tiles (replicate padding = clamped image coordinates); the last one runs the epilogue
+        // ---- S4: 3x3 layers on the LDS tiles (replicate padding was written by the producer); the last one runs the epilogue
         const float* cur = tile_a;
         float* nxt = tile_b;
         for (int l = 0; l < n_conv; ++l) {
@@ -637,22 +649,19 @@ __global__ __launch_bounds__(kFdThreads, 2) void decode_fused_kernel(const Fused
             for (int pass = 0; pass < 2; ++pass) {
                 const int qrow = 2 * (wave + 4 * pass) + qyl;
                 const int ey = 2 * qrow, ex = 2 * qxl;
-                const int gy = ty0 + ey, gx = tx0 + ex;
-                // 4 x 4 window of the quad at clamped image coordinates, as tile coordinates (halo positions whose window
-                // leaves the tile read a clamped copy: their results are never consumed)
-                int ro[4], co[4];
-#pragma unroll
-                for (int d = 0; d < 4; ++d) {
-                    ro[d] = fd_clamp(fd_clamp(gy - 1 + d, 0, H - 1) - ty0, 0, kFdEH - 1) * kFdEW;
-                    co[d] = fd_clamp(fd_clamp(gx - 1 + d, 0, W - 1) - tx0, 0, kFdEW - 1);
-                }
+                // the quad (clamped into the image in border tiles) and its 4 x 4 window, rows ey - 1 .. ey + 2 = tile rows ey .. ey + 3
+                const int cey = bord0 ? fd_clamp(ty0 + ey, 0, (H - 1) & ~1) - ty0 : ey, cex = bord0 ? fd_clamp(tx0 + ex, 0, (W - 1) & ~1) - tx0 : ex;
+                const float* const wb = cur + cey * kFdTP + cex;
                 float win[C][4][4];
 #pragma unroll
                 for (int ci = 0; ci < C; ++ci)
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) win[ci][a][b] = cur[ci * kFdTilePx + ro[a] + co[b]];
+                        for (int b = 0; b < 2; ++b) {
+                            const f32x2 t2 = *reinterpret_cast<const f32x2*>(wb + ci * kFdTileCh + a * kFdTP + 2 * b);
+                            win[ci][a][2 * b] = t2[0]; win[ci][a][2 * b + 1] = t2[1];
+                        }
                 f32x4 y[4][CT];
                 static_for<0, CT>([&](auto tt) {
                     constexpr int t = decltype(tt)::value;
@@ -680,14 +689,8 @@ __global__ __launch_bounds__(kFdThreads, 2) void decode_fused_kernel(const Fused
                         if (relu) v = fd_relu(v);
                         y[s][j / 4][j % 4] = v;
                     }
-                if (!fin) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s)
-#pragma unroll
-                        for (int j = 0; j < C; ++j) nxt[j * kFdTilePx + (ey + (s >> 1)) * kFdEW + ex + (s & 1)] = y[s][j / 4][j % 4];
-                } else {
-                    epilogue(pass, y, ey, ex);
-                }
+                if (!fin) store_tile(nxt, y, ey, ex);
+                else epilogue(pass, y, ey, ex);
             }
             const float* tswap = cur; cur = nxt; nxt = const_cast<float*>(tswap);
         }
@@ -716,7 +719,10 @@ int fused_dec_profile(unsigned long long* out16, int reset) {
 
 bool fused_dec_supports(int c_in, int c) { return c_in >= 5 && c_in <= 9 && c >= 2 && c <= 5; }
 
-size_t fused_dec_lds_bytes(int n_lv, int c, int n_conv, int n_params) { return static_cast<size_t>(fd_layout(n_lv, c, n_conv, n_params).total) * 4; }
+size_t fused_dec_lds_bytes(int n_lv, int c, int n_conv, int n_params) {
+    (void)n_conv;
+    return static_cast<size_t>(fd_layout(n_lv, c).par + ((n_params + 3) & ~3)) * 4;
+}
 
 void fused_dec_param_shape(int c_in, int c, int* nwv, int* nws, int* nwc, int* nwo) {
     const int ct = (c + 3) / 4;
