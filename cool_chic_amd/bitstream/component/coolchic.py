@@ -1,9 +1,13 @@
-"""encode_decode_coolchic(mode="decode") on the MI355X.
+"""encode_decode_coolchic on the MI355X.
 
 Mirror of coolchic/bitstream/component/coolchic.py:29-207 of the reference: same arguments, same
-return shape ([1, C, H, W] float32 tensor, None), same ValueError for missing arguments. The tensor
-lives on the GPU (the reference decoder is CPU-only and has no device argument; pass
-device="cpu" to get a host copy)."""
+return shape ([1, C, H, W] float32 tensor, None | bytes), same ValueError for missing arguments. The tensor
+lives on the GPU (the reference is CPU-only and has no device argument; pass device="cpu" to get a host copy).
+
+mode="encode" (the boundary's second caller, bitstream/encode.py:83-89): the quantised latents are range-coded by the
+bitstream writer, which walks the decoder's integer ARM / IFCE path on the host like the reference (latent.py:168-173);
+the header's n_bytes_latent is filled in, the returned bytes are header + NN payload + latent payload, and the
+synthesis output is what the decoder makes of exactly those bytes."""
 import ctypes as C
 from typing import List, Literal, Optional, Tuple
 
@@ -28,7 +32,21 @@ def encode_decode_coolchic(
                 "Trying to encode cool_chic latent without indicating the quantized latent value. "
                 "Found enc_quantized_latent=None. It should be a list of integer Tensor."
             )
-        raise NotImplementedError("the MI355X build accelerates the decode path only (SURVEY.md section 8)")
+        import numpy as np
+
+        from ... import writer
+
+        latents = [np.ascontiguousarray(t.detach().cpu().numpy()).reshape(t.shape[-2], t.shape[-1]) for t in enc_quantized_latent]
+        c = header.c
+        if len(latents) != c.n_grids or any(a.shape != (c.grid_h[g], c.grid_w[g]) for g, a in enumerate(latents)):
+            raise ValueError("enc_quantized_latent does not match the header's latent grids")
+        if any(a.min() < -64 or a.max() > 63 or not np.array_equal(a, np.round(a)) for a in latents if a.size):
+            raise ValueError("quantised latents must be integers in [-64, 63]")  # AC_MAX_VAL, constants.py:11
+        coolchic_bytes = writer.encode_coolchic(c, bytes_nn, [a.astype(np.int8) for a in latents])
+        rest = header.read_header(coolchic_bytes)  # the written header carries n_bytes_latent (coolchic.py:169)
+        dec_bytes_latent = rest[len(bytes_nn):]
+        out, _ = encode_decode_coolchic(header, bytes_nn, "decode", dec_bytes_latent=dec_bytes_latent, verbosity=verbosity, device=device)
+        return out, coolchic_bytes
     if mode == "decode" and dec_bytes_latent is None:
         raise ValueError(
             "Trying to encode cool_chic latent with dec_bytes_latent=None. "

@@ -106,54 +106,53 @@ def decode_video(bitstream_path: str, decoded_path: Optional[str] = None, max_de
             batch.close()
         print(f"Decoding {len(frames)} intra frame(s) time = {time.time() - start:6.2f} seconds.")
     else:
-        # P / B frames: frames arrive in coding order and name their references by display index
-        # (frame header); the reference recomputes the same from the coding structure (decode.py:54,70-73).
-        for coding_idx in range(max_decoding_order + 1):
-            start = time.time()
-            fh = FrameHeader()
-            fh.read_header(bitstream_bytes)
-            refs = [frames[r] for r in fh.get_value("index_references")]
-            frame_data, bitstream_bytes = decode_frame(bitstream_bytes, refs, verbosity, device)
-            frames[fh.get_value("display_index")] = frame_data
-            print(f"Decoding frame {fh.get_value('display_index'):<4} time = {time.time() - start:6.2f} seconds.")
+        # P / B frames: every cool-chic of every frame decodes in ONE batch (they do not depend on other frames,
+        # decode.py:132-153); the frames are then reconstructed in coding order (ccd_decode_video does the same)
+        start = time.time()
+        frames = _decode_gop(bitstream_bytes, max_decoding_order + 1, device, None, verbosity, sharded=False)
+        print(f"Decoding {len(frames)} frame(s) time = {time.time() - start:6.2f} seconds.")
+    # decode.py:84-89: one entry per display index of the sequence; frames beyond max_decoding_order stay None
     all_frames = {}
-    for display_idx in sorted(frames):
-        all_frames[str(display_idx)] = frames[display_idx]
-        if decoded_path is not None:
+    for display_idx in range(n_frames):
+        all_frames[str(display_idx)] = frames.get(display_idx)
+        if decoded_path is not None and display_idx in frames:
             save_frame_data_to_file(frames[display_idx], decoded_path, append=display_idx != 0)
     return all_frames
 
 
-@torch.no_grad()
-def decode_video_sharded(bitstream_path: str, device: int = 0, group=None) -> Dict[str, FrameData]:
-    """decode_video for one process per GPU (torch.distributed initialised by the caller; works unsharded without).
+def _decode_gop(rest: bytes, n_decode: int, device: int, group, verbosity: int = 0, collect: Optional[int] = 0,
+                sharded: bool = True) -> Dict[int, FrameData]:
+    """The first `n_decode` frames (coding order) of the frame payload `rest`: {display index: FrameData}.
 
-    Frame at coding index k belongs to rank k mod world_size.  Every rank first decodes ALL cool-chics of its own
-    frames in one DecodeBatch (residue and motion networks of every owned frame in flight together - they do not
-    depend on other frames, decode.py:132-153); then the frames are reconstructed in coding order on their owner
-    and their integer planes broadcast, because later frames warp them (decode.py:156-189).  Every rank returns the
-    whole sequence, like decode_video."""
+    With a process group, frame at coding index k belongs to rank k mod world_size: every rank decodes ALL cool-chics
+    of its own frames in one DecodeBatch (residue and motion networks in flight together), then the frames are
+    reconstructed in coding order on their owner; a frame's integer planes go point to point to the ranks whose frames
+    predict from it and to rank `collect`, which returns the whole sequence (other ranks: what they produced or used)."""
     import torch.distributed as dist
 
     from ..parallel import gop_owner, run_sharded_gop
-    from .intercoding import reconstruct_inter_frame
+    from .intercoding import _integer_planes, reconstruct_inter_frame
 
-    with open(bitstream_path, "rb") as f:
-        rest = f.read()
-    vh = VideoHeader()
-    rest = vh.read_header(rest)
-    n_frames = vh.get_value("n_frames")
-    initialised = dist.is_available() and dist.is_initialized()
+    initialised = sharded and dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if initialised else 1
     rank = dist.get_rank(group) if initialised else 0
     dev = torch.device(f"cuda:{device}")
     parsed = []
-    for _ in range(n_frames):
+    for _ in range(n_decode):
         fh, ccs, rest = _split_frame(rest)
+        if verbosity:
+            print(fh.pretty_string())
         parsed.append((fh, ccs))
     display = [fh.get_value("display_index") for fh, _ in parsed]
+    if len(set(display)) != len(display):
+        raise ValueError("two frames share a display index")
     coding_of_display = {d: k for k, d in enumerate(display)}
-    references = [[coding_of_display[r] for r in fh.get_value("index_references")] for fh, _ in parsed]
+    references = []
+    for k, (fh, _) in enumerate(parsed):
+        refs = [coding_of_display.get(r, n_decode) for r in fh.get_value("index_references")]
+        if any(r >= k for r in refs):
+            raise ValueError("a frame references a frame that is not decoded before it")
+        references.append(refs)
     specs = []
     for fh, ccs in parsed:
         h, w = ccs[0][0].c.img_size[0], ccs[0][0].c.img_size[1]
@@ -185,12 +184,27 @@ def decode_video_sharded(bitstream_path: str, device: int = 0, group=None) -> Di
                 return [torch.as_tensor(batch.plane_device(slots[k][0], p), device=dev).clone() for p in range(3)]
             outs = [torch.as_tensor(batch.output_device(s), device=dev) for s in slots[k]]
             ref_fd = [to_frame_data(r, pl) for r, pl in zip(references[k], refs)]
-            fd = reconstruct_inter_frame(fh, outs[0], outs[1], ref_fd)
-            from .intercoding import _integer_planes
+            return _integer_planes(reconstruct_inter_frame(fh, outs[0], outs[1], ref_fd), dev)
 
-            return _integer_planes(fd, dev)
-
-        done = run_sharded_gop(n_frames, specs, references, produce, device=dev, group=group)
+        if initialised:
+            done = run_sharded_gop(n_decode, specs, references, produce, device=dev, group=group, collect=collect)
+        else:  # one process: plain coding-order loop
+            done = {}
+            for k in range(n_decode):
+                done[k] = list(produce(k, [done[r] for r in references[k]]))
     finally:
         batch.close()
-    return {str(display[k]): to_frame_data(k, done[k]) for k in sorted(done, key=lambda k: display[k])}
+    return {display[k]: to_frame_data(k, done[k]) for k in done}
+
+
+@torch.no_grad()
+def decode_video_sharded(bitstream_path: str, device: int = 0, group=None, collect: Optional[int] = 0) -> Dict[str, FrameData]:
+    """decode_video for one process per GPU (torch.distributed initialised by the caller; works unsharded without).
+    Rank `collect` of the group returns the whole sequence like decode_video; the other ranks return the frames they
+    produced or received as references (see _decode_gop)."""
+    with open(bitstream_path, "rb") as f:
+        rest = f.read()
+    vh = VideoHeader()
+    rest = vh.read_header(rest)
+    frames = _decode_gop(rest, vh.get_value("n_frames"), device, group, collect=collect)
+    return {str(d): frames[d] for d in sorted(frames)}

@@ -33,6 +33,12 @@ def reconstruct_inter_frame(frame_header, residue: torch.Tensor, motion: torch.T
     n_refs = 2 if frame_type == "B" else 1
     if len(reference_frames) < n_refs:
         raise ValueError(f"a {frame_type} frame needs {n_refs} reference frame(s)")
+    for fd in reference_frames[:n_refs]:
+        # the references' planes are read with THIS frame's sample layout (a 4:2:0 reference has quarter-size chroma planes)
+        if fd.frame_data_type != fdt or fd.bitdepth != bitdepth:
+            raise ValueError(f"reference frame is {fd.frame_data_type} {fd.bitdepth}-bit, the frame is {fdt} {bitdepth}-bit")
+    if fdt == "yuv420" and (h % 2 or w % 2):
+        raise ValueError("4:2:0 frames need even sizes")
     refs = [_integer_planes(fd, dev) for fd in reference_frames[:n_refs]]
     dt = torch.uint8 if bitdepth == 8 else torch.uint16
     ch, cw = (h // 2, w // 2) if fdt == "yuv420" else (h, w)

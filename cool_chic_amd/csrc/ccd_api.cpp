@@ -239,6 +239,16 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     if (rc < 0) return rc;
     const ccd_cc_header& h = s.hdr;
     if (n_lat % 4) return CCD_ERR_VALUE;  // np.frombuffer(dtype=uint32) raises (rangecoder.py:81)
+    // The header parses, but the reference cannot decode it: after ONE x2 nearest upsample + crop of the decoded stack its
+    // torch.cat raises when consecutive grids differ by more than one level (latent and hyperlatent ranges that do not
+    // touch), and the transmitted grid count is the length of the size list (component/core/coolchic.py:170-185).  The
+    // entropy kernels index the coarser grid with (y >> 1, x >> 1): a larger gap would read past it.
+    if (h.n_latent_grids != h.n_grids) return CCD_ERR_VALUE;
+    for (int g = 1; g < h.n_grids; ++g) {
+        const bool same = h.grid_h[g] == h.grid_h[g - 1] && h.grid_w[g] == h.grid_w[g - 1];
+        const bool half = h.grid_h[g] == (h.grid_h[g - 1] + 1) / 2 && h.grid_w[g] == (h.grid_w[g - 1] + 1) / 2;
+        if (!same && !half) return CCD_ERR_VALUE;
+    }
     rc = decode_network(h, bytes_nn, n_nn, s.net);
     if (rc < 0) return rc;
     s.bitdepth = bitdepth; s.frame_data_type = frame_data_type;
@@ -1011,14 +1021,19 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
     if (rc >= 0) rc = ccd_batch_run(b, nullptr);
     if (rc >= 0) rc = ccd_batch_wait(b, nullptr);
     // ---- frame reconstruction in coding order; device planes of every decoded frame are kept for references ------
-    struct DevFrame { void* plane[3] = {nullptr, nullptr, nullptr}; int h = 0, w = 0, ch = 0, cw = 0, bitdepth = 0, fdt = 0; bool owned = false; };
+    struct DevFrame { void* plane[3] = {nullptr, nullptr, nullptr}; int h = 0, w = 0, ch = 0, cw = 0, bitdepth = 0, fdt = 0; bool owned = false, seen = false; };
     std::vector<DevFrame> dev(n_frames);  // by display index
     for (int f = 0; f < n_frames && rc >= 0; ++f) {
         const ccd_frame_header& fh = fhs[f];
         if (fh.display_index < 0 || fh.display_index >= n_frames) { rc = CCD_ERR_VALUE; break; }
         DevFrame& d = dev[fh.display_index];
+        if (d.seen) { rc = CCD_ERR_VALUE; break; }  // two frames with one display index: the second would overwrite (and leak) the first
+        d.seen = true;
         const Slot& s0 = *b->slots[first_slot[f]];
         d.h = s0.hdr.img_size[0]; d.w = s0.hdr.img_size[1]; d.bitdepth = fh.bitdepth; d.fdt = fh.frame_data_type;
+        // 4:2:0 needs even sizes: F.avg_pool2d(2) drops the odd row / column and write_yuv's chroma planes are h/2 x w/2,
+        // while the reference's 4:4:4 round trip of such a frame (yuv.py:303-316) no longer matches the luma size
+        if (fh.frame_data_type == 1 && ((d.h | d.w) & 1)) { rc = CCD_ERR_VALUE; break; }
         d.ch = fh.frame_data_type == 1 ? d.h / 2 : d.h; d.cw = fh.frame_data_type == 1 ? d.w / 2 : d.w;
         if (fh.frame_type == 0) {
             if (s0.hdr.out_channels < 3) { rc = CCD_ERR_VALUE; break; }
@@ -1030,7 +1045,10 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
             const void* refs[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
             for (int k = 0; k < fh.n_refs && rc >= 0; ++k) {
                 const int ri = fh.index_references[k];
-                if (ri < 0 || ri >= n_frames || !dev[ri].plane[0] || dev[ri].h != d.h || dev[ri].w != d.w || dev[ri].bitdepth != d.bitdepth) { rc = CCD_ERR_VALUE; break; }
+                // a reference must be a decoded frame of the same geometry AND sample layout: its planes are read with this
+                // frame's layout (a 4:2:0 reference has quarter-size chroma planes)
+                if (ri < 0 || ri >= n_frames || !dev[ri].plane[0] || dev[ri].h != d.h || dev[ri].w != d.w || dev[ri].bitdepth != d.bitdepth ||
+                    dev[ri].fdt != d.fdt) { rc = CCD_ERR_VALUE; break; }
                 for (int p = 0; p < 3; ++p) refs[k][p] = dev[ri].plane[p];
             }
             if (rc < 0) break;
@@ -1045,6 +1063,8 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
                                            fh.frame_type == 2 ? refs[1] : nullptr, fh.global_flow, fh.warp_filter_size, d.plane);
         }
     }
+    // every display index must have been produced (a gap would leave a frame without planes)
+    for (int i = 0; i < n_frames && rc >= 0; ++i) if (!dev[i].seen) rc = CCD_ERR_VALUE;
     if (rc >= 0) {
         v->frames = static_cast<ccd_frame*>(std::calloc(std::max(n_frames, 1), sizeof(ccd_frame)));
         v->n_frames = n_frames;
@@ -1057,6 +1077,7 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
             for (int p = 0; p < 3 && rc >= 0; ++p) {
                 const size_t px = p == 0 ? static_cast<size_t>(d.h) * d.w : static_cast<size_t>(d.ch) * d.cw;
                 fr.plane[p] = static_cast<uint16_t*>(std::malloc(px * 2 + 2));
+                if (!fr.plane[p]) { rc = CCD_ERR_NOMEM; break; }
                 if (d.bitdepth == 8) {
                     std::vector<uint8_t> tmp(px);
                     if (hipMemcpy(tmp.data(), d.plane[p], px, hipMemcpyDeviceToHost) != hipSuccess) rc = CCD_ERR_HIP;

@@ -648,7 +648,11 @@ int ccd_png_pack_batch(ccd_png* p, const ccd_png_item* items, int n, void* strea
         blk_off += J.nblk;
         row_off += it.h;
     }
-    hipError_t e = hipMemcpyAsync(p->d_jobs, jobs, static_cast<size_t>(n) * sizeof(PngJob), hipMemcpyHostToDevice, st);
+    // `jobs` is pageable and freed below: a synchronous copy (the table is a few hundred bytes per picture), so that the
+    // host buffer is certainly consumed when the call returns.  The device buffer may still be read by the previous
+    // batch's kernels on `st`: order the copy behind them.
+    hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpy(p->d_jobs, jobs, static_cast<size_t>(n) * sizeof(PngJob), hipMemcpyHostToDevice);
     int rc = e == hipSuccess ? CCD_OK : CCD_ERR_HIP;
     for (int first = 0; first < n && rc == CCD_OK; first += kMaxBatch) {
         const int cnt = std::min(kMaxBatch, n - first);

@@ -3,7 +3,10 @@
 Every cool-chic decodes from its own byte ranges, so frames are independent units: frame i goes to
 rank i mod world_size, each rank decodes its frames in one DecodeBatch, and the only communication is
 one gather of the decoded integer planes to the writer rank (RCCL over xGMI when the backend is
-"nccl"; "gloo" in the CPU tests). No collective runs inside a frame."""
+"nccl"; "gloo" in the CPU tests). No collective runs inside a frame.  A video GOP adds the path's one real
+exchange: a decoded frame travels point to point to the ranks whose frames predict from it.
+
+`dst` / `src` arguments are ranks of `group` (translated to global ranks for torch.distributed)."""
 from typing import List, Optional, Sequence
 
 import torch
@@ -34,7 +37,7 @@ def gather_bytes(local: torch.Tensor, dst: int = 0, group=None) -> Optional[List
     padded = torch.zeros(n_max, dtype=torch.uint8, device=local.device)
     padded[: local.numel()] = local
     bucket = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    dist.gather(padded, bucket, dst=dst, group=group)
+    dist.gather(padded, bucket, dst=_global_rank(group, dst), group=group)
     if rank != dst:
         return None
     return [b[: int(s.item())] for b, s in zip(bucket, sizes)]
@@ -52,7 +55,7 @@ class EqualSizeGather:
 
     def __call__(self, planes: Sequence[torch.Tensor]) -> Optional[List[torch.Tensor]]:
         torch.cat([p.contiguous().view(torch.uint8).reshape(-1) for p in planes], out=self.local)
-        dist.gather(self.local, self.bucket, dst=self.dst, group=self.group)
+        dist.gather(self.local, self.bucket, dst=_global_rank(self.group, self.dst), group=self.group)
         return self.bucket
 
 
@@ -72,23 +75,25 @@ def gop_owner(coding_index: int, world_size: int) -> int:
     return coding_index % world_size
 
 
-def exchange_planes(planes: Optional[Sequence[torch.Tensor]], specs: Sequence, src: int, device, group=None) -> List[torch.Tensor]:
-    """The owner's decoded integer planes -> every rank (the one real exchange step of a sharded GOP: the next
-    frames in coding order use them as references).  One broadcast of one packed message, RCCL over xGMI with the
-    "nccl" backend (3.1 MB for a 1080p 4:2:0 8-bit frame); `specs` = [(shape, dtype), ...] is known to every rank
-    from the frame header, so no sizes travel.  With "gloo" the message is staged through the host."""
-    if dist.get_world_size(group) == 1:
-        return list(planes)
+def _global_rank(group, r: int) -> int:
+    """Collectives / point-to-point calls take GLOBAL ranks; `r` is a rank of `group`."""
+    return r if group is None else dist.get_global_rank(group, r)
+
+
+def send_planes(planes: Sequence[torch.Tensor], dst: int, device, group=None) -> None:
+    """The owner's integer planes of one frame -> rank `dst` of `group`: one packed message, point to point (RCCL
+    send / recv over the direct xGMI link with the "nccl" backend; staged through the host with "gloo")."""
+    staged = dist.get_backend(group) == "gloo"
+    buf = pack_planes([p.to("cpu" if staged else device) for p in planes])
+    dist.send(buf, dst=_global_rank(group, dst), group=group)
+
+
+def recv_planes(specs: Sequence, src: int, device, group=None) -> List[torch.Tensor]:
+    """Counterpart of send_planes; `specs` = [(shape, dtype), ...] comes from the frame header, so no sizes travel."""
     n_bytes = [int(torch.Size(s).numel()) * torch.empty(0, dtype=d).element_size() for s, d in specs]
     staged = dist.get_backend(group) == "gloo"
-    buf_dev = torch.device("cpu") if staged else torch.device(device)
-    if dist.get_rank(group) == src:
-        buf = pack_planes([p.to(buf_dev) for p in planes])
-    else:
-        buf = torch.empty(sum(n_bytes), dtype=torch.uint8, device=buf_dev)
-    dist.broadcast(buf, src=src, group=group)
-    if dist.get_rank(group) == src:
-        return list(planes)
+    buf = torch.empty(sum(n_bytes), dtype=torch.uint8, device="cpu" if staged else device)
+    dist.recv(buf, src=_global_rank(group, src), group=group)
     out, off = [], 0
     for (shape, dtype), nb in zip(specs, n_bytes):
         out.append(buf[off:off + nb].view(dtype).reshape(shape).to(device))
@@ -96,20 +101,43 @@ def exchange_planes(planes: Optional[Sequence[torch.Tensor]], specs: Sequence, s
     return out
 
 
-def run_sharded_gop(n_frames: int, plane_specs, references, produce, device="cpu", group=None) -> dict:
+def gop_consumers(n_frames: int, references, world_size: int, collect: Optional[int] = 0) -> List[List[int]]:
+    """For every frame (coding index) the ranks that need its planes besides its owner: the owners of the frames that
+    predict from it (at most two per frame in a hierarchical GOP, decode.py:156-189) and the rank that collects the
+    sequence (None: nobody)."""
+    out = []
+    for k in range(n_frames):
+        need = {gop_owner(j, world_size) for j in range(k + 1, n_frames) if k in references[j]}
+        if collect is not None:
+            need.add(collect)
+        need.discard(gop_owner(k, world_size))
+        out.append(sorted(need))
+    return out
+
+
+def run_sharded_gop(n_frames: int, plane_specs, references, produce, device="cpu", group=None, collect: Optional[int] = 0) -> dict:
     """Coding-order schedule of a GOP whose frames are spread round-robin over the ranks.
 
     plane_specs[k]  [(shape, dtype) x 3] of frame k (coding index), known to every rank
     references[k]   coding indices of the frames frame k predicts from (all < k)
     produce(k, refs) -> planes of frame k; called ONLY on gop_owner(k); refs = planes of references[k]
-    Returns {k: planes} on every rank.  The expensive part of `produce` (the cool-chic decodes) does not depend on
-    the references, so an owner runs it for all of its frames up front and `produce` only reconstructs."""
+    collect         rank that ends up with every frame (the writer), or None
+    Returns {k: planes} holding, on each rank, the frames it produced or received: everything on `collect`.
+
+    The expensive part of `produce` (the cool-chic decodes) does not depend on the references, so an owner runs it for
+    all of its frames up front and `produce` only reconstructs.  A frame's planes travel point to point, only to the
+    ranks whose frames predict from it (and to the collector): the one real exchange step of the path."""
     initialised = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if initialised else 1
     rank = dist.get_rank(group) if initialised else 0
+    consumers = gop_consumers(n_frames, references, world, collect if world > 1 else None)
     done = {}
     for k in range(n_frames):
         owner = gop_owner(k, world)
-        planes = produce(k, [done[r] for r in references[k]]) if rank == owner else None
-        done[k] = list(planes) if world == 1 else exchange_planes(planes, plane_specs[k], owner, device, group)
+        if rank == owner:
+            done[k] = list(produce(k, [done[r] for r in references[k]]))
+            for dst in consumers[k]:
+                send_planes(done[k], dst, device, group)
+        elif rank in consumers[k]:
+            done[k] = recv_planes(plane_specs[k], owner, device, group)
     return done

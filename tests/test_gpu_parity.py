@@ -234,6 +234,18 @@ def test_python_surface(gpu, oracle, tmp_path):
     assert np.array_equal(t[0].cpu().numpy().view(np.uint32), ref.view(np.uint32))
     with pytest.raises(ValueError):
         encode_decode_coolchic(ch, nn, "decode", dec_bytes_latent=None)
+    # the boundary's second caller (bitstream/encode.py:83-89): mode="encode" with the decoded latents as the encoder's
+    # quantised latents gives back the reference encoder's own bytes (header + NN + latent payload) and the same output
+    with pytest.raises(ValueError):
+        encode_decode_coolchic(ch, nn, "encode")
+    q = [torch.from_numpy(z[f"cc0.latent{g}"].astype(np.float32))[None, None] for g in range(ch.c.n_grids)]
+    ch2 = CoolChicHeader()
+    ch2.read_header(ch.raw)
+    ch2.c.n_bytes_latent = 0  # "we don't know the number of bytes in the latent grids yet" (bitstream/encode.py:76-79)
+    t2, enc = encode_decode_coolchic(ch2, nn, "encode", enc_quantized_latent=q)
+    assert enc == ch.raw + nn + lat
+    assert ch2.get_value("n_bytes_latent") == len(lat)
+    assert torch.equal(t2, t)
 
 
 @pytest.mark.parametrize("stream", ["vid5", "vid5_w2", "vid5_w4"])
@@ -527,7 +539,7 @@ def test_rate_model_matches_the_float32_formula(gpu):
         compute_rate(x, mu, scale)  # host tensors
 
 
-def _sharded_worker(rank, world, port, path, q):
+def _sharded_worker(rank, world, port, path, q, backend="gloo"):
     import os
 
     import torch
@@ -535,52 +547,171 @@ def _sharded_worker(rank, world, port, path, q):
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)  # one GPU on the box: both ranks use cuda:0, host-staged exchange
+    # gloo: one GPU on the box, both ranks use cuda:0 and the exchange is staged through the host;
+    # nccl: one GPU per rank, planes travel over RCCL send / recv
+    device = rank if backend == "nccl" else 0
+    if backend == "nccl":
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{device}"))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from cool_chic_amd.bitstream.decode import decode_video_sharded
+    from cool_chic_amd.parallel import EqualSizeGather
 
-    frames = decode_video_sharded(path, device=0)
+    frames = decode_video_sharded(path, device=device)
     out = {}
     for k, fd in frames.items():
         planes = fd.integer_planes()
         out[k] = [np.asarray(p) for p in planes]
-    q.put((rank, out))
+    # the fixed-size gather of bench.py --gpus N on the same backend
+    dev = f"cuda:{device}" if backend == "nccl" else "cpu"
+    mine = [torch.full((16, 8), 10 * rank + p, dtype=torch.uint8, device=dev) for p in range(3)]
+    got = EqualSizeGather(3 * 128, dev, dst=0)(mine)
+    gather_ok = True
+    if rank == 0:
+        for r in range(world):
+            want = torch.cat([torch.full((128,), 10 * r + p, dtype=torch.uint8) for p in range(3)])
+            gather_ok = gather_ok and torch.equal(got[r].cpu(), want)
+    q.put((rank, out, gather_ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_video_gop_sharded_over_ranks(gpu, oracle):
-    """The I/P/B fixture decoded (a) unsharded through decode_video_sharded, (b) by two ranks that each decode the
-    cool-chics of their own frames and exchange reconstructed planes: both equal the oracle's planes."""
+def _run_sharded(backend, oracle):
     import os
     import socket
 
     import torch.multiprocessing as mp
 
     from conftest import GOLDEN
-    from cool_chic_amd.bitstream.decode import decode_video_sharded
 
     path = os.path.join(GOLDEN, "vid5.cool")
     bs, _, _ = load_golden("vid5")
     want = {str(fr["display_index"]): fr["planes"] for fr in oracle.decode_video(bs)}
-    single = decode_video_sharded(path, device=0)
-    assert sorted(single) == sorted(want)
-    for k, fd in single.items():
-        for p, w in zip(fd.integer_planes(), want[k]):
-            assert np.array_equal(np.asarray(p).astype(np.uint16), w), k
     with socket.socket() as s_:
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, path, q)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, path, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in range(2)]
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
-    for rank, out in results:
-        assert sorted(out) == sorted(want)
+    for rank, out, gather_ok in results:
+        assert gather_ok
+        # rank 0 collects the whole sequence; rank 1 holds its own frames and the references it was sent
+        if rank == 0:
+            assert sorted(out) == sorted(want)
+        else:
+            assert 0 < len(out) <= len(want)
         for k in out:
             for p, w in zip(out[k], want[k]):
                 assert np.array_equal(p.astype(np.uint16), w), (rank, k)
+    return want
+
+
+def test_video_gop_sharded_over_ranks(gpu, oracle):
+    """The I/P/B fixture decoded (a) unsharded through decode_video_sharded, (b) by two ranks that each decode the
+    cool-chics of their own frames and hand reconstructed planes point to point to the ranks that predict from them:
+    both equal the oracle's planes."""
+    import os
+
+    from conftest import GOLDEN
+    from cool_chic_amd.bitstream.decode import decode_video, decode_video_sharded
+
+    path = os.path.join(GOLDEN, "vid5.cool")
+    want = _run_sharded("gloo", oracle)
+    single = decode_video_sharded(path, device=0)
+    assert sorted(single) == sorted(want)
+    for k, fd in single.items():
+        for p, w in zip(fd.integer_planes(), want[k]):
+            assert np.array_equal(np.asarray(p).astype(np.uint16), w), k
+    # decode_video itself: all cool-chics of the GOP in one batch; a partial decode returns None for the frames that
+    # were not reached (decode.py:84-89 iterates every display index)
+    full = decode_video(path, device=0)
+    for k, fd in full.items():
+        for p, w in zip(fd.integer_planes(), want[k]):
+            assert np.array_equal(np.asarray(p).astype(np.uint16), w), k
+    part = decode_video(path, max_decoding_order=1, device=0)  # coding order I0 P4 ...
+    assert sorted(part) == sorted(want)
+    decoded = {k for k, fd in part.items() if fd is not None}
+    assert decoded == {"0", "4"}
+    for k in decoded:
+        for p, w in zip(part[k].integer_planes(), want[k]):
+            assert np.array_equal(np.asarray(p).astype(np.uint16), w), k
+
+
+def _n_gpus():
+    import torch
+
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: RCCL send / recv and gather between two ranks")
+def test_video_gop_sharded_over_two_gpus_nccl(gpu, oracle):
+    """The same over the "nccl" backend (RCCL over xGMI), one GPU per rank: the sharded GOP's point-to-point plane
+    hand-over and bench.py's EqualSizeGather."""
+    _run_sharded("nccl", oracle)
+
+
+def test_streams_the_reference_cannot_decode_are_rejected(gpu, oracle):
+    """Headers that parse but that the reference's decoder raises on (or that would read out of bounds here) give
+    CCD_ERR_VALUE instead of garbage: latent / hyperlatent ranges that do not touch (torch.cat of grids two levels
+    apart), a transmitted grid count that is not the number of grids, a P / B frame whose reference has another sample
+    layout, duplicate display indices, odd-sized 4:2:0 frames."""
+    import ctypes as C
+
+    from cool_chic_amd import writer
+    from cool_chic_amd._lib import CcdError, Video, lib
+
+    bs, z, _ = load_golden("rgb192")
+    fh, ccs = oracle.split_stream(bs)[1][0]
+    hdr, nn, lat = ccs[0]
+    arch = writer.parse_cc_header(hdr)
+    # (1) latent levels 0..1 and hyperlatent levels 4..6: consecutive grids three levels apart
+    bad = writer.derive_arch(arch)
+    bad.latent_resolution[0], bad.latent_resolution[1] = 0, 1
+    bad.hyperlatent_resolution[0], bad.hyperlatent_resolution[1] = 4, 6
+    bad.n_latent_grids = 5
+    b = gpu(0)
+    try:
+        with pytest.raises(CcdError) as e:
+            b.add(writer.cc_header_bytes(bad), nn, lat, 8, 0)
+        assert e.value.code == -2
+        # (2) the transmitted number of grids is not the length of the size list
+        bad2 = writer.derive_arch(arch)
+        bad2.n_latent_grids = arch.n_latent_grids - 1
+        with pytest.raises(CcdError) as e:
+            b.add(writer.cc_header_bytes(bad2), nn, lat, 8, 0)
+        assert e.value.code == -2
+        assert b.add(hdr, nn, lat, 8, 0) == 0  # the untouched header is fine
+    finally:
+        b.close()
+    # (3)-(5) video level, through ccd_decode_video
+    vbs, _, _ = load_golden("vid5")
+    vh, frames = oracle.split_stream(vbs)
+
+    def rebuild(edit):
+        out = [writer.video_header_bytes(vh.n_frames, list(vh.intra_pos[:vh.n_intras]), list(vh.p_pos[:vh.n_p_frames]))]
+        for k, (f, cc) in enumerate(frames):
+            di, fdt = f.display_index, f.frame_data_type
+            di, fdt = edit(k, di, fdt)
+            out.append(writer.frame_header_bytes(di, "IPB"[f.frame_type], fdt, f.bitdepth, list(f.index_references[:f.n_refs]),
+                                                 list(f.global_flow[:2 * f.n_refs]), f.warp_filter_size))
+            for h_, n_, l_ in cc:
+                out.append(h_ + n_ + l_)
+        return b"".join(out)
+
+    def decode(stream):
+        v = Video()
+        rc = lib().ccd_decode_video(stream, len(stream), 0, C.byref(v))
+        if rc == 0:
+            lib().ccd_video_free(C.byref(v))
+        return rc
+
+    assert decode(rebuild(lambda k, di, fdt: (di, fdt))) == 0
+    assert decode(rebuild(lambda k, di, fdt: (di, 2 if k == 0 else fdt))) == -2   # I frame yuv444, its P / B users yuv420
+    assert decode(rebuild(lambda k, di, fdt: (0 if k == 4 else di, fdt))) == -2    # display index 0 twice

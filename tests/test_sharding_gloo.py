@@ -8,7 +8,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from cool_chic_amd.parallel import EqualSizeGather, gather_bytes, gop_owner, pack_planes, run_sharded_gop, shard_indices, unshard
+from cool_chic_amd.parallel import (EqualSizeGather, gather_bytes, gop_consumers, gop_owner, pack_planes, run_sharded_gop, shard_indices,
+                                    unshard)
 
 
 def _free_port():
@@ -74,7 +75,7 @@ def test_round_robin_and_gather_world2():
     assert ok
 
 
-# ---- a GOP sharded over ranks: coding-order schedule + broadcast of reference planes --------------------------------
+# ---- a GOP sharded over ranks: coding-order schedule + point-to-point hand-over of reference planes -------------------
 # hierarchical GOP like the reference's (I0 P4 B2 B1 B3 I8 B6 ...): references by coding index
 _GOP_REFS = [[], [0], [0, 1], [0, 2], [2, 1], [], [1, 5], [1, 6], [6, 5]]
 
@@ -125,10 +126,28 @@ def test_sharded_gop_schedule_world2():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    consumers = gop_consumers(n, _GOP_REFS, 2, collect=0)
     for rank, calls, done in results:
         assert calls == [k for k in range(n) if gop_owner(k, 2) == rank]  # only its own frames, in coding order
-        assert sorted(done) == list(range(n))
-        for k in range(n):
+        # a rank holds what it produced and what it was sent: everything on the collector (rank 0), only the
+        # references of its own frames elsewhere - nothing is broadcast
+        assert sorted(done) == [k for k in range(n) if gop_owner(k, 2) == rank or rank in consumers[k]]
+        if rank == 0:
+            assert sorted(done) == list(range(n))
+        else:
+            assert len(done) < n
+        for k in sorted(done):
             for got, want, (shape, dt) in zip(done[k], serial[k], _gop_specs(k)):
                 assert got.shape == tuple(shape)
                 assert np.array_equal(got, want.to(torch.int32).numpy()), (rank, k)
+
+
+def test_gop_consumers_are_only_the_predicting_ranks():
+    """Hierarchical GOP of 9 frames on 4 ranks: a frame goes to the owners of the frames that predict from it (+ collector)."""
+    cons = gop_consumers(len(_GOP_REFS), _GOP_REFS, 4, collect=None)
+    for k, need in enumerate(cons):
+        want = sorted({gop_owner(j, 4) for j, refs in enumerate(_GOP_REFS) if k in refs} - {gop_owner(k, 4)})
+        assert need == want
+    assert max(len(c) for c in cons) <= 3 and cons[8] == []
+    with_collector = gop_consumers(len(_GOP_REFS), _GOP_REFS, 4, collect=0)
+    assert all((0 in c) or gop_owner(k, 4) == 0 for k, c in enumerate(with_collector))
