@@ -94,6 +94,7 @@ SIGNATURES = {
     "ccd_batch_slot_status": (C.c_int, [C.c_void_p, C.c_int]),
     "ccd_batch_slot_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ccd_batch_slot_kernels": (C.c_int, [C.c_void_p, C.c_int]),
+    "ccd_network_fits_fast_path": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "ccd_debug_fd_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ccd_batch_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ccd_batch_output": (C.c_void_p, [C.c_void_p, C.c_int]),

@@ -1093,6 +1093,20 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
     return rc < 0 ? rc : CCD_OK;
 }
 
+int ccd_network_fits_fast_path(const uint8_t* cc_header, size_t n_hdr, const uint8_t* bytes_nn, size_t n_nn) {
+    if (!cc_header || !bytes_nn) return CCD_ERR_ARG;
+    std::unique_ptr<ccd_cc_header> h(new (std::nothrow) ccd_cc_header());
+    if (!h) return CCD_ERR_NOMEM;
+    int rc = read_cc_header(cc_header, n_hdr, h.get());
+    if (rc < 0) return rc;
+    Network net;
+    rc = decode_network(*h, bytes_nn, n_nn, net);
+    if (rc < 0) return rc;
+    int max_w = 0;
+    for (int g = 0; g < h->n_grids; ++g) max_w = std::max(max_w, static_cast<int>(h->grid_w[g]));
+    return entropy_pipe_supports(h->total_context_arm, h->n_hidden_layers_arm + 1, net.arm.narrow ? 1 : 0, max_w) ? 1 : 0;
+}
+
 int ccd_debug_fd_profile(uint64_t* out16, int reset) {
     return out16 ? fused_dec_profile(reinterpret_cast<unsigned long long*>(out16), reset) : CCD_ERR_ARG;
 }

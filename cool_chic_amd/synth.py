@@ -1,0 +1,214 @@
+"""Synthetic .cool bitstreams shaped like BASELINE.json's configurations (hard part H6).
+
+Only `samples/bitstreams/kodim14.cool` is a real Cool-chic stream and there is no network for datasets, so every
+benchmark / full-size test input is MANUFACTURED here with the build's own bitstream writer: trained networks of a
+reference-encoded donor stream (grown to more pyramid levels where the picture size asks for it), real latent pyramids
+tiled / rolled / transposed to the new geometry (real symbol statistics, 0.6-0.9 bpp), framed exactly like the reference
+frames them.  Used by bench.py and tests/; nothing here runs while decoding.
+
+Sizes: Kodak = 18 landscape + 6 portrait 512x768; CLIC20-pro-valid = the 41 pixel counts of
+results/v5.0/image-clic20-pro-valid.tsv (n_pixels column, 91.45 Mpx) factorised with an aspect ratio near 3:2 (the TSV
+does not carry widths and heights); 1080p GOP = intra period 32, hierarchical B (docs/source/results/video.rst:28,
+samples/encode.py:23-70); 4K = 3840x2160.  Latent / hyperlatent ranges follow the reference's "auto" rule
+(utils/parsecli.py:82-117)."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+
+from . import writer
+from ._lib import CCHeader
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(os.path.dirname(_HERE), "tests", "golden")
+
+# (H, W) per picture of CLIC20-pro-valid: H * W = the TSV's n_pixels, rows in the TSV's order
+CLIC41_SIZES = [(1363, 2048), (1339, 2048), (1188, 2048), (1361, 2048), (1365, 2048), (1020, 1464), (1361, 2048), (1365, 2048),
+                (1360, 2048), (1365, 2048), (1000, 1266), (1292, 1945), (1360, 2040), (1166, 1750), (1370, 2048), (1365, 2048),
+                (1365, 2048), (1220, 1936), (1145, 1725), (1365, 2048), (1365, 2048), (640, 960), (1365, 2048), (1365, 2048),
+                (772, 1158), (1366, 2048), (640, 906), (960, 1350), (1281, 1922), (1365, 2048), (384, 512), (1365, 2048),
+                (1028, 1542), (1367, 2048), (790, 1264), (439, 720), (1033, 2048), (1366, 2048), (1232, 1836), (1325, 1988),
+                (1365, 2048)]
+assert len(CLIC41_SIZES) == 41 and sum(h * w for h, w in CLIC41_SIZES) == 91451931
+
+Triple = Tuple[bytes, bytes, bytes]  # cool-chic header, NN payload, latent payload
+
+
+def auto_resolution(n_pixels: int) -> int:
+    """Coarsest latent level of the reference's "auto" rule (utils/parsecli.py:86-93)."""
+    return 6 if n_pixels < 1_000_000 else (7 if n_pixels < 3_000_000 else 8)
+
+
+def _pool(n: int) -> ThreadPoolExecutor:
+    return ThreadPoolExecutor(max_workers=max(1, min(n, 32, os.cpu_count() or 4)))  # the writer's ARM walk releases the GIL
+
+
+def _golden(name: str):
+    with open(os.path.join(GOLDEN, name + ".cool"), "rb") as f:
+        bs = f.read()
+    return bs, np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def split_image_stream(bs: bytes) -> Triple:
+    """One-frame intra stream -> (cool-chic header, NN bytes, latent bytes)."""
+    from .bitstream.header import CoolChicHeader, FrameHeader, VideoHeader
+
+    rest = VideoHeader().read_header(bs)
+    rest = FrameHeader().read_header(rest)
+    ch = CoolChicHeader()
+    rest = ch.read_header(rest)
+    n_nn = ch.get_value("nn_n_bytes")
+    return ch.raw, rest[:n_nn], rest[n_nn:n_nn + ch.get_value("n_bytes_latent")]
+
+
+def _kodim14():
+    bs, z = _golden("kodim14")
+    hdr, nn, lat = split_image_stream(bs)
+    donor = writer.parse_cc_header(hdr)
+    latents = [z[f"cc0.latent{g}"] for g in range(donor.n_grids)]
+    return bs, hdr, nn, donor, z["cc0.nn_ints"], latents
+
+
+def kodak24() -> Tuple[List[bytes], List[Tuple[int, int]]]:
+    """BASELINE configs[1]: 24 RGB 8-bit 512x768 streams (18 landscape, 6 portrait as in Kodak), HOP decoder.
+    Stream 0 is the reference's kodim14.cool; the others carry kodim14's network and rolled / transposed copies of
+    its latent pyramid.  Returns (streams, sizes)."""
+    real, hdr, nn, donor, _, latents = _kodim14()
+    _, levels = writer.grid_sizes((512, 768), hdr)
+    jobs = [(1000 + i, i in (3, 8, 9, 16, 17, 18)) for i in range(1, 24)]
+
+    def make(job):
+        seed, portrait = job
+        v = writer.variant_latents(latents, levels, seed, portrait)
+        return writer.encode_stream(hdr, nn, v, img_size=(768, 512) if portrait else (512, 768))
+
+    with _pool(len(jobs)) as ex:
+        streams = [real] + list(ex.map(make, jobs))
+    sizes = [(512, 768)] + [((768, 512) if p else (512, 768)) for _, p in jobs]
+    return streams, sizes
+
+
+def _image_arch(donor: CCHeader, h: int, w: int) -> CCHeader:
+    v = auto_resolution(h * w)
+    return writer.derive_arch(donor, img_size=(h, w), latent_resolution=(0, v), hyperlatent_resolution=(4, v),
+                              n_latent_grids=(v + 1) + (v - 3))
+
+
+def _rolled(latents: Sequence[np.ndarray], arch: CCHeader, seed: int) -> List[np.ndarray]:
+    """Per-picture variation: the tiled pyramid rolled consistently across levels."""
+    _, levels = writer.grid_sizes(tuple(arch.img_size), writer.cc_header_bytes(arch))
+    return writer.variant_latents(list(latents), levels, seed, False)
+
+
+def image_stream(h: int, w: int, seed: int = 0) -> bytes:
+    """One RGB 8-bit HOP picture of any size: kodim14's networks grown to the "auto" number of levels, its latents tiled."""
+    _, _, _, donor, ints, latents = _kodim14()
+    arch = _image_arch(donor, h, w)
+    nn = writer.encode_network(arch, writer.adapt_network(donor, ints, arch))
+    lat = writer.tile_latents(latents, donor, arch)
+    if seed:
+        lat = _rolled(lat, arch, seed)
+    return writer.encode_stream(writer.cc_header_bytes(arch), nn, lat)
+
+
+def clic41() -> Tuple[List[bytes], List[Tuple[int, int]]]:
+    """BASELINE configs[2]: 41 RGB 8-bit pictures with CLIC20-pro-valid's pixel counts (91.45 Mpx), HOP decoder."""
+    with _pool(len(CLIC41_SIZES)) as ex:
+        streams = list(ex.map(lambda a: image_stream(a[1][0], a[1][1], 2000 + a[0]), enumerate(CLIC41_SIZES)))
+    return streams, list(CLIC41_SIZES)
+
+
+def uhd4k() -> Tuple[List[bytes], List[Tuple[int, int]]]:
+    """BASELINE configs[4]: one 3840x2160 RGB 8-bit picture, latent 0-8 + hyperlatent 4-8 (14 grids, 11.1 M symbols)."""
+    return [image_stream(2160, 3840, 0)], [(2160, 3840)]
+
+
+def hierarchical_gop(intra_period: int) -> List[Tuple[int, str, List[int], int]]:
+    """Coding order of one closed GOP I0 .. I<period> with dyadic hierarchical B frames (the structure
+    utils/codingstructure.py:267-436 produces for p_pos = []): [(display index, type, references, depth)]."""
+    out = [(0, "I", [], 0), (intra_period, "I", [], 0)]
+
+    def split(a, b, depth):
+        if b - a < 2:
+            return
+        m = (a + b) // 2
+        out.append((m, "B", [a, b], depth))
+        split(a, m, depth + 1)
+        split(m, b, depth + 1)
+
+    split(0, intra_period, 1)
+    return out
+
+
+def gop1080p(intra_period: int = 32, size: Tuple[int, int] = (1080, 1920)) -> Tuple[bytes, dict]:
+    """BASELINE configs[3]: a 1920x1080 YUV 4:2:0 8-bit GOP of intra_period + 1 frames (I0, I<period>, hierarchical B in
+    between): the networks and headers of the reference-encoded `vid5` fixture (I = intra/hop, B at depth 1 =
+    residue/mop + motion/mop, deeper B = lop, samples/encode.py:23-70), residue cool-chics grown to the "auto" levels of
+    the picture size, latents tiled.  Returns (stream, info)."""
+    from .bitstream.decode import _split_frame
+    from .bitstream.header import VideoHeader
+
+    bs, z = _golden("vid5")
+    vh = VideoHeader()
+    rest = vh.read_header(bs)
+    # donors by role: vid5 is I0 P4 B2 B1 B3 (coding order); cc indices count cool-chics in coding order
+    role, cc_idx = {}, 0
+    for _ in range(vh.get_value("n_frames")):
+        fh, ccs, rest = _split_frame(rest)
+        ftype, di = fh.get_value("frame_type"), fh.get_value("display_index")
+        key = ftype if ftype != "B" else ("B1" if di == 2 else "B2")
+        if key not in role:
+            role[key] = (fh.c, [(ch.raw, nn, [z[f"cc{cc_idx + j}.latent{g}"] for g in range(ch.c.n_grids)], z[f"cc{cc_idx + j}.nn_ints"])
+                                for j, (ch, nn, _) in enumerate(ccs)])
+        cc_idx += len(ccs)
+    # I frames: intra/hop (samples/encode.py:30-36) = kodim14's architecture and trained network (vid5's own I frame is a
+    # 60-iteration LOP network whose integer ARM leaves the 32-bit envelope of the production entropy kernel)
+    _, k_hdr, k_nn, _, k_ints, k_lat = _kodim14()
+    role["I"] = (role["I"][0], [(k_hdr, k_nn, k_lat, k_ints)])
+    H, W = size
+    order = hierarchical_gop(intra_period)
+
+    def coolchic(donor_cc, seed):
+        hdr, nn, lat, ints = donor_cc
+        donor = writer.parse_cc_header(hdr)
+        if donor.latent_resolution[0] == 0:  # residue / intra: "auto" levels for this picture size
+            v = auto_resolution(H * W)
+            arch = writer.derive_arch(donor, img_size=(H, W), latent_resolution=(0, v),
+                                      hyperlatent_resolution=(4, v) if donor.flag_hyperlatent else tuple(donor.hyperlatent_resolution),
+                                      n_latent_grids=(v + 1) + ((v - 3) if donor.flag_hyperlatent else 0))
+            nn = writer.encode_network(arch, writer.adapt_network(donor, ints, arch))
+        else:                                # motion: latent 2-6 whatever the size (cfg/dec/motion/*.cfg)
+            arch = writer.derive_arch(donor, img_size=(H, W))
+        tiled = writer.tile_latents(lat, donor, arch)
+        return writer.encode_coolchic(arch, nn, _rolled(tiled, arch, seed) if seed else tiled)
+
+    def frame_bytes(item):
+        k, (di, ftype, refs, depth) = item
+        fh, ccs = role["I" if ftype == "I" else ("B1" if depth == 1 else "B2")]
+        head = writer.frame_header_bytes(di, ftype, fh.frame_data_type, fh.bitdepth, refs, [0] * (2 * len(refs)), fh.warp_filter_size)
+        return head + b"".join(coolchic(cc, 3000 + 7 * k + j) for j, cc in enumerate(ccs))
+
+    with _pool(len(order)) as ex:
+        body = list(ex.map(frame_bytes, enumerate(order)))
+    stream = writer.video_header_bytes(intra_period + 1, [0, intra_period], []) + b"".join(body)
+    info = {"frames": intra_period + 1, "size": size, "coding_order": [o[0] for o in order],
+            "cool_chics": sum(1 if o[1] == "I" else 2 for o in order)}
+    return stream, info
+
+
+def workload(name: str) -> Dict:
+    """{"streams": [...], "sizes": [(H, W) per frame], "video": bool} for "kodak24" | "clic41" | "uhd4k" | "gop1080p33"."""
+    if name == "kodak24":
+        s, z = kodak24()
+        return {"streams": s, "sizes": z, "video": False}
+    if name == "clic41":
+        s, z = clic41()
+        return {"streams": s, "sizes": z, "video": False}
+    if name == "uhd4k":
+        s, z = uhd4k()
+        return {"streams": s, "sizes": z, "video": False}
+    if name == "gop1080p33":
+        s, info = gop1080p(32)
+        return {"streams": [s], "sizes": [info["size"]] * info["frames"], "video": True, "info": info}
+    raise ValueError(name)

@@ -135,10 +135,16 @@ def _cycle_cols(w: np.ndarray, n_cols: int) -> np.ndarray:
     return w[:, np.arange(n_cols) % w.shape[1]]
 
 
-def adapt_network(donor: CCHeader, donor_ints: np.ndarray, arch: CCHeader, noise_gain: float = 0.25) -> np.ndarray:
+def fits_fast_path(cc_header: bytes, bytes_nn: bytes) -> bool:
+    """Whether this cool-chic's integer ARM provably fits the pipelined entropy kernel's 32-bit operands (include/ccd.h)."""
+    return check(lib().ccd_network_fits_fast_path(cc_header, len(cc_header), bytes_nn, len(bytes_nn)), "ccd_network_fits_fast_path") == 1
+
+
+def adapt_network(donor: CCHeader, donor_ints: np.ndarray, arch: CCHeader, noise_gain: float = 0.25, ifce_gain: float = 0.25) -> np.ndarray:
     """Quantised parameters for `arch` grown from a trained donor network: groups of equal size are copied,
-    the others are extended by cycling the donor's rows / columns (IFCE inputs, upsampling filters, the first
-    synthesis layer's input channels; common-randomness channels get the donor columns scaled by noise_gain)."""
+    the others are extended by cycling the donor's rows / columns (IFCE inputs the donor never saw scaled by ifce_gain,
+    upsampling filters, the first synthesis layer's input channels; common-randomness channels get the donor columns
+    scaled by noise_gain)."""
     dl, al = network_layout(donor), network_layout(arch)
     d = np.split(np.asarray(donor_ints, dtype=np.int64), np.cumsum(dl)[:-1])
     out = []
@@ -156,7 +162,7 @@ def adapt_network(donor: CCHeader, donor_ints: np.ndarray, arch: CCHeader, noise
             w0 = w0[np.arange(n_out) % w0.shape[0]]
             def grown(f):  # inputs the donor never saw (more, coarser grids) get a quarter of the weight
                 w = _cycle_cols(w0, f).astype(np.float64)
-                w[:, w0.shape[1]:] *= 0.25
+                w[:, w0.shape[1]:] *= ifce_gain
                 return np.round(w).astype(np.int64).ravel()
             out.append(np.concatenate([grown(f) for f in arch.input_features_ifce[:arch.n_grids] if f > 0]))
         elif k == 4:  # ups.w: n_ups x (k/2) transposed-conv halves, then n_ups x ceil(k_pre/2)

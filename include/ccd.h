@@ -256,6 +256,11 @@ int ccd_compute_rate(int device, void* stream, const float* x, const float* mu, 
 int ccd_debug_laplace_bounds(int device, const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* s,
                              int64_t n, uint32_t* left, uint32_t* right);
 
+/* Host only: 1 when this cool-chic's ARM runs on the pipelined entropy kernel (every operand of the integer MLP provably
+ * fits 32 bits for |latent| <= 64 and the worst-case IFCE features, no accumulator can wrap, picture not wider than the
+ * symbol ring), 0 when it needs the generic 64-bit kernel (~7x slower), < 0 on a malformed header / payload. */
+int ccd_network_fits_fast_path(const uint8_t* cc_header, size_t n_hdr, const uint8_t* bytes_nn, size_t n_nn);
+
 /* Profile builds only (-DCCD_FD_PROFILE): cycles per phase of the fused float kernel, summed over wave 0 of every
  * workgroup since the last reset; returns 1 with out16 filled, 0 when the library was built without the counters. */
 int ccd_debug_fd_profile(uint64_t* out16, int reset);

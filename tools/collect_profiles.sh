@@ -1,19 +1,28 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): rocprofv3 summaries of the bench command.
-#   pass 1: kernel trace + stats          -> gpurun_out/prof/stats
-#   pass 2: PMC FETCH_SIZE (own run)      -> gpurun_out/prof/fetch
-#   pass 3: PMC WRITE_SIZE (own run)      -> gpurun_out/prof/write
+# Runs on the GPU box (gpurun): rocprofv3 summaries of the bench command, for the metric's workload (kodak24) and for the
+# chip-filling one (kodak24 x 8 = 192 frames in one batch: bench.py --scaling strong on one GPU).
+#   pass 1: kernel trace + stats          -> gpurun_out/prof/<tag>/stats
+#   pass 2: PMC FETCH_SIZE (own run)      -> gpurun_out/prof/<tag>/fetch
+#   pass 3: PMC WRITE_SIZE (own run)      -> gpurun_out/prof/<tag>/write
 # (counters are never combined with sys/hip/hsa traces; see MI355X_MICROARCH.md, rocprofv3 PMC slots)
+# Afterwards (here or in the build container):  python tools/summarise_pmc.py gpurun_out/prof/<tag> profiles/r02 <tag>
 set -u
 REPO=$(pwd)
 export TMPDIR=/tmp
-OUT=$REPO/gpurun_out/prof
-rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/bench_stats.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/bench_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- $CMD > "$OUT/bench_write.log" 2>&1
-cd "$REPO"
-find "$OUT" -name "*.csv" | head -40
-tail -1 "$OUT/bench_stats.log" | cut -c1-300
+for TAG in kodak24 kodak192; do
+  OUT=$REPO/gpurun_out/prof/$TAG
+  rm -rf "$OUT"; mkdir -p "$OUT"
+  EXTRA=""; [ "$TAG" = kodak192 ] && EXTRA="--scaling strong"
+  CMD="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --legs none $EXTRA"
+  cd /tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/bench_stats.log" 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/bench_fetch.log" 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- $CMD > "$OUT/bench_write.log" 2>&1
+  cd "$REPO"
+  python tools/summarise_pmc.py "$OUT" "$REPO/gpurun_out/prof/summary" $TAG > /dev/null
+  cp $(find "$OUT/stats" -name "*kernel_stats.csv" | head -1) "$REPO/gpurun_out/prof/summary/${TAG}_kernel_stats.csv"
+  tail -1 "$OUT/bench_stats.log" | cut -c1-400 > "$REPO/gpurun_out/prof/summary/${TAG}_bench_under_rocprof.json"
+  # the counter CSVs are large: keep the summaries only
+  rm -rf "$OUT/fetch" "$OUT/write"
+done
+ls -la "$REPO/gpurun_out/prof/summary"

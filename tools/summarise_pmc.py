@@ -1,6 +1,6 @@
-"""gpurun_out/prof/{fetch,write} (tools/collect_profiles.sh: one rocprofv3 --pmc run per counter) -> profiles/<round>/kodak24_pmc_traffic.json
+"""gpurun_out/prof/{fetch,write} (tools/collect_profiles.sh: one rocprofv3 --pmc run per counter) -> profiles/<round>/<tag>_pmc_traffic.json
 
-    python tools/summarise_pmc.py [gpurun_out/prof] [profiles/r01]
+    python tools/summarise_pmc.py [gpurun_out/prof] [profiles/r02] [kodak24]
 
 Bytes per launch = mean of the counter over the launches of a kernel (first launch of every kernel dropped: warm-up
 with cold caches), counter unit KiB.  Kernels launched several times per step (the six pyramid levels) also get a
@@ -16,6 +16,7 @@ KERNELS = {  # short name -> (substring of the kernel name, launches per bench s
     "entropy_pipe_kernel": ("entropy_pipe_kernel", None),
     "upsample_step_kernel": ("upsample_step_kernel", 6),
     "syn_fused_kernel": ("syn_fused_kernel", None),
+    "decode_fused_kernel": ("decode_fused_kernel", None),
     "png_filter_huff_kernel": ("png_filter_huff_kernel", None),
     "png_emit_kernel": ("png_emit_kernel", None),
     "png_crc_kernel": ("png_crc_kernel", None),
@@ -34,7 +35,8 @@ def read(dir_, counter):
 
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-    dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01"
+    dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02"
+    tag = sys.argv[3] if len(sys.argv) > 3 else "kodak24"
     fetch, write = read(os.path.join(src, "fetch"), "FETCH_SIZE"), read(os.path.join(src, "write"), "WRITE_SIZE")
     out = {}
     for short, (sub, per_step) in KERNELS.items():
@@ -53,7 +55,8 @@ def main():
             e["write_bytes"] = sum(w) / len(w)
         out[short] = e
     doc = {
-        "command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline (tools/collect_profiles.sh; one rocprofv3 run per counter)",
+        "command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --legs none" + (" --scaling strong" if tag != "kodak24" else "")
+                   + " (tools/collect_profiles.sh; one rocprofv3 run per counter)",
         "unit": "bytes per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB; raw values, no gfx950 correction applied)",
         "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced reads by 2x; these kernels "
                 "read 4-byte and 1-byte elements, for which the guide gives no calibration - read FETCH_SIZE as a lower bound "
@@ -61,7 +64,7 @@ def main():
         "kernels": out,
     }
     os.makedirs(dst, exist_ok=True)
-    with open(os.path.join(dst, "kodak24_pmc_traffic.json"), "w") as fh:
+    with open(os.path.join(dst, tag + "_pmc_traffic.json"), "w") as fh:
         json.dump(doc, fh, indent=1)
     print(json.dumps(out, indent=1))
 
