@@ -486,6 +486,27 @@ static int rc_decode(rc_decoder* d, int mu_idx, int scale_idx, int* sym) {
     return ORA_OK;
 }
 
+/* Incremental decoder handle: lets a caller that owns the symbol schedule (the reference's Python decoder behind an import
+ * shim, tools/ref_baseline.py) drive this range decoder one wavefront at a time.  Test / baseline infrastructure only. */
+struct ora_rc_decoder { rc_decoder d; uint8_t* copy; };
+ora_rc_decoder* ora_rc_decoder_new(const uint8_t* bytes, size_t n_bytes) {
+    ora_rc_decoder* h = (ora_rc_decoder*)calloc(1, sizeof(*h));
+    if (!h) return NULL;
+    h->copy = (uint8_t*)malloc(n_bytes ? n_bytes : 1);
+    if (!h->copy) { free(h); return NULL; }
+    memcpy(h->copy, bytes, n_bytes);
+    rc_decoder_init(&h->d, h->copy, n_bytes);
+    return h;
+}
+int ora_rc_decode_many(ora_rc_decoder* h, const int* mu_idx, const int* scale_idx, int n, int* out) {
+    for (int i = 0; i < n; ++i) {
+        int rc = rc_decode(&h->d, mu_idx[i], scale_idx[i], &out[i]);
+        if (rc != ORA_OK) return rc;
+    }
+    return ORA_OK;
+}
+void ora_rc_decoder_free(ora_rc_decoder* h) { if (h) { free(h->copy); free(h); } }
+
 struct ora_rc_encoder {
     uint64_t lower, range;
     int inv_active; uint64_t inv_n; uint32_t inv_first;

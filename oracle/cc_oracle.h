@@ -152,6 +152,10 @@ int ora_decode_video(const uint8_t* bitstream, size_t n, ora_video* v);
 void ora_video_free(ora_video* v);
 
 /* ---- range encoder (constriction RangeEncoder) for round trips --- */
+typedef struct ora_rc_decoder ora_rc_decoder;
+ora_rc_decoder* ora_rc_decoder_new(const uint8_t* bytes, size_t n_bytes);
+int ora_rc_decode_many(ora_rc_decoder* h, const int* mu_idx, const int* scale_idx, int n, int* out);
+void ora_rc_decoder_free(ora_rc_decoder* h);
 typedef struct ora_rc_encoder ora_rc_encoder;
 ora_rc_encoder* ora_rc_encoder_new(void);
 void ora_rc_encode(ora_rc_encoder* e, int s, int mu_idx, int scale_idx);

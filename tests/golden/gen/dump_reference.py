@@ -244,6 +244,19 @@ def main():
             entry["chan_mean"] = [float(x) for x in q.astype(np.float64).mean(axis=(1, 2))]
         rec["frames"][k] = entry
 
+    if len(sys.argv) > 3 and sys.argv[3] == "--block-sums":
+        # full-plane coverage of the float stages at fixture size: float64 sums of every 8 x 8 block of the reference's
+        # dense planes and synthesis output (the per-stage crops of the main fixture cover three windows only)
+        def blocks(a):
+            c, h, w = a.shape
+            hp, wp = -(-h // 8) * 8, -(-w // 8) * 8
+            b = np.zeros((c, hp, wp), np.float64)
+            b[:, :h, :w] = a
+            return b.reshape(c, hp // 8, 8, wp // 8, 8).sum(axis=(2, 4))
+
+        np.savez_compressed(os.path.join(out_dir, name + "_blocks.npz"), dense=blocks(cur["dense"]), syn_out=blocks(cur["syn_out"]))
+        print("wrote", name + "_blocks.npz")
+        return
     if len(sys.argv) > 3 and sys.argv[3] == "--planes-only":
         # variants that differ from an existing fixture only after the cool-chics (e.g. the warp filter): keep the decoded planes
         arrays = {k: v for k, v in arrays.items() if k.startswith("frame")}
