@@ -56,9 +56,10 @@ __host__ __device__ constexpr int fd_reg_h(int i) { return i == 0 ? 32 : i == 1 
 __host__ __device__ constexpr int fd_reg_w(int i) { return i == 0 ? 64 : i == 1 ? 36 : i == 2 ? 23 : i == 3 ? 16 : i == 4 ? 13 : i == 5 ? 11 : 10; }
 __host__ __device__ constexpr int fd_pl(int i) { return fd_reg_h(i) * fd_reg_w(i); }  // plane of a level's channel (pitch fd_reg_w)
 // latent tiles: footprint + 4 on every side (3 for the 7x7 filter, 1 because a quad may start one row above the footprint),
-// origin column moved left to an odd coordinate so that 7x7 windows start 8-byte aligned; even pitch
+// origin column moved left to an odd coordinate so that 7x7 windows start 8-byte aligned; pitch a multiple of 4 (S1 stores
+// four samples at a time)
 __host__ __device__ constexpr int fd_lat_h(int i) { return fd_reg_h(i) + 8; }
-__host__ __device__ constexpr int fd_lat_p(int i) { return (fd_reg_w(i) + 9 + 1) & ~1; }
+__host__ __device__ constexpr int fd_lat_p(int i) { return (fd_reg_w(i) + 9 + 3) & ~3; }
 __host__ __device__ constexpr int fd_lat_elems(int i) { return fd_lat_h(i) * fd_lat_p(i); }
 // most quads of level i (S2 wave-items of 64 quads)
 __host__ __device__ constexpr int fd_max_q(int i) { return (fd_reg_h(i) / 2 + 1) * (fd_reg_w(i) / 2 + 1); }
@@ -225,10 +226,10 @@ __device__ __forceinline__ float fd_pick(f32x4 r, int cy, int cx) {
     return i == 0 ? r[0] : (i == 1 ? r[1] : (i == 2 ? r[2] : r[3]));
 }
 
-// S1 maps the workgroup onto a level's latent tile with a power-of-two row pitch: level 0 (40 x 74) 2 rows x 128 columns
-// per round, level 1 (28 x 46) 4 x 64, deeper levels 8 x 32.
-__host__ __device__ constexpr int fd_s1_shift(int i) { return i == 0 ? 7 : i == 1 ? 6 : 5; }
-__host__ __device__ constexpr int fd_s1_rounds(int i) { return (fd_lat_h(i) + (kFdThreads >> fd_s1_shift(i)) - 1) / (kFdThreads >> fd_s1_shift(i)); }
+// S1: a thread fetches FOUR neighbouring samples of a level's latent tile with one (unaligned) dword load: item t of level i
+// is row t / (pitch / 4), columns 4 (t % (pitch / 4)) .. + 3.
+__host__ __device__ constexpr int fd_s1_items(int i) { return fd_lat_h(i) * (fd_lat_p(i) / 4); }
+__host__ __device__ constexpr int fd_s1_rounds(int i) { return (fd_s1_items(i) + kFdThreads - 1) / kFdThreads; }
 __host__ __device__ constexpr int fd_s1_slot(int i) { int n = 0; for (int j = 0; j < i; ++j) n += fd_s1_rounds(j); return n; }
 // S2 wave-items (64 quads / samples) of level i in phase A and per channel in phase B, and the wave that takes the first one
 __host__ __device__ constexpr int fd_wi_a(int cin, int i) { return ((i == cin - 1 ? fd_pl(i) : fd_max_q(i)) + 63) / 64; }
@@ -314,26 +315,22 @@ __global__ __launch_bounds__(kFdThreads, 2) void decode_fused_kernel(const Fused
                 y0 = (y0 >> 1) - 2; y1 = (y1 >> 1) + 2; x0 = (x0 >> 1) - 2; x1 = (x1 >> 1) + 2;
             });
         }
-        // ---- S1: the latent bytes of every level's tile are requested back-to-back from clamped addresses (a conditional load
-        // makes the compiler wait at every join) and stored as f32 after ONE wait; zero outside the grid
-        int ld_val[fd_s1_slot(CIN)];
-        unsigned long long ld_ok = 0;  // bit s: slot s is a sample of the grid
-        static_assert(fd_s1_slot(CIN) <= 64, "one validity bit per load slot");
+        // ---- S1: the latent bytes of every level's tile are requested back-to-back, four samples per (unaligned) dword load from
+        // a clamped address (a conditional load makes the compiler wait at every join), and stored as f32 after ONE wait;
+        // zero outside the grid.  A dword that would cross the row's right end starts at gw - 4 and is shifted instead.
+        uint32_t ld_val[fd_s1_slot(CIN)];
+        typedef const uint32_t __attribute__((address_space(1), aligned(1)))* gcu32_t;
         static_for<0, CIN>([&](auto ll) {
             constexpr int i = decltype(ll)::value;
-            constexpr int SH = fd_s1_shift(i), RPR = kFdThreads >> SH;
+            constexpr int DW = fd_lat_p(i) / 4;
             const int oy = ay[i] - 4, ox = (ax[i] - 5) | 1;
             const gci8_t src = (gci8_t)p.lat[i];
-            const int c = tid & ((1 << SH) - 1);
-            const int rb = SH == 7 ? (wave >> 1) : (SH == 6 ? wave : (tid >> SH));  // wave-uniform for the two big levels
-            const int x = ox + c;
-            const bool col_ok = c < fd_lat_p(i) && x >= 0 && x < gw[i];
-            const int xc = fd_clamp(x, 0, gw[i] - 1);
             static_for<0, fd_s1_rounds(i)>([&](auto kk) {
                 constexpr int k = decltype(kk)::value;
-                const int r = k * RPR + rb, y = oy + r;
-                if (col_ok && r < fd_lat_h(i) && y >= 0 && y < gh[i]) ld_ok |= 1ull << (fd_s1_slot(i) + k);
-                ld_val[fd_s1_slot(i) + k] = src[static_cast<size_t>(fd_clamp(y, 0, gh[i] - 1)) * gw[i] + xc];
+                const int t = min(tid + k * kFdThreads, fd_s1_items(i) - 1);
+                const int r = t / DW, j = t - r * DW;
+                const int cy = fd_clamp(oy + r, 0, gh[i] - 1), xs = fd_clamp(ox + 4 * j, 0, max(gw[i] - 4, 0));
+                ld_val[fd_s1_slot(i) + k] = *(gcu32_t)(src + static_cast<uint32_t>(cy * gw[i] + xs));
             });
         });
         FDP_ADD(10, tp1);
@@ -343,14 +340,25 @@ __global__ __launch_bounds__(kFdThreads, 2) void decode_fused_kernel(const Fused
         const unsigned long long tq2 = FDP_T();
         static_for<0, CIN>([&](auto ll) {
             constexpr int i = decltype(ll)::value;
-            constexpr int SH = fd_s1_shift(i), RPR = kFdThreads >> SH, P = fd_lat_p(i);
+            constexpr int DW = fd_lat_p(i) / 4, P = fd_lat_p(i);
             float* const dst = fd_smem + (i == 0 ? L.lat0 : L.rest + fd_lat_off_rel(i));
-            const int c = tid & ((1 << SH) - 1), rb = tid >> SH;
+            const int oy = ay[i] - 4, ox = (ax[i] - 5) | 1;
             static_for<0, fd_s1_rounds(i)>([&](auto kk) {
                 constexpr int k = decltype(kk)::value;
-                const int r = k * RPR + rb;
-                if (c < P && r < fd_lat_h(i))
-                    dst[r * P + c] = ((ld_ok >> (fd_s1_slot(i) + k)) & 1ull) ? static_cast<float>(ld_val[fd_s1_slot(i) + k]) : 0.0f;
+                const int t = tid + k * kFdThreads;
+                const int r = t / DW, j = t - r * DW;
+                const int y = oy + r, x = ox + 4 * j;
+                const int xs = fd_clamp(x, 0, max(gw[i] - 4, 0));
+                const bool row_ok = y >= 0 && y < gh[i];
+                const uint32_t w = ld_val[fd_s1_slot(i) + k];
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int sh = (x + e - xs) * 8;  // byte of the loaded dword that holds sample x + e (if it is in the grid)
+                    const int b = static_cast<int>(static_cast<int8_t>(w >> (sh & 24)));
+                    v[e] = (row_ok && x + e >= 0 && x + e < gw[i]) ? static_cast<float>(b) : 0.0f;
+                }
+                if (t < fd_s1_items(i)) *reinterpret_cast<f32x4*>(dst + r * P + 4 * j) = v;
             });
         });
         FDP_ADD(12, tq2);
