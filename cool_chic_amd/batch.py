@@ -26,11 +26,13 @@ class DecodeBatch:
     enqueues kernels on `stream` (a hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream).
     """
 
-    OPT_FUSED_DEC, OPT_KEEP_FLOAT = 1, 2  # include/ccd.h
+    OPT_FUSED_DEC, OPT_KEEP_FLOAT, OPT_MFMA_ARM = 1, 2, 3  # include/ccd.h
 
-    def __init__(self, device: int = 0, fused_dec: Optional[bool] = None, keep_float: Optional[bool] = None):
+    def __init__(self, device: int = 0, fused_dec: Optional[bool] = None, keep_float: Optional[bool] = None,
+                 mfma_arm: Optional[int] = None):
         """fused_dec=False: unfused float path (materialises dense()); keep_float=False: rgb / yuv444 intra slots
-        write integer planes only (output() is then unavailable for them).  None = library default (both on)."""
+        write integer planes only (output() is then unavailable for them); mfma_arm=0: the integer ARM on the vector
+        ALU only (1: matrix cores where the stream allows; 2..22: test hook, see ccd.h).  None = library default (all on)."""
         self._h = C.c_void_p()
         check(lib().ccd_batch_create(int(device), C.byref(self._h)), "ccd_batch_create")
         self.device = int(device)
@@ -38,6 +40,8 @@ class DecodeBatch:
             check(lib().ccd_batch_set_option(self._h, self.OPT_FUSED_DEC, int(bool(fused_dec))), "ccd_batch_set_option")
         if keep_float is not None:
             check(lib().ccd_batch_set_option(self._h, self.OPT_KEEP_FLOAT, int(bool(keep_float))), "ccd_batch_set_option")
+        if mfma_arm is not None:
+            check(lib().ccd_batch_set_option(self._h, self.OPT_MFMA_ARM, int(mfma_arm)), "ccd_batch_set_option")
         self._meta: List[Tuple[int, int]] = []
 
     def close(self):

@@ -15,9 +15,11 @@ namespace ccd {
 // kernels (ccd_entropy.hip, ccd_float.hip)
 size_t entropy_lds_bytes(int dim, int arm_len);
 hipError_t launch_entropy(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream);
-size_t entropy_pipe_lds_bytes(int dim, int n_layers);
+size_t entropy_pipe_lds_bytes(int dim, int n_layers, int ring_rows, int mfma);
+int entropy_pipe_ring_rows(int max_grid_w);
+bool entropy_pipe_supports_mfma(int dim, int n_layers, int n_ifce_out, int narrow, int max_grid_w, long long max_abs_weight);
 bool entropy_pipe_supports(int dim, int n_layers, int narrow, int max_grid_w);
-hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, int mfma, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_laplace_bounds(const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* sym,
                                  const float* scale_table, int64_t n, uint32_t* left, uint32_t* right, hipStream_t stream);
 hipError_t launch_upsample_step(const UpsampleLevel* d_levels, const uint32_t* d_zmap, int n_z, int max_w, int max_h, hipStream_t stream);
@@ -110,6 +112,8 @@ struct Slot {
     int plane_h[3] = {0, 0, 0}, plane_w[3] = {0, 0, 0};
     int32_t* d_status = nullptr;
     bool use_pipe = false;   // pipelined entropy kernel (32-bit operands) or the generic one
+    bool use_mfma = false;   // ... with the ARM's layers on the matrix cores (limb-split int8)
+    int ring_rows = 64;      // rows of the pipelined kernel's decoded-symbol ring
     size_t lds_generic = 0, lds_pipe = 0;
     int status = CCD_OK;
     int32_t host_status[64] = {0};
@@ -123,7 +127,7 @@ struct ccd_batch {
     EntropyParams* d_params = nullptr;   // [pipe slots..., generic slots...]
     int n_params_uploaded = 0;
     int n_pipe = 0, n_generic = 0;
-    struct PipeGroup { int nv, first, n; };
+    struct PipeGroup { int nv, mfma, first, n; size_t lds; };
     std::vector<PipeGroup> pipe_groups;
     float* d_scale_table = nullptr;
     double* d_rcp_table = nullptr;
@@ -140,6 +144,7 @@ struct ccd_batch {
     void* d_fdec_work = nullptr;
     int opt_fused_dec = 1;               // CCD_OPT_FUSED_DEC
     int opt_keep_float = 1;              // CCD_OPT_KEEP_FLOAT
+    int opt_mfma_arm = 0;                // CCD_OPT_MFMA_ARM (off: bit-exact but slower than the vector-ALU producers)
     // upsampling: step k of every slot's pyramid in one launch
     struct UpsStep { int first_z, n_z, max_w, max_h; };
     std::vector<UpsStep> ups_steps;
@@ -184,6 +189,7 @@ int ccd_batch_create(int device, ccd_batch** out) {
     b->device = device;
     if (const char* e = std::getenv("CCD_FORCE_GENERIC")) b->force_generic = std::atoi(e);
     if (const char* e = std::getenv("CCD_FUSED_DEC")) b->opt_fused_dec = std::atoi(e);
+    if (const char* e = std::getenv("CCD_MFMA_ARM")) b->opt_mfma_arm = std::atoi(e);
     if (hipMalloc(&b->d_scale_table, sizeof(kScaleBits)) != hipSuccess) { delete b; return CCD_ERR_NOMEM; }
     if (hipMemcpy(b->d_scale_table, kScaleBits, sizeof(kScaleBits), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(b->d_scale_table); delete b; return CCD_ERR_HIP;
@@ -274,7 +280,15 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     int max_w = 0;
     for (int g = 0; g < h.n_grids; ++g) max_w = std::max(max_w, static_cast<int>(h.grid_w[g]));
     s.use_pipe = !b->force_generic && entropy_pipe_supports(h.total_context_arm, h.n_hidden_layers_arm + 1, net.arm.narrow ? 1 : 0, max_w);
-    s.lds_pipe = entropy_pipe_lds_bytes(h.total_context_arm, h.n_hidden_layers_arm + 1);
+    {
+        long long max_w_abs = 0;
+        for (const FixedLayer& L : net.arm.layers) for (int64_t w : L.w) max_w_abs = std::max<long long>(max_w_abs, w < 0 ? -w : w);
+        for (int64_t w : net.arm.ws) max_w_abs = std::max<long long>(max_w_abs, w < 0 ? -w : w);
+        s.use_mfma = s.use_pipe && b->opt_mfma_arm &&
+                     entropy_pipe_supports_mfma(h.total_context_arm, h.n_hidden_layers_arm + 1, h.output_feature_ifce, net.arm.narrow ? 1 : 0, max_w, max_w_abs);
+    }
+    s.ring_rows = s.use_mfma ? std::max(entropy_pipe_ring_rows(max_w), 64) : 512;  // the matrix-core variant needs the LDS for its operand tables
+    s.lds_pipe = entropy_pipe_lds_bytes(h.total_context_arm, h.n_hidden_layers_arm + 1, s.ring_rows, s.use_mfma ? 1 : 0);
     s.lds_generic = entropy_lds_bytes(h.total_context_arm, static_cast<int>(arm_blob.size()));
     if (!s.use_pipe && s.lds_generic > 160 * 1024) return CCD_ERR_UNSUPPORTED;  // ARM too large for the LDS-resident kernels
 
@@ -518,6 +532,8 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     E.dim = h.total_context_arm; E.n_spatial = h.spatial_context_arm; E.n_ifce_out = h.output_feature_ifce;
     E.n_layers = h.n_hidden_layers_arm + 1;
     E.narrow = net.arm.narrow ? 1 : 0;
+    E.ring_rows = s.ring_rows;
+    E.mfma = s.use_mfma ? std::min(std::max(b->opt_mfma_arm == 1 ? 23 : b->opt_mfma_arm, 1), 23) : 0;
     E.has_ifce = h.has_ifce_resolution;
     context_offsets(h.spatial_context_arm, E.ctx_dy, E.ctx_dx);
     E.arm = A.at<int64_t>(o_arm); E.arm_len = static_cast<int32_t>(arm_blob.size());
@@ -597,12 +613,16 @@ static int upload_params(ccd_batch* b) {
     if (b->d_params) { (void)hipFree(b->d_params); b->d_params = nullptr; }
     std::vector<EntropyParams> host;
     b->pipe_groups.clear();  // the pipelined kernel is instantiated per input width nv = ceil(dim / 4): one launch per width
-    for (int nv = 1; nv <= 8; ++nv) {
-        const int first = static_cast<int>(host.size());
-        for (int i = 0; i < n; ++i)
-            if (b->slots[i]->use_pipe && (b->slots[i]->ep.dim + 3) / 4 == nv) host.push_back(b->slots[i]->ep);
-        if (static_cast<int>(host.size()) > first) b->pipe_groups.push_back({nv, first, static_cast<int>(host.size()) - first});
-    }
+    for (int nv = 1; nv <= 8; ++nv)
+        for (int mf = 0; mf < 2; ++mf) {
+            const int first = static_cast<int>(host.size());
+            size_t lds = 0;
+            for (int i = 0; i < n; ++i) {
+                const Slot& sl = *b->slots[i];
+                if (sl.use_pipe && (sl.ep.dim + 3) / 4 == nv && (sl.use_mfma ? 1 : 0) == mf) { host.push_back(sl.ep); lds = std::max(lds, sl.lds_pipe); }
+            }
+            if (static_cast<int>(host.size()) > first) b->pipe_groups.push_back({nv, mf, first, static_cast<int>(host.size()) - first, lds});
+        }
     b->n_pipe = static_cast<int>(host.size());
     for (int i = 0; i < n; ++i) if (!b->slots[i]->use_pipe) host.push_back(b->slots[i]->ep);
     b->n_generic = n - b->n_pipe;
@@ -796,7 +816,7 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
     int rc = upload_params(b);
     if (rc < 0) return rc;
     if (stage == 0) {
-        for (const auto& g : b->pipe_groups) HIP_TRY(launch_entropy_pipe(b->d_params + g.first, g.n, g.nv, b->lds_pipe, st));
+        for (const auto& g : b->pipe_groups) HIP_TRY(launch_entropy_pipe(b->d_params + g.first, g.n, g.nv, g.mfma, g.lds, st));
         HIP_TRY(launch_entropy(b->d_params + b->n_pipe, b->n_generic, b->lds_generic, st));
         return CCD_OK;
     }
@@ -852,7 +872,7 @@ int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64) {
 int ccd_batch_slot_kernels(const ccd_batch* b, int slot) {
     if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
     const Slot& s = *b->slots[slot];
-    return (s.use_pipe ? 1 : 0) | (s.use_fused_syn ? 2 : 0) | (s.use_fused_dec ? 4 : 0);
+    return (s.use_pipe ? 1 : 0) | (s.use_fused_syn ? 2 : 0) | (s.use_fused_dec ? 4 : 0) | (s.use_mfma ? 8 : 0);
 }
 
 const float* ccd_batch_output(const ccd_batch* b, int slot) {
@@ -870,6 +890,7 @@ int ccd_batch_set_option(ccd_batch* b, int option, int value) {
     switch (option) {
         case CCD_OPT_FUSED_DEC: b->opt_fused_dec = value; return CCD_OK;
         case CCD_OPT_KEEP_FLOAT: b->opt_keep_float = value; return CCD_OK;
+        case CCD_OPT_MFMA_ARM: b->opt_mfma_arm = value; return CCD_OK;
         default: return CCD_ERR_ARG;
     }
 }

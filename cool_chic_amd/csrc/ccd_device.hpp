@@ -34,6 +34,9 @@ struct EntropyParams {
     const float* scale_table;  // 2561 float32 scales
     const double* rcp_table;   // RN(1 / (double)scale): correctly rounded reciprocals for the f64 quotient
     int32_t* status;         // [0] error code, [1] words consumed, [2..3] symbols decoded (lo, hi)
+    int32_t ring_rows;       // rows of the decoded-symbol ring in LDS: power of two >= widest grid / 10 + 6
+    int32_t mfma;            // > 0: the ARM's layers run on the matrix cores (limb-split int8, ccd_entropy_pipe.hip); the value
+                             // is the number of bits a hidden activation may have before the task is redone in int64 (23)
 };
 
 // Upsampling level: stack_in [c_in][h_in][w_in] f32 (or the coarsest int8 grid) ->

@@ -32,9 +32,11 @@ namespace ccd {
 #if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE >= 3
 #define PROF_T() __builtin_amdgcn_s_memtime()
 #define PROF_ADD(var, t0) var += __builtin_amdgcn_s_memtime() - (t0)
+#define PROF_SUB(var, t0) var -= __builtin_amdgcn_s_memtime() - (t0)
 #else
 #define PROF_T() 0ull
 #define PROF_ADD(var, t0) (void)(t0)
+#define PROF_SUB(var, t0) (void)(t0)
 #endif
 // level 2 only: stamps per task of producer 0 (idle before the early wait, early work, late wait, late work)
 #if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
@@ -59,7 +61,8 @@ constexpr int kRows = 128;                  // table rows in LDS = slots x pixel
 // (small grids are bound by the producers' latency, not their throughput).
 constexpr int kSlots = 16;                  // most batch slots in flight (power of two)
 constexpr int kMaxNV = 8;                   // MLP width <= 32 (in 4-wide vectors)
-constexpr int kRingRows = 512;              // rows of the decoded-symbol ring (>= live rows + 4; 4K: 384 + 4)
+constexpr int kRingRows = 512;              // most rows of the decoded-symbol ring (>= live rows + 4; 4K: 384 + 4); a slot uses
+                                            // EntropyParams::ring_rows of them (power of two >= widest grid / 10 + 6)
 // Scale index up to which a 14-symbol window [round(mu) - 7, round(mu) + 6] is used (b <= 1: 99.3 % of the symbols of
 // a real stream, window misses ~3e-4): four pixels' windows are then built by ONE pass of the wave.
 constexpr int kNarrowMaxScale = kScaleOffset;
@@ -139,12 +142,14 @@ struct PipeCtx {
     LdsRef<const float> s_scale;  // [kNumScale] b        pixel would put an L2 round trip on every task's critical path)
     LdsRef<int32_t> s_w;          // transposed int32 weights Wt[out][in_pad]
     LdsRef<int64_t> s_b;          // biases: hidden layers, output (2), stabiliser (2)
-    LdsRef<int32_t> s_act;        // [kProducers][8][in_pad] (a task holds at most 8 pixels)
-    LdsRef<int8_t> s_ring;        // [kRingRows][64]
+    LdsRef<int32_t> s_act;        // [kProducers][8][in_pad] (a task holds at most 8 pixels); [kProducers][16][in_pad] with MF
+    LdsRef<uint32_t> s_a;         // MF: A operands [mf_tables][64] x 16 bytes
+    LdsRef<int8_t> s_ring;        // [ring_mask + 1][64]
     LdsRef<uint32_t> s_ready;     // [kSlots] parts of the slot's batch finished by the producers (cleared by the decoder)
     LdsRef<uint32_t> s_consumed;
     LdsRef<uint32_t> s_abort;
     int dim, n_layers, n_sp, n_if, n_w_hidden;
+    int ring_mask;         // ring rows - 1
     // per grid
     int H, W, fin, fh, fw;
     int task_pix;          // pixels per producer task in this grid (8, 4 or 2)
@@ -223,6 +228,7 @@ struct StepIter {
 // =================================================================================================
 // DECODER (wave 0): one grid.  Returns the batch sequence number after the grid.
 // =================================================================================================
+template <bool MF>
 __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) {
     const int lane = threadIdx.x & 63;
     const EntropyParams& P = *C.P;
@@ -247,6 +253,10 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     const int task_shift = task_pix == 8 ? 3 : (task_pix == 4 ? 2 : 1);
     // LDS byte addresses (the dynamic LDS starts at 0) and per-lane constants of the step loop below
     const uint32_t ready_base = C.s_ready.off, consumed_addr = C.s_consumed.off, ring_base = C.s_ring.off;
+    // the ring has kRingRows rows unless the matrix-core variant needs the LDS (then EntropyParams::ring_rows): a constant
+    // here keeps one more SGPR out of the step loop
+    const int ring_mask = MF ? uni(C.ring_mask) : kRingRows - 1;
+    const uint32_t ring_cells_mask = static_cast<uint32_t>(ring_mask) * 64u + 63u;
     const uint32_t top_base = C.s_meta.off + static_cast<uint32_t>(offsetof(RowMeta, top));
     const uint32_t tab_lane = C.s_tab.off + static_cast<uint32_t>(lane) * 8u;
     const uint32_t lane_top_off = static_cast<uint32_t>(lane & (bpx - 1)) * 4u;
@@ -264,7 +274,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
         const uint32_t n_step = static_cast<uint32_t>(it.n);
         uint32_t i = 0, mode = 0;
         // lane p <-> pixel p of the step's first batch; both advance by one batch in the epilogue
-        uint32_t v_ring = static_cast<uint32_t>((((it.y0 + lane) & (kRingRows - 1)) << 6) | ((it.x0 + 10 * it.y0) & 63));
+        uint32_t v_ring = static_cast<uint32_t>((((it.y0 + lane) & ring_mask) << 6) | ((it.x0 + 10 * it.y0) & 63));
         uint32_t v_goff = static_cast<uint32_t>((it.y0 + lane) * grid_w + (it.x0 - 10 * lane));
         while (true) {
             uint32_t status, k_rare;
@@ -434,7 +444,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "global_store_byte %[goff], v52, %[lat]\n\t"
                 "s_mov_b64 exec, s[60:61]\n\t"
                 "v_add_u32 %[ring], s71, %[ring]\n\t"
-                "v_and_b32 %[ring], 0x7fff, %[ring]\n\t"
+                "v_and_b32 %[ring], %[rmask], %[ring]\n\t"
                 "v_add_u32 %[goff], %[gstride], %[goff]\n\t"
                 "v_mov_b32 v51, s59\n\t"
                 "v_mov_b32 v52, 0\n\t"
@@ -575,7 +585,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                   [ring] "+v"(v_ring), [goff] "+v"(v_goff), [spins] "+s"(n_spins), [wpos] "+s"(word_pos), [st] "=s"(status), [kr] "=s"(k_rare)
                 : [mode] "s"(mode), [n] "s"(n_step), [smask] "s"(static_cast<uint32_t>(slot_mask)),
                   [bshift] "s"(bpx_shift), [tshift] "s"(static_cast<uint32_t>(task_shift)),
-                  [rdy] "s"(ready_base), [cons] "s"(consumed_addr), [topb] "s"(top_base), [ringb] "s"(ring_base),
+                  [rdy] "s"(ready_base), [cons] "s"(consumed_addr), [topb] "s"(top_base), [ringb] "s"(ring_base), [rmask] "s"(ring_cells_mask),
                   [gstride] "s"(glo_stride), [wbuf] "v"(wbuf), [wbase] "s"(wbase), [tabl] "v"(tab_lane), [lane] "v"(static_cast<uint32_t>(lane)),
                   [l4] "v"(lane_top_off), [lat] "s"(lat_addr)
                 : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
@@ -687,7 +697,154 @@ __device__ __forceinline__ void mad64(int64_t& acc, int32_t x, int32_t w) {
     _Pragma("unroll") for (int g_ = 0; g_ < (NCH); ++g_) mad64(ACC[g_], (X).z, Wv[g_].z); \
     _Pragma("unroll") for (int g_ = 0; g_ < (NCH); ++g_) mad64(ACC[g_], (X).w, Wv[g_].w);
 
-template <int NV, int kLpp>
+
+// ---- the ARM on the matrix cores (MF = true) ---------------------------------------------------------------------------
+// v_mfma_i32_16x16x64_i8 with N = the (<= 16) pixels of a task, M = output neurons, K = (input, signed-digit byte):
+// every operand is split into signed bytes (x = sum d_j 256^j, d_j in [-128, 127]: the bytes of (x + 0x808080) ^ 0x808080),
+// byte products with i + j = s accumulate in one i32 tile (|partial| < 2^21) and the tiles are recombined with 64-bit
+// shift-adds, so the result is the int64 sum of armint.py:180-203 exactly.  Lane l = 16 g + n holds pixel n; the accumulator
+// of rows 4 g + r lands in lane group g, register r - which is where the next layer's B operand wants it when tile 1 puts
+// neurons 16..19 at rows 0, 4, 8, 12: no cross-lane movement between layers.  Envelope (host: ccd_api.cpp): `narrow`
+// (so |IFCE feature| < 2^15: two bytes), dim <= 20, <= 8 IFCE features, |weight| < 2^23 (three bytes).  Hidden activations
+// travel as three bytes; a task that meets one >= 2^23 (128.0 in Q16; never seen on real streams; EntropyParams::mfma holds
+// the exponent so that tests can lower it) is redone
+// by mf_exact_task in plain int64.  tools/ubench/arm_mfma.hip is the stand-alone version of this scheme.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int kMfLayer1 = 8;    // A operands of the first layer: 2 tiles x 4 byte sums (tile 1 also holds the stabiliser rows 1, 2)
+constexpr int kMfHidden = 10;   // per further hidden layer: 2 tiles x 5 byte sums
+constexpr int kMfOut = 5;       // output layer: rows 0 (mu), 1 (log-scale)
+__host__ __device__ constexpr int mf_tables(int n_layers) { return kMfLayer1 + (n_layers - 2) * kMfHidden + kMfOut; }
+
+__device__ __forceinline__ uint32_t mf_byte(int32_t w, int j) {  // signed digit j of w as a byte (0 outside 0..2)
+    const uint32_t d = (static_cast<uint32_t>(w) + 0x00808080u) ^ 0x00808080u;
+    return (j < 0 || j > 2) ? 0u : ((d >> (8 * j)) & 0xffu);
+}
+// Which input the K-slot (lane group g, byte beta) of a layer carries and which of its bytes; -1: none.
+// First layer: spatial context k = g + 4 t at byte t (one byte), IFCE feature f = g + 4 u at bytes 8 + 2 u, 9 + 2 u.
+// Later layers: activations 4 g + a (a < 4: tile 0, registers 0..3) and 16 + g (a = 4: tile 1, register 0), 3 bytes each.
+__device__ __forceinline__ int mf_slot_input(bool first, int g, int beta, int n_sp, int n_if, int dim, int* limb) {
+    if (first) {
+        if (beta < 8) { *limb = 0; const int k = g + 4 * beta; return k < n_sp ? k : -1; }
+        if (beta < 12) { *limb = (beta - 8) & 1; const int f = g + 4 * ((beta - 8) >> 1); return f < n_if ? n_sp + f : -1; }
+        return -1;
+    }
+    if (beta >= 15) return -1;
+    const int a = beta / 3;
+    *limb = beta - 3 * a;
+    const int k = a < 4 ? 4 * g + a : 16 + g;
+    return k < dim ? k : -1;
+}
+// 5 activations -> 15 signed-digit bytes in 4 dwords (byte 15 = 0)
+__device__ __forceinline__ i32x4 mf_pack15(const int32_t (&a)[5]) {
+    uint32_t d[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) d[i] = ((static_cast<uint32_t>(a[i]) + 0x00808080u) ^ 0x00808080u) & 0x00ffffffu;
+    i32x4 r;
+    r[0] = static_cast<int>(d[0] | (d[1] << 24));
+    r[1] = static_cast<int>((d[1] >> 8) | (d[2] << 16));
+    r[2] = static_cast<int>((d[2] >> 16) | (d[3] << 8));
+    r[3] = static_cast<int>(d[4]);
+    return r;
+}
+// bias + (sum_s c_s 256^s) 2^16: first layer (its inputs are the raw values, armint.py:193 shifts them by 16)
+__device__ __forceinline__ int64_t mf_comb4(const i32x4 (&c)[4], int r, int64_t bias) {
+    const int32_t lo = c[0][r] + (c[1][r] << 8), hi = c[2][r] + (c[3][r] << 8);
+    return bias + (static_cast<int64_t>(lo) << 16) + (static_cast<int64_t>(hi) << 32);
+}
+// bias + sum_s c_s 256^s: later layers (Q16 activations)
+__device__ __forceinline__ int64_t mf_comb5(const i32x4 (&c)[5], int r, int64_t bias) {
+    const int32_t lo = c[0][r] + (c[1][r] << 8), mid = c[2][r] + (c[3][r] << 8);
+    return bias + lo + (static_cast<int64_t>(mid) << 16) + (static_cast<int64_t>(c[4][r]) << 32);
+}
+
+// A operands [mf_tables][64 lanes] x 16 bytes from the staged int32 weights (whole workgroup, once per stream).
+__device__ void mf_build_tables(const PipeCtx& C, int in_pad, uint32_t* s_a_words, int tid) {
+    const int dim = C.dim, n_layers = C.n_layers, n_sp = C.n_sp, n_if = C.n_if;
+    const int n_tab = mf_tables(n_layers);
+    for (int e = tid; e < n_tab * 256; e += kPipeThreads) {
+        const int idx = e >> 8, ln = (e >> 2) & 63, dw = e & 3, m = ln & 15, g = ln >> 4;
+        int layer, tile, s;
+        if (idx < kMfLayer1) { layer = 0; tile = idx >> 2; s = idx & 3; }
+        else {
+            const int j = idx - kMfLayer1, hl = j / kMfHidden;
+            if (hl < n_layers - 2) { layer = 1 + hl; tile = (j - hl * kMfHidden) / 5; s = (j - hl * kMfHidden) % 5; }
+            else { layer = n_layers - 1; tile = 0; s = j - (n_layers - 2) * kMfHidden; }
+        }
+        const int32_t* row = nullptr;  // Wt[out][.] of the output this row computes
+        if (layer == n_layers - 1) { if (m < 2) row = C.s_w + C.n_w_hidden + m * in_pad; }
+        else {
+            int o = -1;
+            if (tile == 0) o = m;
+            else if ((m & 3) == 0) o = 16 + (m >> 2);
+            if (o >= 0 && o < dim) row = C.s_w + layer * dim * in_pad + o * in_pad;
+            if (layer == 0 && tile == 1 && (m == 1 || m == 2)) row = C.s_w + C.n_w_hidden + 2 * in_pad + (m - 1) * in_pad;  // stabiliser
+        }
+        uint32_t word = 0;
+        if (row)
+            for (int bb = 0; bb < 4; ++bb) {
+                int limb = 0;
+                const int k = mf_slot_input(layer == 0, g, dw * 4 + bb, n_sp, n_if, dim, &limb);
+                if (k >= 0) word |= mf_byte(row[k], s - limb) << (8 * bb);
+            }
+        s_a_words[e] = word;
+    }
+}
+
+// The task in plain int64 (rare: an activation left the 3-byte range).  Lanes 0..cnt-1 each run their pixel's whole MLP
+// through two private rows of the wave's LDS tile [16][in_pad]; returns the two table indices like the fast path.
+template <int NV>
+__device__ __forceinline__ void mf_exact_task(const PipeCtx& C, int32_t* tile, int n, int y, int x, int W, int fin, int fw, int feat_plane,
+                                              int ring_mask, int64_t& out_mu, int64_t& out_ls) {
+    constexpr int in_pad = 4 * NV;
+    const EntropyParams& P = *C.P;
+    const int dim = C.dim, n_layers = C.n_layers, n_sp = C.n_sp;
+    int32_t* ain = tile + n * in_pad;
+    int32_t* aout = tile + (8 + n) * in_pad;
+#pragma unroll 1
+    for (int k = 0; k < dim; ++k) {
+        int32_t v = 0;
+        if (k < n_sp) {
+            const int yy = y - P.ctx_dy[k], xx = x + P.ctx_dx[k];
+            if (yy >= 0 && xx >= 0 && xx < W) v = C.s_ring[(yy & ring_mask) * 64 + ((xx + 10 * yy) & 63)];
+        } else if (fin > 0) {
+            v = P.ifce_feat[(k - n_sp) * feat_plane + (y >> 1) * fw + (x >> 1)];
+        }
+        ain[k] = v << 16;
+    }
+    int64_t stab[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        int64_t acc = C.s_b[(n_layers - 1) * dim + 2 + o];
+        const int32_t* w = C.s_w + C.n_w_hidden + 2 * in_pad + o * in_pad;
+#pragma unroll 1
+        for (int k = 0; k < dim; ++k) acc += static_cast<int64_t>(ain[k]) * w[k];
+        stab[o] = acc;
+    }
+#pragma unroll 1
+    for (int l = 0; l < n_layers - 1; ++l) {
+#pragma unroll 1
+        for (int o = 0; o < dim; ++o) {
+            int64_t acc = C.s_b[l * dim + o];
+            const int32_t* w = C.s_w + l * dim * in_pad + o * in_pad;
+#pragma unroll 1
+            for (int k = 0; k < dim; ++k) acc += static_cast<int64_t>(ain[k]) * w[k];
+            aout[o] = static_cast<int32_t>((acc < 0 ? 0 : acc) >> 16);
+        }
+        int32_t* t = ain; ain = aout; aout = t;
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        int64_t acc = C.s_b[(n_layers - 1) * dim + o] + stab[o];
+        const int32_t* w = C.s_w + C.n_w_hidden + o * in_pad;
+#pragma unroll 1
+        for (int k = 0; k < dim; ++k) acc += static_cast<int64_t>(ain[k]) * w[k];
+        if (o == 0) out_mu = acc; else out_ls = acc;
+    }
+}
+
+// MF: this grid's tasks run the ARM on the matrix cores; DYN_RING: the kernel's ring of decoded symbols has
+// EntropyParams::ring_rows rows instead of kRingRows (every grid of a matrix-core kernel, whichever producer serves it).
+template <int NV, int kLpp, bool MF, bool DYN_RING>
 __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned long long* prof) {
     constexpr int in_pad = 4 * NV;
     constexpr int kTaskPix = 64 / kLpp;
@@ -703,8 +860,11 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     const int dim = uni(C.dim), n_layers = uni(C.n_layers), n_sp = uni(C.n_sp), W = uni(C.W);
     const int k_left = uni(C.k_left), fin = uni(C.fin), fw = uni(C.fw);
     const uint32_t seq_base = uni(C.seq_base);
-    int32_t* act = C.s_act + pw * 8 * in_pad;        // this wave's activation tile [kTaskPix][in_pad]
-    const int px = lane / kLpp, q = lane % kLpp;     // pixel of the task, lane within its group
+    int32_t* act = C.s_act + pw * (MF ? 16 : 8) * in_pad;  // this wave's activation tile [kTaskPix][in_pad] (MF: [16][in_pad], the exact redo)
+    const int px = MF ? (lane & 15) : lane / kLpp;   // pixel of the task
+    const int q = MF ? (lane >> 4) : lane % kLpp;    // lane within the pixel's group (MF: K-slot group of the matrix operands)
+    const int ring_mask = DYN_RING ? uni(C.ring_mask) : kRingRows - 1, n_if = uni(C.n_if), mf_bits = uni(P.mfma);
+    (void)n_if; (void)mf_bits;
     const int4* act_row = reinterpret_cast<const int4*>(act + px * in_pad);
     // Per-lane constants of the gather: the lane always fetches inputs k = q + kLpp t.  Read through the parameter block
     // inside the task loop they were global loads on every task's path.
@@ -719,6 +879,27 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     }
     const glb_ptr<const int32_t> ifce_feat = (glb_ptr<const int32_t>)P.ifce_feat;
     const int feat_plane = uni(C.fh) * fw;
+    // MF: the lane's context offsets (k = q + 4 t, dy << 16 | dx) and the left neighbour's weights of the lane's rows
+    // (neurons 4 q .. 4 q + 3 and 16 + q, then the two stabiliser outputs)
+    int32_t mf_dxy[8], mf_wl[7];
+    if constexpr (MF) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int k = q + 4 * t;
+            mf_dxy[t] = k < n_sp ? static_cast<int32_t>((static_cast<uint32_t>(P.ctx_dy[k]) << 16) | (static_cast<uint32_t>(P.ctx_dx[k]) & 0xffffu)) : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            const int o = r < 4 ? 4 * q + r : 16 + q;
+            int32_t w = 0;
+            if (k_left >= 0) {
+                if (r < 5) w = o < dim ? C.s_w[o * in_pad + k_left] : 0;
+                else w = C.s_w[C.n_w_hidden + 2 * in_pad + (r - 5) * in_pad + k_left];
+            }
+            mf_wl[r] = w;
+        }
+    }
+    (void)mf_dxy; (void)mf_wl;
     StepIter it;
     it.init(uni(C.H), W);
     uint32_t seq = seq_base, prev_first = seq_base;
@@ -749,7 +930,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 for (int t = 0; t < NOUT; ++t) {
                     const int k = q + kLpp * t;
                     fv[t] = 0;
-                    if (px < cnt && k >= n_sp && k < dim && fin > 0)
+                    if (!MF && px < cnt && k >= n_sp && k < dim && fin > 0)
                         fv[t] = ifce_feat[(k - n_sp) * feat_plane + (y >> 1) * fw + (x >> 1)];
                 }
                 // ---- Two waits.  Of all contexts only the left neighbour (y, x - 1) lies in the previous step (pixel i of this
@@ -763,8 +944,184 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 need = max(need, seq_base);
                 uint32_t need_early = seq_base;
                 if (prev2_nb > 0) need_early = max(need_early, prev2_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev2_y0), prev2_n - 1) / kBpx) + 1);
-                const unsigned long long lt_a = LPROF_T(pw == 0);
-                (void)lt_a;
+                unsigned long long lt_a = 0, lt_b = 0, lt_c = 0, lt_d = 0;  // level-2 profile stamps
+                (void)lt_a; (void)lt_b; (void)lt_c; (void)lt_d;
+                unsigned narrow_mask = 0;  // bit i: pixel i of the task is narrow (wave-uniform)
+                RowMeta& meta = *C.s_meta;
+                if constexpr (MF) {
+                    const int n = px, g = q;  // lane = 16 g + n: pixel n of the task, K-slot group g of the matrix operands
+                    const bool live = n < cnt;
+                    // ---- IFCE features (two signed bytes each) do not depend on this grid: fetch them before waiting on the decoder
+                    int32_t f0 = 0, f1 = 0;
+                    if (live && fin > 0) {
+                        const int fo = (y >> 1) * fw + (x >> 1);
+                        if (g < n_if) f0 = ifce_feat[g * feat_plane + fo];
+                        if (g + 4 < n_if) f1 = ifce_feat[(g + 4) * feat_plane + fo];
+                    }
+                    lt_a = LPROF_T(pw == 0);
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
+                    if (pw == 0 && lt_prev_end) prof[4] += lt_a - lt_prev_end;
+#endif
+                    {
+                        const unsigned long long t0 = PROF_T();
+                        if (!wait_ge(C.s_consumed, split ? need_early : need, C.s_abort)) { ok = false; break; }
+                        PROF_ADD(prof[0], t0);
+                    }
+                    lt_b = LPROF_T(pw == 0);
+                    const unsigned long long t_g = PROF_T();
+                    // ---- B operand of the first layer: context k = g + 4 t at byte t, the two features at bytes 8..11
+                    uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        if (4 * t < n_sp) {
+                            const int k = g + 4 * t;
+                            // unconditional read of a clamped cell + select: no exec-mask branches on the task's path
+                            const int yy = y - (mf_dxy[t] >> 16), xx = x + static_cast<int16_t>(mf_dxy[t] & 0xffff);
+                            const bool take = live && k < n_sp && yy >= 0 && xx >= 0 && xx < W && !(split && k == k_left);
+                            const int cell = take ? (yy & ring_mask) * 64 + ((xx + 10 * yy) & 63) : 0;
+                            int32_t v = C.s_ring[cell];
+                            v = take ? v : 0;
+                            if (t < 4) w0 |= static_cast<uint32_t>(v & 0xff) << (8 * t);
+                            else w1 |= static_cast<uint32_t>(v & 0xff) << (8 * (t - 4));
+                        }
+                    }
+                    const uint32_t d0 = (static_cast<uint32_t>(f0) + 0x8080u) ^ 0x8080u, d1 = (static_cast<uint32_t>(f1) + 0x8080u) ^ 0x8080u;
+                    const i32x4 bop = {static_cast<int>(w0), static_cast<int>(w1), static_cast<int>((d0 & 0xffffu) | (d1 << 16)), 0};
+                    PROF_ADD(prof[1], t_g);
+                    const unsigned long long t_m = PROF_T();
+                    const i32x4* sa = reinterpret_cast<const i32x4*>(static_cast<uint32_t*>(C.s_a)) + lane;
+                    const i32x4 zero4 = {0, 0, 0, 0};
+                    // ---- first layer and stabiliser on the early inputs: 2 tiles x 4 byte sums
+                    int64_t pre[5], st0, st1;
+                    {
+                        i32x4 c1[2][4];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) c1[t][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(sa[(t * 4 + s) * 64], bop, zero4, 0, 0, 0);
+                        const int64_t* bl = C.s_b;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int o = 4 * g + r;
+                            const int64_t bias = bl[min(o, dim - 1)];
+                            pre[r] = mf_comb4(c1[0], r, o < dim ? bias : 0);
+                        }
+                        {
+                            const int64_t bias = bl[min(16 + g, dim - 1)];
+                            pre[4] = mf_comb4(c1[1], 0, 16 + g < dim ? bias : 0);
+                        }
+                        st0 = mf_comb4(c1[1], 1, bl[(n_layers - 1) * dim + 2]);
+                        st1 = mf_comb4(c1[1], 2, bl[(n_layers - 1) * dim + 3]);
+                    }
+                    // A operands and biases of the next two stages: on their way before the left neighbour is waited for
+                    const i32x4* sl_out = sa + (kMfLayer1 + (n_layers - 2) * kMfHidden) * 64;
+                    i32x4 a_h[10], a_o[5];
+                    int64_t b_h[5];
+                    if (n_layers > 2) {
+#pragma unroll
+                        for (int s = 0; s < 10; ++s) a_h[s] = sa[(kMfLayer1 + s) * 64];
+#pragma unroll
+                        for (int r = 0; r < 5; ++r) {
+                            const int o = r < 4 ? 4 * g + r : 16 + g;
+                            const int64_t bias = C.s_b[dim + min(o, dim - 1)];
+                            b_h[r] = o < dim ? bias : 0;
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 5; ++s) a_o[s] = sl_out[s * 64];
+                    const int64_t b_mu = C.s_b[(n_layers - 1) * dim], b_ls = C.s_b[(n_layers - 1) * dim + 1];
+                    PROF_ADD(prof[4], t_m);  // first layer
+                    // ---- the left neighbour: wait for it (and for the slot), add its term as a rank-1 update
+                    int32_t xleft = 0;
+                    lt_c = LPROF_T(pw == 0);
+                    if (split) {
+                        const unsigned long long t0 = PROF_T();
+                        if (!wait_ge(C.s_consumed, need, C.s_abort)) { ok = false; break; }
+                        PROF_ADD(prof[0], t0);
+                        PROF_SUB(prof[2], t0);  // the MLP's stamps bracket this wait: take it out of them
+                        PROF_ADD(prof[5], t0);  // late wait
+                        if (live && x >= 1) xleft = static_cast<int32_t>(C.s_ring[(y & ring_mask) * 64 + ((x - 1 + 10 * y) & 63)]) << 16;
+                    }
+                    lt_d = LPROF_T(pw == 0);
+                    const unsigned long long t_h = PROF_T();
+                    int32_t av[5];
+                    uint32_t big = 0;  // OR of every hidden activation of the lane (they are >= 0)
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) {
+                        mad64(pre[r], xleft, mf_wl[r]);
+                        const int64_t a = pre[r] < 0 ? 0 : pre[r];
+                        av[r] = static_cast<int32_t>(a >> 16);
+                        big |= static_cast<uint32_t>(av[r]);
+                    }
+                    mad64(st0, xleft, mf_wl[5]);
+                    mad64(st1, xleft, mf_wl[6]);
+                    // ---- further hidden layers: (1 or 2) tiles x 5 byte sums each
+                    for (int l = 1; l < n_layers - 1; ++l) {
+                        const i32x4 b2 = mf_pack15(av);
+                        i32x4 c2[5], c2b[5];
+#pragma unroll
+                        for (int s = 0; s < 5; ++s) c2[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[s], b2, zero4, 0, 0, 0);
+                        if (dim > 16) {
+#pragma unroll
+                            for (int s = 0; s < 5; ++s) c2b[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_h[5 + s], b2, zero4, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int64_t a = mf_comb5(c2, r, b_h[r]);
+                            av[r] = static_cast<int32_t>((a < 0 ? 0 : a) >> 16);
+                            big |= static_cast<uint32_t>(av[r]);
+                        }
+                        av[4] = 0;
+                        if (dim > 16) {
+                            const int64_t a = mf_comb5(c2b, 0, b_h[4]);
+                            av[4] = static_cast<int32_t>((a < 0 ? 0 : a) >> 16);
+                            big |= static_cast<uint32_t>(av[4]);
+                        }
+                        if (l + 1 < n_layers - 1) {  // deeper networks: operands of the next hidden layer
+                            const i32x4* sl = sa + (kMfLayer1 + l * kMfHidden) * 64;
+#pragma unroll
+                            for (int s = 0; s < 10; ++s) a_h[s] = sl[s * 64];
+#pragma unroll
+                            for (int r = 0; r < 5; ++r) {
+                                const int o = r < 4 ? 4 * g + r : 16 + g;
+                                const int64_t bias = C.s_b[(l + 1) * dim + min(o, dim - 1)];
+                                b_h[r] = o < dim ? bias : 0;
+                            }
+                        }
+                    }
+                    PROF_ADD(prof[6], t_h);  // left term + further hidden layers
+                    const unsigned long long t_o = PROF_T();
+                    // ---- output layer: rows 0 (mu) and 1 (log-scale) land in lane group 0, next to the stabiliser
+                    int64_t out_mu, out_ls;
+                    {
+                        const i32x4 b3 = mf_pack15(av);
+                        i32x4 c3[5];
+#pragma unroll
+                        for (int s = 0; s < 5; ++s) c3[s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_o[s], b3, zero4, 0, 0, 0);
+                        out_mu = mf_comb5(c3, 0, b_mu) + st0;
+                        out_ls = mf_comb5(c3, 1, b_ls) + st1;
+                    }
+                    // an activation outside the 3-byte range anywhere in the task: redo the task in plain int64
+                    if (__ballot((big >> mf_bits) != 0u) != 0ull) {
+                        if (g == 0 && live) mf_exact_task<NV>(C, act, n, y, x, W, fin, fw, feat_plane, ring_mask, out_mu, out_ls);
+                    }
+                    const int64_t m8 = (out_mu >> 24) + kMuOffset, s8 = (out_ls >> 24) + kScaleOffset;
+                    const int32_t idx_mu = static_cast<int32_t>(m8 < 0 ? 0 : (m8 > kNumMu - 1 ? kNumMu - 1 : m8));
+                    const int32_t idx_sc = static_cast<int32_t>(s8 < 0 ? 0 : (s8 > kNumScale - 1 ? kNumScale - 1 : s8));
+                    const int mpx = slot * kBpx + half * kTaskPix + n;  // table row of the pixel
+                    if (g == 0 && live) {
+                        meta.mu_idx[mpx] = idx_mu;
+                        meta.b[mpx] = static_cast<double>(C.s_scale[idx_sc]);
+                        meta.rcp[mpx] = C.s_rcp[idx_sc];
+                    }
+                    narrow_mask = static_cast<unsigned>(__ballot(g == 0 && live && idx_sc <= kNarrowMaxScale)) & 0xffffu;
+                    PROF_ADD(prof[2], t_m);
+                    PROF_ADD(prof[7], t_o);
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE >= 3
+                    prof[8] += 1;
+#endif
+                } else {
+                lt_a = LPROF_T(pw == 0);
 #if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
                 if (pw == 0 && lt_prev_end) prof[4] += lt_a - lt_prev_end;
 #endif
@@ -773,8 +1130,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     if (!wait_ge(C.s_consumed, split ? need_early : need, C.s_abort)) { ok = false; break; }
                     PROF_ADD(prof[0], t0);
                 }
-                const unsigned long long lt_b = LPROF_T(pw == 0);
-                (void)lt_b;
+                lt_b = LPROF_T(pw == 0);
                 const unsigned long long t_g = PROF_T();
                 // ---- gather: lane q of the pixel's group fetches inputs k = q, q + 8, ... --------------------------
                 if (px < cnt) {
@@ -786,7 +1142,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                             if (k < n_sp) {
                                 const int yy = y - ctx_dy_l[t], xx = x + ctx_dx_l[t];
                                 v = (yy >= 0 && xx >= 0 && xx < W && !(split && k == k_left))
-                                        ? C.s_ring[(yy & (kRingRows - 1)) * 64 + ((xx + 10 * yy) & 63)] : 0;
+                                        ? C.s_ring[(yy & ring_mask) * 64 + ((xx + 10 * yy) & 63)] : 0;
                             }
                             act[px * in_pad + k] = v << 16;  // armint.py:193
                         }
@@ -844,16 +1200,16 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 }
                 // ---- the left neighbour: wait for it (and for the slot), add its term to the first layer and the stabiliser
                 int32_t xleft = 0;
-                const unsigned long long lt_c = LPROF_T(pw == 0);
-                (void)lt_c;
+                lt_c = LPROF_T(pw == 0);
                 if (split) {
                     const unsigned long long t0 = PROF_T();
                     if (!wait_ge(C.s_consumed, need, C.s_abort)) { ok = false; break; }
                     PROF_ADD(prof[0], t0);
-                    if (px < cnt && x >= 1) xleft = static_cast<int32_t>(C.s_ring[(y & (kRingRows - 1)) * 64 + ((x - 1 + 10 * y) & 63)]) << 16;
+                    PROF_SUB(prof[2], t0);  // the MLP's stamps bracket this wait: take it out of them
+                    PROF_SUB(prof[6], t0);
+                    if (px < cnt && x >= 1) xleft = static_cast<int32_t>(C.s_ring[(y & ring_mask) * 64 + ((x - 1 + 10 * y) & 63)]) << 16;
                 }
-                const unsigned long long lt_d = LPROF_T(pw == 0);
-                (void)lt_d;
+                lt_d = LPROF_T(pw == 0);
                 mad64(so[0], xleft, wleft_stab);
                 const int64_t stab = so[0] + so[1];
                 if (n_layers >= 2) {
@@ -897,7 +1253,6 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 PROF_ADD(prof[6], t_h);
                 const unsigned long long t_o = PROF_T();
                 // output layer (q = 0: mu, q = 1: log-scale) -> table indices -> per-pixel table parameters
-                RowMeta& meta = *C.s_meta;
                 const int mpx = slot * kBpx + half * kTaskPix + px;  // table row of the pixel
                 int32_t idx = 0;
                 if (q < 2) {
@@ -925,23 +1280,25 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 }
                 // bit (px * kLpp + 1) of the ballot: pixel px of the task takes a narrow window (wave-uniform, no LDS trip)
                 const unsigned long long narrow_lanes = __ballot(q == 1 && px < cnt && idx <= kNarrowMaxScale);
+#pragma unroll
+                for (int i = 0; i < kTaskPix; ++i) narrow_mask |= static_cast<unsigned>((narrow_lanes >> (i * kLpp + 1)) & 1ull) << i;
                 PROF_ADD(prof[2], t_m);
                 PROF_ADD(prof[7], t_o);
 #if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE >= 3
                 prof[8] += 1;
 #endif
+                }
                 const unsigned long long t_t = PROF_T();
                 // ---- window tables (lanes hold symbols in DESCENDING order; entry 0 = upper sentinel, trailing entries =
                 // lower sentinels, both with P = 0).  Narrow pixels (small scale): 14 real symbols, four pixels per pass.
                 // Wide pixels: 62 real symbols, one pixel per pass.
                 const int base = slot * kBpx + half * kTaskPix;  // first table row of the task
                 uint2* tab = C.s_tab + static_cast<size_t>(base) * 64;
-                unsigned narrow_mask = 0;  // bit i: pixel i of the task is narrow (wave-uniform)
-#pragma unroll
-                for (int i = 0; i < kTaskPix; ++i) narrow_mask |= static_cast<unsigned>((narrow_lanes >> (i * kLpp + 1)) & 1ull) << i;
                 unsigned rest = narrow_mask;
                 while (rest) {
-                    // up to four narrow pixels: sub-wave u = lane >> 4 handles pixel pix[u], entry e = lane & 15
+                    // up to four narrow pixels: sub-wave u = lane >> 4 handles pixel pix[u], entry e = lane & 15.  (Both passes of an
+                    // 8-pixel task as two interleaved chains per lane were tried: slower - a pass is bound by the issue rate of its
+                    // f64 instructions, not by their latency.)
                     int pix[4];
                     int n_here = 0;
 #pragma unroll
@@ -1029,7 +1386,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 
 // One kernel per input width NV = ceil(dim / 4): a single instantiation keeps the register file for the variant that runs
 // (all widths in one kernel cost 444 SGPR spills and VGPR scratch in every path).
-template <int NV>
+template <int NV, bool MF>
 __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const EntropyParams* slots_desc) {
     unsigned char* const smem = ccd_pipe_smem;
     const EntropyParams& P = slots_desc[blockIdx.x];
@@ -1051,10 +1408,14 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     C.s_b = reinterpret_cast<int64_t*>(C.s_w + ((n_w_total + 3) & ~3));
     const int n_b_total = (n_layers - 1) * dim + 4;
     C.s_act = reinterpret_cast<int32_t*>(C.s_b + ((n_b_total + 1) & ~1));
-    C.s_tab = reinterpret_cast<uint2*>(C.s_act + kProducers * 8 * in_pad);
+    constexpr int kActRows = MF ? 16 : 8;
+    C.s_a = reinterpret_cast<uint32_t*>(C.s_act + kProducers * kActRows * in_pad);
+    C.s_tab = reinterpret_cast<uint2*>(static_cast<uint32_t*>(C.s_a) + (MF ? mf_tables(n_layers) * 256 : 0));
     C.s_meta = reinterpret_cast<RowMeta*>(C.s_tab + kRows * 64);
     C.s_ring = reinterpret_cast<int8_t*>(C.s_meta + 1);
-    double* s_rcp = reinterpret_cast<double*>(C.s_ring + kRingRows * 64);
+    const int ring_rows = MF ? P.ring_rows : kRingRows;
+    C.ring_mask = ring_rows - 1;
+    double* s_rcp = reinterpret_cast<double*>(C.s_ring + ring_rows * 64);
     float* s_scale = reinterpret_cast<float*>(s_rcp + kNumScale + 1);
     C.s_rcp = s_rcp; C.s_scale = s_scale;
     uint32_t* s_sync = reinterpret_cast<uint32_t*>(s_scale + ((kNumScale + 3) & ~3));
@@ -1087,7 +1448,11 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         }
         if (tid < 2) C.s_b[(n_layers - 1) * dim + 2 + tid] = src[dim * 2 + tid];
     }
-    for (int i = tid; i < kProducers * 8 * in_pad; i += kPipeThreads) C.s_act[i] = 0;
+    for (int i = tid; i < kProducers * kActRows * in_pad; i += kPipeThreads) C.s_act[i] = 0;
+    if constexpr (MF) {
+        __syncthreads();  // the int32 weights are staged
+        mf_build_tables(C, in_pad, C.s_a, tid);
+    }
     if (tid < kSlots) C.s_ready[tid] = 0;
     if (tid == 0) { *C.s_consumed = 0; *C.s_abort = 0; }
 
@@ -1180,7 +1545,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
             const unsigned long long w0 = S.prof_wait, k0 = S.prof_work;
             const unsigned long long g_t0 = __builtin_amdgcn_s_memtime(), st0 = S.stall_ticks, se0 = S.stall_events;
 #endif
-            seq_end = decoder_grid(C, S);
+            seq_end = decoder_grid<MF>(C, S);
             __builtin_amdgcn_s_setprio(0);
 #ifdef CCD_PIPE_PROFILE
             if (lane == 0 && g == 0)
@@ -1195,7 +1560,9 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
             }
 #endif
         } else {
-            seq_end = C.task_pix == 8 ? producer_grid<NV, 8>(C, prof) : (C.task_pix == 4 ? producer_grid<NV, 16>(C, prof) : producer_grid<NV, 32>(C, prof));
+            // the matrix-core evaluation only serves the 8-pixel tasks of wide grids: its chain has the same length whatever
+            // the number of pixels, while the vector-ALU code of a 4- / 2-pixel task spreads a pixel over 16 / 32 lanes
+            seq_end = C.task_pix == 8 ? producer_grid<NV, 8, MF, MF>(C, prof) : (C.task_pix == 4 ? producer_grid<NV, 16, false, MF>(C, prof) : producer_grid<NV, 32, false, MF>(C, prof));
         }
         const unsigned long long t_b = PROF_T();
         __syncthreads();  // also makes the decoder's global writes of this grid visible to every wave
@@ -1235,7 +1602,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
 #endif
 }
 
-size_t entropy_pipe_lds_bytes(int dim, int n_layers) {
+size_t entropy_pipe_lds_bytes(int dim, int n_layers, int ring_rows, int mfma) {
     const int in_pad = (dim + 3) & ~3;
     const int n_w_total = (n_layers - 1) * dim * in_pad + 4 * in_pad;
     const int n_b_total = (n_layers - 1) * dim + 4;
@@ -1243,39 +1610,67 @@ size_t entropy_pipe_lds_bytes(int dim, int n_layers) {
     n += sizeof(RowMeta);
     n += static_cast<size_t>((n_w_total + 3) & ~3) * 4;
     n += static_cast<size_t>((n_b_total + 1) & ~1) * 8;
-    n += static_cast<size_t>(kProducers) * 8 * in_pad * 4;
-    n += static_cast<size_t>(kRingRows) * 64;
+    n += static_cast<size_t>(kProducers) * (mfma ? 16 : 8) * in_pad * 4;
+    if (mfma) n += static_cast<size_t>(mf_tables(n_layers)) * 1024;
+    n += static_cast<size_t>(ring_rows) * 64;
     n += static_cast<size_t>(kNumScale + 1) * 8 + static_cast<size_t>((kNumScale + 3) & ~3) * 4;
     n += (kSlots + 8) * 4;
     return (n + 15) & ~size_t{15};
 }
 
-bool entropy_pipe_supports(int dim, int n_layers, int narrow, int max_grid_w) {
-    return narrow && dim <= 4 * kMaxNV && n_layers <= 8 && max_grid_w / 10 + 6 <= kRingRows &&
-           entropy_pipe_lds_bytes(dim, n_layers) <= 160 * 1024;
+// rows of the decoded-symbol ring for a stream whose widest grid is max_grid_w (0: too wide for the kernel)
+int entropy_pipe_ring_rows(int max_grid_w) {
+    const int need = max_grid_w / 10 + 6;
+    if (need > kRingRows) return 0;
+    int r = 64;
+    while (r < need) r *= 2;
+    return r;
 }
 
-template <int NV>
+bool entropy_pipe_supports(int dim, int n_layers, int narrow, int max_grid_w) {
+    const int ring = entropy_pipe_ring_rows(max_grid_w);
+    return narrow && dim <= 4 * kMaxNV && n_layers <= 8 && ring > 0 && entropy_pipe_lds_bytes(dim, n_layers, ring, 0) <= 160 * 1024;
+}
+
+// The matrix-core evaluation of the ARM (see the MF notes above producer_grid); max_abs_weight over every ARM layer
+// and the stabiliser.
+bool entropy_pipe_supports_mfma(int dim, int n_layers, int n_ifce_out, int narrow, int max_grid_w, long long max_abs_weight) {
+    const int ring = entropy_pipe_ring_rows(max_grid_w);
+    return entropy_pipe_supports(dim, n_layers, narrow, max_grid_w) && dim <= 20 && n_layers >= 2 && n_ifce_out <= 8 &&
+           max_abs_weight < (1ll << 23) && entropy_pipe_lds_bytes(dim, n_layers, ring, 1) <= 160 * 1024;
+}
+
+template <int NV, bool MF>
 static hipError_t launch_pipe_nv(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(entropy_pipe_kernel<NV>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(entropy_pipe_kernel<NV, MF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(entropy_pipe_kernel<NV>, dim3(n_slots), dim3(kPipeThreads), lds_bytes, stream, d_slots);
+    hipLaunchKernelGGL((entropy_pipe_kernel<NV, MF>), dim3(n_slots), dim3(kPipeThreads), lds_bytes, stream, d_slots);
     return hipGetLastError();
 }
 
-// All `n_slots` descriptors must share nv = ceil(dim / 4) (the host groups the slots of a batch by it).
-hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, size_t lds_bytes, hipStream_t stream) {
+// All `n_slots` descriptors must share nv = ceil(dim / 4) and the mfma flag (the host groups the slots of a batch by both).
+hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, int mfma, size_t lds_bytes, hipStream_t stream) {
     if (n_slots <= 0) return hipSuccess;
+    if (mfma) {
+        switch (nv) {
+            case 1: return launch_pipe_nv<1, true>(d_slots, n_slots, lds_bytes, stream);
+            case 2: return launch_pipe_nv<2, true>(d_slots, n_slots, lds_bytes, stream);
+            case 3: return launch_pipe_nv<3, true>(d_slots, n_slots, lds_bytes, stream);
+            case 4: return launch_pipe_nv<4, true>(d_slots, n_slots, lds_bytes, stream);
+            case 5: return launch_pipe_nv<5, true>(d_slots, n_slots, lds_bytes, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (nv) {
-        case 1: return launch_pipe_nv<1>(d_slots, n_slots, lds_bytes, stream);
-        case 2: return launch_pipe_nv<2>(d_slots, n_slots, lds_bytes, stream);
-        case 3: return launch_pipe_nv<3>(d_slots, n_slots, lds_bytes, stream);
-        case 4: return launch_pipe_nv<4>(d_slots, n_slots, lds_bytes, stream);
-        case 5: return launch_pipe_nv<5>(d_slots, n_slots, lds_bytes, stream);
-        case 6: return launch_pipe_nv<6>(d_slots, n_slots, lds_bytes, stream);
-        case 7: return launch_pipe_nv<7>(d_slots, n_slots, lds_bytes, stream);
-        case 8: return launch_pipe_nv<8>(d_slots, n_slots, lds_bytes, stream);
+        case 1: return launch_pipe_nv<1, false>(d_slots, n_slots, lds_bytes, stream);
+        case 2: return launch_pipe_nv<2, false>(d_slots, n_slots, lds_bytes, stream);
+        case 3: return launch_pipe_nv<3, false>(d_slots, n_slots, lds_bytes, stream);
+        case 4: return launch_pipe_nv<4, false>(d_slots, n_slots, lds_bytes, stream);
+        case 5: return launch_pipe_nv<5, false>(d_slots, n_slots, lds_bytes, stream);
+        case 6: return launch_pipe_nv<6, false>(d_slots, n_slots, lds_bytes, stream);
+        case 7: return launch_pipe_nv<7, false>(d_slots, n_slots, lds_bytes, stream);
+        case 8: return launch_pipe_nv<8, false>(d_slots, n_slots, lds_bytes, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -137,7 +137,8 @@ int ccd_batch_slot_status(const ccd_batch* b, int slot);
 int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64);
 /* Which kernels serve this slot: bit 0 = pipelined entropy kernel (else the generic int64 one),
  * bit 1 = fused synthesis kernel (else one launch per layer), bit 2 = the whole float path (upsampling +
- * synthesis + integer samples) in one kernel, ccd_fused.hip. */
+ * synthesis + integer samples) in one kernel, ccd_fused.hip, bit 3 = the ARM's layers evaluated on the matrix cores
+ * inside the pipelined entropy kernel (exact limb-split int8, ccd_entropy_pipe.hip). */
 int ccd_batch_slot_kernels(const ccd_batch* b, int slot);
 
 /* Batch options, to be set before the slots they concern are added:
@@ -145,8 +146,14 @@ int ccd_batch_slot_kernels(const ccd_batch* b, int slot);
  *                       the reference, cfg/dec) run it; 0: unfused path (per-level upsampling launches + synthesis
  *                       kernel), which materialises the dense stack ccd_batch_dense() returns.
  *   CCD_OPT_KEEP_FLOAT  1 (default): the f32 synthesis output is always written (ccd_batch_output);
- *                       0: slots that produce integer planes directly (rgb / yuv444 intra frames) write only those. */
-enum { CCD_OPT_FUSED_DEC = 1, CCD_OPT_KEEP_FLOAT = 2 };
+ *                       0: slots that produce integer planes directly (rgb / yuv444 intra frames) write only those.
+ *   CCD_OPT_MFMA_ARM    0 (default): the integer ARM on the vector ALU; 1: streams inside the envelope (<= 20 ARM inputs,
+ *                       <= 8 IFCE features, |weight| < 2^23, widest grid <= 2 500) evaluate it with
+ *                       v_mfma_i32_16x16x64_i8 (exact limb-split int8).  Results are identical bit for bit either way; on
+ *                       MI355X the matrix-core variant is the slower one, it is kept as a measured
+ *                       alternative.  Values 2..22 lower the activation width above which a task is redone in plain
+ *                       int64 - normally 23 bits - so that tests reach that path. */
+enum { CCD_OPT_FUSED_DEC = 1, CCD_OPT_KEEP_FLOAT = 2, CCD_OPT_MFMA_ARM = 3 };
 int ccd_batch_set_option(ccd_batch* b, int option, int value);
 
 /* Device pointers of a slot's results (valid until the batch is destroyed / re-run): */

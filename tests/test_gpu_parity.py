@@ -36,19 +36,21 @@ def _decode(gpu, triples, bitdepth, fdt, **opts):
 @pytest.mark.parametrize("path", ["fused", "unfused"])
 @pytest.mark.parametrize("name", IMAGE_STREAMS)
 def test_stream_parity(gpu, oracle, name, path):
-    """path = "fused": upsampling + synthesis + integer samples in one kernel (ccd_fused.hip, the production path for
-    every preset architecture); "unfused": per-level upsampling launches + synthesis kernel, which also exposes the
-    dense stack."""
+    """path = "fused": the production path - the ARM's layers on the matrix cores where the stream allows (limb-split int8),
+    upsampling + synthesis + integer samples in one kernel (ccd_fused.hip, every preset architecture); "unfused": the ARM on
+    the vector ALU, per-level upsampling launches + synthesis kernel, which also exposes the dense stack."""
     bs, z, j = load_golden(name)
     _, frames = oracle.split_stream(bs)
     fh, ccs = frames[0]
     ref = oracle.decode_coolchic(*ccs[0])
-    b = _decode(gpu, ccs[:1], fh.bitdepth, fh.frame_data_type, fused_dec=(path == "fused"))
+    b = _decode(gpu, ccs[:1], fh.bitdepth, fh.frame_data_type, fused_dec=(path == "fused"), mfma_arm=int(path == "fused"))
     try:
         if path == "fused" and name != "cr192":  # common randomness is outside the fused kernel's envelope
             assert b.slot_kernels(0) & 4, "the fused float kernel must serve this stream"
+        if path == "fused" and name == "kodim14":
+            assert b.slot_kernels(0) & 8, "the ARM of the reference's sample stream must run on the matrix cores"
         if path == "unfused":
-            assert not b.slot_kernels(0) & 4
+            assert not b.slot_kernels(0) & 12
         # integer stage: every latent grid bit-exact with the oracle AND the reference fixture
         for g in range(ref["n_grids"]):
             got = b.latent(0, g)
@@ -71,6 +73,23 @@ def test_stream_parity(gpu, oracle, name, path):
             n_diff += int((d != 0).sum())
             n_tot += d.size
         assert n_diff <= max(3, 2e-5 * n_tot)
+    finally:
+        b.close()
+
+
+@pytest.mark.parametrize("bits", [4, 10, 16])
+@pytest.mark.parametrize("name", ["kodim14", "yuv420_8b"])
+def test_mfma_arm_exact_redo(gpu, oracle, name, bits):
+    """Hidden activations travel through the matrix cores as three signed bytes; a task that meets a wider one is redone in
+    plain int64.  Real streams never get there, so the width limit is lowered until (nearly) every / many / a few tasks do."""
+    bs, z, j = load_golden(name)
+    fh, ccs = oracle.split_stream(bs)[1][0]
+    b = _decode(gpu, ccs[:1], fh.bitdepth, fh.frame_data_type, mfma_arm=bits)
+    try:
+        assert b.slot_kernels(0) & 8
+        assert b.slot_status(0) == 0
+        for g in range(len([k for k in z.files if k.startswith("cc0.latent")])):
+            assert np.array_equal(b.latent(0, g), z[f"cc0.latent{g}"]), f"grid {g} vs reference fixture"
     finally:
         b.close()
 

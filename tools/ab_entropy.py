@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B of entropy-kernel builds on ONE box: for each library variant given as label=path, the entropy stage of kodak24
 (24 streams in one launch, HIP events) and of the first landscape / portrait stream alone, latents checked against the
-first variant.   python tools/ab_entropy.py base=cool_chic_amd/libccd.so t16=cool_chic_amd/libccd_t16.so ..."""
+first variant.   python tools/ab_entropy.py base=cool_chic_amd/libccd.so t16=cool_chic_amd/libccd_t16.so ...
+A variant may carry environment settings: valu=cool_chic_amd/libccd.so:CCD_MFMA_ARM=0,CCD_X=1"""
 import os
 import subprocess
 import sys
@@ -39,7 +40,11 @@ def main():
     ref = None
     for arg in sys.argv[1:]:
         label, path = arg.split("=", 1)
-        env = dict(os.environ, CCD_LIB=os.path.abspath(path))
+        extra = {}
+        if ":" in path:
+            path, settings = path.split(":", 1)
+            extra = dict(kv.split("=", 1) for kv in settings.split(","))
+        env = dict(os.environ, CCD_LIB=os.path.abspath(path), **extra)
         try:
             r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=90)
         except subprocess.TimeoutExpired:
