@@ -1543,7 +1543,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
             __builtin_amdgcn_s_setprio(3);
 #ifdef CCD_PIPE_PROFILE
             const unsigned long long w0 = S.prof_wait, k0 = S.prof_work;
-            const unsigned long long g_t0 = __builtin_amdgcn_s_memtime(), st0 = S.stall_ticks, se0 = S.stall_events;
+            const unsigned long long g_t0 = __builtin_amdgcn_s_memtime(), sp0 = S.n_spins, se0 = S.stall_events;
 #endif
             seq_end = decoder_grid<MF>(C, S);
             __builtin_amdgcn_s_setprio(0);
@@ -1555,7 +1555,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                 P.status[25 + 2 * g] = static_cast<int32_t>((S.prof_work - k0) >> 10);
                 // light counters: total ticks of the grid, ticks stalled on producers, number of stalls
                 P.status[50 + 3 * g] = static_cast<int32_t>((__builtin_amdgcn_s_memtime() - g_t0) >> 10);
-                P.status[51 + 3 * g] = static_cast<int32_t>((S.stall_ticks - st0) >> 10);
+                P.status[51 + 3 * g] = static_cast<int32_t>(S.n_spins - sp0);  // polls of a ready counter inside the asm region
                 P.status[52 + 3 * g] = static_cast<int32_t>(S.stall_events - se0);
             }
 #endif
