@@ -343,7 +343,7 @@ def main():
             "serial_chain_bound": {"achieved": nsym / (stage_ms["entropy"] / 1e3) / 1e6, "peak": n_frames * 2.4e9 / 164.0 / 1e6,
                                    "unit": "Msymbol/s", "frac": (nsym / (stage_ms["entropy"] / 1e3)) / (n_frames * 2.4e9 / 164.0),
                                    "streams": n_frames, "ticks_per_symbol_floor": 164},
-            "roofline": {"bound": "hbm", "kernel": f"entropy_pipe_kernel<5> ({n_frames} streams, one workgroup each)", "achieved": ent_ach,
+            "roofline": {"bound": "hbm", "kernel": f"entropy_pipe_kernel<5, false> ({n_frames} streams, one workgroup each)", "achieved": ent_ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ent_ach / HBM_PEAK_GBS, "traffic": traffic("entropy_pipe_kernel"),
                          "algorithmic_bytes": ent_bytes, "ms_per_launch": stage_ms["entropy"],
                          "note": "latency-bound serial chain (one range decoder per stream): see entropy_msym_per_s, serial_chain_bound "
