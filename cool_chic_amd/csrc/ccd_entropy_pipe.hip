@@ -66,6 +66,7 @@ constexpr int kRingRows = 512;              // most rows of the decoded-symbol r
 // Scale index up to which a 14-symbol window [round(mu) - 7, round(mu) + 6] is used (b <= 1: 99.3 % of the symbols of
 // a real stream, window misses ~3e-4): four pixels' windows are then built by ONE pass of the wave.
 constexpr int kNarrowMaxScale = kScaleOffset;
+constexpr int kIfceFastIn = 12;             // most IFCE input channels (coarser grids) of the register-resident feature pass
 constexpr unsigned kSpinLimit = 1u << 27;   // bounded spins: a lost hand-over becomes an error, not a hang
 
 // exp(x) for x <= 0 in f64: range reduction by ln 2 (two-part constant) + degree-13 Taylor/Horner.
@@ -1509,6 +1510,70 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
             __syncthreads();
             const bool zero_input = g == P.n_grids - 1;  // first grid: the stack is one all-zero channel (coolchic.py:95-96)
             int32_t* feat = P.ifce_feat;
+            if (fin <= kIfceFastIn && n_if <= 8) {
+                // The usual shape (<= 12 coarser grids incl. hyperlatents, <= 8 features).  The generic loop below waits for one
+                // L2 round trip per input channel and position (~10 k ticks per position, measured); here a position's `fin`
+                // bytes are requested together, one position ahead, through explicit global pointers (a FLAT access can only be
+                // waited for with vmcnt(0), i.e. together with the previous position's stores).  Under `narrow` |weight| < 2^17
+                // and |input << 16| < 2^23: one v_mad_i64_i32 per product gives the reference's int64 sums exactly, and the
+                // .to(torch.float) / back round trip around F.interpolate (coolchic.py:142-144) is the identity (|feature| < 2^15).
+                // The loop body is straight-line code on purpose: with branches in it the compiler falls back to
+                // s_waitcnt vmcnt(0) everywhere.  Channels >= fin read channel fin - 1 again and meet zero weights; features
+                // >= n_if are computed and not stored (the store's predicate is a lane mask).
+                // [kIfceFastIn][8] int32 copies of the weights (16-byte rows), zero rows past fin; 16 KB into the idle table region
+                // (a pointer rounded up through uintptr_t would lose its LDS address space and turn the reads into FLAT loads)
+                int32_t* const s_w32 = reinterpret_cast<int32_t*>(static_cast<uint2*>(C.s_tab) + 2048);
+                for (int i = tid; i < kIfceFastIn * 8; i += kPipeThreads) {
+                    const int c = i >> 3, j = i & 7;
+                    s_w32[i] = (c < fin && j < n_if) ? static_cast<int32_t>(s_fw[c * n_if + j]) : 0;
+                }
+                __syncthreads();
+                const glb_ptr<int32_t> featg = (glb_ptr<int32_t>)feat;
+                const int plane = fh * fw;
+                // source descriptors: wave-uniform, read from LDS once (inside the loop each costs an LDS round trip per position)
+                glb_ptr<const int8_t> srcp[kIfceFastIn];
+                int gwr[kIfceFastIn], shr[kIfceFastIn];
+#pragma unroll
+                for (int c = 0; c < kIfceFastIn; ++c) {
+                    const int cc = min(c, fin - 1);
+                    srcp[c] = (glb_ptr<const int8_t>)reinterpret_cast<const int8_t*>(uni(reinterpret_cast<uint64_t>(s_src[cc])));
+                    gwr[c] = uni(s_gw[cc]);
+                    shr[c] = uni(s_sh[cc]);
+                }
+                auto fetch = [&](int p, int32_t (&v)[kIfceFastIn]) {
+                    const int y = p / fw, x = p - y * fw;
+#pragma unroll
+                    for (int c = 0; c < kIfceFastIn; ++c) v[c] = static_cast<int32_t>(srcp[c][(y >> shr[c]) * gwr[c] + (x >> shr[c])]);
+                };
+                int64_t br[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) br[j] = j < n_if ? s_fw[fin * n_if + j] : 0;
+                int n_if_lane = n_if;
+                asm volatile("" : "+v"(n_if_lane));  // opaque: the stores below are predicated per lane, not branched around
+                const int in_scale = zero_input ? 0 : 65536;  // first grid: the stack is one all-zero channel; else armint.py:193's << 16
+                int32_t v_next[kIfceFastIn];
+                fetch(min(tid, plane - 1), v_next);
+                for (int p = tid; p < plane; p += kPipeThreads) {
+                    int32_t v[kIfceFastIn];
+#pragma unroll
+                    for (int c = 0; c < kIfceFastIn; ++c) v[c] = v_next[c] * in_scale;
+                    fetch(min(p + kPipeThreads, plane - 1), v_next);
+                    int64_t acc[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = br[j];
+#pragma unroll
+                    for (int c = 0; c < kIfceFastIn; ++c) {
+                        const int4 w0 = *reinterpret_cast<const int4*>(s_w32 + c * 8), w1 = *reinterpret_cast<const int4*>(s_w32 + c * 8 + 4);
+                        // (plain C++, not mad64: an inline-asm statement makes the compiler wait for every outstanding load)
+                        const int64_t x = v[c];
+                        acc[0] += x * w0.x; acc[1] += x * w0.y; acc[2] += x * w0.z; acc[3] += x * w0.w;
+                        acc[4] += x * w1.x; acc[5] += x * w1.y; acc[6] += x * w1.z; acc[7] += x * w1.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (j < n_if_lane) featg[min(j, n_if - 1) * plane + p] = static_cast<int32_t>(acc[j] >> 24);
+                }
+            } else
             for (int p = tid; p < fh * fw; p += kPipeThreads) {
                 const int y = p / fw, x = p - y * fw;
                 for (int o0 = 0; o0 < n_if; o0 += 8) {
@@ -1537,6 +1602,12 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         }
         __syncthreads();  // features visible; every wave finished the previous grid
         PROF_ADD(prof_ifce, t_if);
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE >= 3
+        const unsigned long long ifce_grid_ticks = __builtin_amdgcn_s_memtime() - t_if;  // this grid's feature pass (all waves)
+#else
+        const unsigned long long ifce_grid_ticks = 0;
+        (void)ifce_grid_ticks;
+#endif
 
         uint32_t seq_end;
         if (wave == 0) {
@@ -1551,7 +1622,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
             if (lane == 0 && g == 0)
                 for (int i = 0; i < 6; ++i) P.status[32 + i] = static_cast<int32_t>(S.wait_by_j[i] >> 10);
             if (lane == 0 && g < 4) {  // per-grid decoder counters for the four finest grids: status[24 + 2 g ..]
-                P.status[24 + 2 * g] = static_cast<int32_t>((S.prof_wait - w0) >> 10);
+                P.status[24 + 2 * g] = static_cast<int32_t>(ifce_grid_ticks >> 10);  // level 3: ticks of the IFCE feature pass before this grid
                 P.status[25 + 2 * g] = static_cast<int32_t>((S.prof_work - k0) >> 10);
                 // light counters: total ticks of the grid, ticks stalled on producers, number of stalls
                 P.status[50 + 3 * g] = static_cast<int32_t>((__builtin_amdgcn_s_memtime() - g_t0) >> 10);

@@ -22,7 +22,8 @@ nb=526272/16/7
 print(' per batch (approx %d batches): gather %.0f mlp %.0f table %.0f cycles'%(nb,u[7]/nb,u[8]/nb,u[9]/nb))
 
 hw=[(512,768),(256,384),(128,192),(64,96)]
-for g in range(4):
+print(' IFCE feature pass before grids 0..3 (Mticks, level-3 builds):', [round(int(st[24+2*g])*1024/1e6,3) for g in range(4)])
+for g in range(0):
     w,k=int(st[24+2*g])*1024,int(st[25+2*g])*1024
     n=hw[g][0]*hw[g][1]
     print(' grid %d (%dx%d): wait %.1fM work %.1fM cycles -> %.0f cycles/symbol total, wait share %.2f'%(g,hw[g][0],hw[g][1],w/1e6,k/1e6,(w+k)/n,w/(w+k+1)))
