@@ -1165,9 +1165,14 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + 2 * in_pad + qs * in_pad);
                     so[0] = C.s_b[(n_layers - 1) * dim + 2 + qs];
                     so[1] = 0;
+                    // weight vectors are requested ahead of their use everywhere below: left to itself the compiler reads each
+                    // one right before its multiply-adds and the task eats an LDS round trip per vector
+                    int4 wv[NV];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) wv[v] = wr[v];
 #pragma unroll
                     for (int v = 0; v < NV; ++v) {
-                        const int4 w = wr[v];
+                        const int4 w = wv[v];
                         int64_t& a = so[v & 1];
                         mad64(a, xv[v].x, w.x); mad64(a, xv[v].y, w.y); mad64(a, xv[v].z, w.z); mad64(a, xv[v].w, w.w);
                     }
@@ -1191,12 +1196,18 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         wleft[t] = wl[oc * in_pad + kl];
                     }
                     wleft_stab = C.s_w[C.n_w_hidden + 2 * in_pad + qs * in_pad + kl];
+                    int4 w[NOUT], wn[NOUT];
+#pragma unroll
+                    for (int t = 0; t < NOUT; ++t) w[t] = wr[t][0];
 #pragma unroll
                     for (int v = 0; v < NV; ++v) {
-                        int4 w[NOUT];
+                        if (v + 1 < NV) {
 #pragma unroll
-                        for (int t = 0; t < NOUT; ++t) w[t] = wr[t][v];
+                            for (int t = 0; t < NOUT; ++t) wn[t] = wr[t][v + 1];
+                        }
                         CCD_MAD4(acc0, xv[v], w, NOUT)
+#pragma unroll
+                        for (int t = 0; t < NOUT; ++t) w[t] = wn[t];
                     }
                 }
                 // ---- the left neighbour: wait for it (and for the slot), add its term to the first layer and the stabiliser
@@ -1235,12 +1246,18 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         wr[t] = reinterpret_cast<const int4*>(wl + oc * in_pad);
                         acc[t] = bl[oc];
                     }
+                    int4 w[NOUT], wn[NOUT];
+#pragma unroll
+                    for (int t = 0; t < NOUT; ++t) w[t] = wr[t][0];
 #pragma unroll
                     for (int v = 0; v < NV; ++v) {
-                        int4 w[NOUT];
+                        if (v + 1 < NV) {
 #pragma unroll
-                        for (int t = 0; t < NOUT; ++t) w[t] = wr[t][v];
+                            for (int t = 0; t < NOUT; ++t) wn[t] = wr[t][v + 1];
+                        }
                         CCD_MAD4(acc, xv[v], w, NOUT)
+#pragma unroll
+                        for (int t = 0; t < NOUT; ++t) w[t] = wn[t];
                     }
 #pragma unroll
                     for (int t = 0; t < NOUT; ++t) {
@@ -1259,9 +1276,12 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 if (q < 2) {
                     const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + q * in_pad);
                     int64_t ao[2] = {C.s_b[(n_layers - 1) * dim + q] + stab, 0};
+                    int4 wv[NV];
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) wv[v] = wr[v];
 #pragma unroll
                     for (int v = 0; v < NV; ++v) {
-                        const int4 w = wr[v];
+                        const int4 w = wv[v];
                         int64_t& a = ao[v & 1];
                         mad64(a, xv[v].x, w.x); mad64(a, xv[v].y, w.y); mad64(a, xv[v].z, w.z); mad64(a, xv[v].w, w.w);
                     }
