@@ -22,6 +22,8 @@ for idx in [int(a) for a in sys.argv[1:]] or [0]:
         tot, polls, ev = int(st[50 + 3 * g]) * 1024, int(st[51 + 3 * g]), int(st[52 + 3 * g])
         print("  grid %d (%dx%d): total %.1fM ticks = %.0f / symbol; %d polls of a ready counter (~%.0f%% of the grid's time at 200 ticks each), %d long waits" % (g, hh.grid_h[g], hh.grid_w[g], tot / 1e6, tot / n, polls, 100.0 * polls * 200 / max(tot, 1), ev))
     u = st[4:24].view(np.uint64); e = st[40:50].view(np.uint64); nt = max(int(e[4]), 1)
+    g03 = sum(int(st[50 + 3 * g]) * 1024 for g in range(4))
+    print("  grids 0-3 together %.1fM ticks of about %.0fM (wall time x 2.4 GHz): the rest is the coarser grids, the feature passes and the set-up" % (g03 / 1e6, dt * 2.4e3))
     print("  producer 0: %d tasks; per task: idle before early wait %.0f, early work %.0f, late wait %.0f, late work %.0f; between tasks (loop control, IFCE prefetch issue) %.0f (CCD_PIPE_PROFILE=2 builds only)" % (nt, u[6] / nt, u[7] / nt, u[8] / nt, u[9] / nt, e[0] / nt))
     print("  polls of a ready counter inside the decoder's asm region (each ~250 ticks of stall not in the per-grid figures): %d" % int(st[38]))
     print("  symbol-loop exits (renormalisation / miss / sentinel): %d, of which full 128-way searches: %d" % (int(st[62]), int(st[63])))
