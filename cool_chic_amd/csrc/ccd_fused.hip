@@ -192,6 +192,10 @@ __device__ __forceinline__ void fd_tconv_quad2(const float* base0, const float* 
     for (int a = 0; a < 5; ++a)
 #pragma unroll
         for (int b = 0; b < 5; ++b) { v0[a][b] = base0[a * P + b]; v1[a][b] = base1[a * P + b]; }
+    // all reads of the two windows first: left alone, the scheduler (short of registers) issues each read one step before its
+    // MFMA and the two chains run at LDS latency instead of MFMA latency.  (The single-chain variants above and below are bound
+    // by the dependent-MFMA latency either way; grouping their reads made S2 10 % slower.)
+    __builtin_amdgcn_sched_barrier(0);
     f32x4 a0 = {0.0f, 0.0f, 0.0f, 0.0f}, a1 = a0;
     static_for<0, 25>([&](auto ss) {
         constexpr int st = decltype(ss)::value;
