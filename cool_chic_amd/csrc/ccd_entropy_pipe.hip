@@ -808,7 +808,7 @@ __device__ __forceinline__ void mf_exact_task(const PipeCtx& C, int32_t* tile, i
             const int yy = y - P.ctx_dy[k], xx = x + P.ctx_dx[k];
             if (yy >= 0 && xx >= 0 && xx < W) v = C.s_ring[(yy & ring_mask) * 64 + ((xx + 10 * yy) & 63)];
         } else if (fin > 0) {
-            v = P.ifce_feat[(k - n_sp) * feat_plane + (y >> 1) * fw + (x >> 1)];
+            v = reinterpret_cast<const int16_t*>(P.ifce_feat)[(k - n_sp) * feat_plane + (y >> 1) * fw + (x >> 1)];
         }
         ain[k] = v << 16;
     }
@@ -878,7 +878,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
         ctx_dy_l[t] = k < n_sp ? P.ctx_dy[k] : 0;
         ctx_dx_l[t] = k < n_sp ? P.ctx_dx[k] : 0;
     }
-    const glb_ptr<const int32_t> ifce_feat = (glb_ptr<const int32_t>)P.ifce_feat;
+    // this kernel keeps the features as int16 (|feature| < 2^15 under `narrow`): half the scratch traffic of the int32 planes
+    const glb_ptr<const int16_t> ifce_feat = (glb_ptr<const int16_t>)reinterpret_cast<const int16_t*>(P.ifce_feat);
     const int feat_plane = uni(C.fh) * fw;
     // MF: the lane's context offsets (k = q + 4 t, dy << 16 | dx) and the left neighbour's weights of the lane's rows
     // (neurons 4 q .. 4 q + 3 and 16 + q, then the two stabiliser outputs)
@@ -1529,7 +1530,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
             }
             __syncthreads();
             const bool zero_input = g == P.n_grids - 1;  // first grid: the stack is one all-zero channel (coolchic.py:95-96)
-            int32_t* feat = P.ifce_feat;
+            int16_t* feat = reinterpret_cast<int16_t*>(P.ifce_feat);  // int16 planes: |feature| < 2^15 under `narrow`
             if (fin <= kIfceFastIn && n_if <= 8) {
                 // The usual shape (<= 12 coarser grids incl. hyperlatents, <= 8 features).  The generic loop below waits for one
                 // L2 round trip per input channel and position (~10 k ticks per position, measured); here a position's `fin`
@@ -1548,7 +1549,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                     s_w32[i] = (c < fin && j < n_if) ? static_cast<int32_t>(s_fw[c * n_if + j]) : 0;
                 }
                 __syncthreads();
-                const glb_ptr<int32_t> featg = (glb_ptr<int32_t>)feat;
+                const glb_ptr<int16_t> featg = (glb_ptr<int16_t>)feat;
                 const int plane = fh * fw;
                 // source descriptors: wave-uniform, read from LDS once (inside the loop each costs an LDS round trip per position)
                 glb_ptr<const int8_t> srcp[kIfceFastIn];
@@ -1591,7 +1592,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        if (j < n_if_lane) featg[min(j, n_if - 1) * plane + p] = static_cast<int32_t>(acc[j] >> 24);
+                        if (j < n_if_lane) featg[min(j, n_if - 1) * plane + p] = static_cast<int16_t>(acc[j] >> 24);
                 }
             } else
             for (int p = tid; p < fh * fw; p += kPipeThreads) {
@@ -1614,7 +1615,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                         if (o0 + j < n_if) {
                             const int64_t q8 = static_cast<int64_t>(acc[j]) >> 24;
                             // .to(torch.float) / back to int64 round trip around F.interpolate (coolchic.py:142-144)
-                            feat[(o0 + j) * fh * fw + p] = static_cast<int32_t>(static_cast<int64_t>(static_cast<float>(q8)));
+                            feat[(o0 + j) * fh * fw + p] = static_cast<int16_t>(static_cast<int64_t>(static_cast<float>(q8)));
                         }
                     }
                 }
