@@ -328,6 +328,11 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "8:\n\t"
                 "ds_read_b64 v[40:41], v50\n\t"
                 "ds_read_b64 v[42:43], v50 offset:512\n\t"
+                // a full batch of 16 symbols takes the unrolled copy of the loop (80:): no loop control on the chain
+                "19:\n\t"
+                "s_sub_u32 s58, s54, %[i]\n\t"
+                "s_cmp_eq_u32 s58, 16\n\t"
+                "s_cbranch_scc1 80f\n\t"
                 ".p2align 6\n\t"
                 "1:\n\t"
                 // ---- copy 0: (L, P) of the current symbol in v[40:41], two rows ahead in flight (order: dloop_variants.hip)
@@ -479,7 +484,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_mov_b32 v41, v57\n\t"
                 "v_mov_b32 v42, v58\n\t"
                 "v_mov_b32 v43, v59\n\t"
-                "s_branch 1b\n\t"
+                "s_branch 19b\n\t"
                 "10:\n\t"
                 "s_mov_b32 %[st], 0\n\t"
                 "s_branch 4f\n\t"
@@ -572,6 +577,378 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_cmp_lt_u32 %[i], s54\n\t"
                 "s_cbranch_scc0 2b\n\t"
                 "s_branch 1b\n\t"
+                // ---- a full 16-symbol batch, unrolled: the three copies of the loop above in rotation without the index arithmetic, the
+                // bound test and the branch (a lone wave issues in order: every instruction between two symbols lengthens the chain);
+                // rows are addressed with immediate offsets from the batch's first row.  Anything unusual (renormalisation, sentinel)
+                // leaves through a trampoline that restores the loop's conventions (i, v50) and continues in the loop.
+                ".p2align 6\n\t"
+                "80:\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[46:47], v50 offset:1024\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
+                "v_mad_u32_u24 v45, v40, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
+                "v_mad_u32_u24 v49, v41, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 81f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 0\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[40:41], v50 offset:1536\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
+                "v_mad_u32_u24 v45, v42, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
+                "v_mad_u32_u24 v49, v43, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 82f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 1\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[42:43], v50 offset:2048\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
+                "v_mad_u32_u24 v45, v46, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
+                "v_mad_u32_u24 v49, v47, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 83f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 2\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[46:47], v50 offset:2560\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
+                "v_mad_u32_u24 v45, v40, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
+                "v_mad_u32_u24 v49, v41, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 84f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 3\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[40:41], v50 offset:3072\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
+                "v_mad_u32_u24 v45, v42, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
+                "v_mad_u32_u24 v49, v43, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 85f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 4\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[42:43], v50 offset:3584\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
+                "v_mad_u32_u24 v45, v46, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
+                "v_mad_u32_u24 v49, v47, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 86f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 5\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[46:47], v50 offset:4096\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
+                "v_mad_u32_u24 v45, v40, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
+                "v_mad_u32_u24 v49, v41, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 87f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 6\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[40:41], v50 offset:4608\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
+                "v_mad_u32_u24 v45, v42, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
+                "v_mad_u32_u24 v49, v43, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 88f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 7\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[42:43], v50 offset:5120\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
+                "v_mad_u32_u24 v45, v46, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
+                "v_mad_u32_u24 v49, v47, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 89f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 8\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[46:47], v50 offset:5632\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
+                "v_mad_u32_u24 v45, v40, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
+                "v_mad_u32_u24 v49, v41, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 90f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 9\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[40:41], v50 offset:6144\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
+                "v_mad_u32_u24 v45, v42, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
+                "v_mad_u32_u24 v49, v43, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 91f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 10\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[42:43], v50 offset:6656\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
+                "v_mad_u32_u24 v45, v46, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
+                "v_mad_u32_u24 v49, v47, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 92f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 11\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[46:47], v50 offset:7168\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
+                "v_mad_u32_u24 v45, v40, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
+                "v_mad_u32_u24 v49, v41, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 93f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 12\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[40:41], v50 offset:7680\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
+                "v_mad_u32_u24 v45, v42, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
+                "v_mad_u32_u24 v49, v43, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 94f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 13\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[42:43], v50 offset:8192\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
+                "v_mad_u32_u24 v45, v46, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
+                "v_mad_u32_u24 v49, v47, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 95f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 14\n\t"
+                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "ds_read_b64 v[46:47], v50 offset:8704\n\t"
+                "s_waitcnt lgkmcnt(2)\n\t"
+                "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
+                "v_mad_u32_u24 v45, v40, s41, v45\n\t"
+                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
+                "v_mad_u32_u24 v49, v41, s41, v49\n\t"
+                "s_ff1_i32_b64 s44, vcc\n\t"
+                "v_readlane_b32 s48, v48, s44\n\t"
+                "v_readlane_b32 s49, v49, s44\n\t"
+                "v_readlane_b32 s46, v44, s44\n\t"
+                "v_readlane_b32 s47, v45, s44\n\t"
+                "s_cmp_eq_u32 s49, 0\n\t"
+                "s_cbranch_scc1 96f\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_sub_u32 s50, s50, s46\n\t"
+                "s_subb_u32 s51, s51, s47\n\t"
+                "v_writelane_b32 %[raw], s44, 15\n\t"
+                "s_add_u32 %[i], %[i], 16\n\t"
+                "s_branch 2b\n\t"
+                "81:\n\t"
+                "s_branch 40b\n\t"
+                "82:\n\t"
+                "s_add_u32 %[i], %[i], 1\n\t"
+                "s_branch 41b\n\t"
+                "83:\n\t"
+                "s_add_u32 %[i], %[i], 2\n\t"
+                "s_branch 42b\n\t"
+                "84:\n\t"
+                "s_add_u32 %[i], %[i], 3\n\t"
+                "v_add_u32 v50, 0x600, v50\n\t"
+                "s_branch 40b\n\t"
+                "85:\n\t"
+                "s_add_u32 %[i], %[i], 4\n\t"
+                "v_add_u32 v50, 0x600, v50\n\t"
+                "s_branch 41b\n\t"
+                "86:\n\t"
+                "s_add_u32 %[i], %[i], 5\n\t"
+                "v_add_u32 v50, 0x600, v50\n\t"
+                "s_branch 42b\n\t"
+                "87:\n\t"
+                "s_add_u32 %[i], %[i], 6\n\t"
+                "v_add_u32 v50, 0xc00, v50\n\t"
+                "s_branch 40b\n\t"
+                "88:\n\t"
+                "s_add_u32 %[i], %[i], 7\n\t"
+                "v_add_u32 v50, 0xc00, v50\n\t"
+                "s_branch 41b\n\t"
+                "89:\n\t"
+                "s_add_u32 %[i], %[i], 8\n\t"
+                "v_add_u32 v50, 0xc00, v50\n\t"
+                "s_branch 42b\n\t"
+                "90:\n\t"
+                "s_add_u32 %[i], %[i], 9\n\t"
+                "v_add_u32 v50, 0x1200, v50\n\t"
+                "s_branch 40b\n\t"
+                "91:\n\t"
+                "s_add_u32 %[i], %[i], 10\n\t"
+                "v_add_u32 v50, 0x1200, v50\n\t"
+                "s_branch 41b\n\t"
+                "92:\n\t"
+                "s_add_u32 %[i], %[i], 11\n\t"
+                "v_add_u32 v50, 0x1200, v50\n\t"
+                "s_branch 42b\n\t"
+                "93:\n\t"
+                "s_add_u32 %[i], %[i], 12\n\t"
+                "v_add_u32 v50, 0x1800, v50\n\t"
+                "s_branch 40b\n\t"
+                "94:\n\t"
+                "s_add_u32 %[i], %[i], 13\n\t"
+                "v_add_u32 v50, 0x1800, v50\n\t"
+                "s_branch 41b\n\t"
+                "95:\n\t"
+                "s_add_u32 %[i], %[i], 14\n\t"
+                "v_add_u32 v50, 0x1800, v50\n\t"
+                "s_branch 42b\n\t"
+                "96:\n\t"
+                "s_add_u32 %[i], %[i], 15\n\t"
+                "v_add_u32 v50, 0x1e00, v50\n\t"
+                "s_branch 40b\n\t"
                 "15:\n\t"
                 "s_mov_b32 %[st], 3\n\t"
                 "s_branch 4f\n\t"
