@@ -15,7 +15,13 @@
 //     exchanged through a per-wave LDS tile) and expand (mu, scale) into the window table with one
 //     f64 exp per lane;
 //   * hand-over is by sequence numbers in LDS; a batch of diagonal c+1 only needs its own rows' pixels
-//     of diagonal c, so producers work on c+1 while the decoder is still finishing c.
+//     of diagonal c, so producers work on c+1 while the decoder is still finishing c;
+//   * a lone wave issues in order, so every instruction between two symbols lengthens the chain: a full
+//     16-symbol batch runs an unrolled copy of the symbol loop without index arithmetic, bound test or branch;
+//   * between grids the whole workgroup computes the IFCE features of the next grid (loads requested a
+//     position ahead through explicit global pointers, straight-line body: see the notes there);
+//   * optionally (EntropyParams::mfma, off by default: measured slower) the ARM's layers of 8-pixel tasks run
+//     on the matrix cores with operands split into signed bytes - exact, see the MF notes above producer_grid.
 //
 // Reference behaviour restated: bitstream/component/latent.py:18-187, armint.py:180-203,
 // coolchic.py:89-169, rangecoder.py:80-94 (constriction RangeDecoder + QuantizedLaplace(-64,63)).
