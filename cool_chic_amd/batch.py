@@ -26,13 +26,16 @@ class DecodeBatch:
     enqueues kernels on `stream` (a hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream).
     """
 
-    OPT_FUSED_DEC, OPT_KEEP_FLOAT, OPT_MFMA_ARM = 1, 2, 3  # include/ccd.h
+    OPT_FUSED_DEC, OPT_KEEP_FLOAT, OPT_MFMA_ARM, OPT_RANGE_BITS = 1, 2, 3, 4  # include/ccd.h
 
     def __init__(self, device: int = 0, fused_dec: Optional[bool] = None, keep_float: Optional[bool] = None,
-                 mfma_arm: Optional[int] = None):
+                 mfma_arm: Optional[int] = None, range_bits: Optional[Tuple[int, int]] = None):
         """fused_dec=False: unfused float path (materialises dense()); keep_float=False: rgb / yuv444 intra slots
-        write integer planes only (output() is then unavailable for them); mfma_arm=0: the integer ARM on the vector
-        ALU only (1: matrix cores where the stream allows; 2..22: test hook, see ccd.h).  None = library default (all on)."""
+        write integer planes only (output() is then unavailable for them); mfma_arm=1: the integer ARM on the matrix
+        cores where the stream allows (2..22: test hook, see ccd.h); range_bits=(feature bits, activation bits): test
+        hook that lowers the limits of the pipelined entropy kernel's dynamic operand check.
+        None = library default: fused_dec on, keep_float on, mfma_arm OFF (the vector-ALU ARM is the faster one),
+        production limits (15, 31)."""
         self._h = C.c_void_p()
         check(lib().ccd_batch_create(int(device), C.byref(self._h)), "ccd_batch_create")
         self.device = int(device)
@@ -42,6 +45,8 @@ class DecodeBatch:
             check(lib().ccd_batch_set_option(self._h, self.OPT_KEEP_FLOAT, int(bool(keep_float))), "ccd_batch_set_option")
         if mfma_arm is not None:
             check(lib().ccd_batch_set_option(self._h, self.OPT_MFMA_ARM, int(mfma_arm)), "ccd_batch_set_option")
+        if range_bits is not None:
+            check(lib().ccd_batch_set_option(self._h, self.OPT_RANGE_BITS, int(range_bits[0]) | int(range_bits[1]) << 8), "ccd_batch_set_option")
         self._meta: List[Tuple[int, int]] = []
 
     def close(self):
@@ -83,9 +88,17 @@ class DecodeBatch:
     def slot_status(self, slot: int) -> int:
         return lib().ccd_batch_slot_status(self._h, slot)
 
+    def slot_stats(self, slot: int) -> np.ndarray:
+        """Raw counters of the entropy kernel after wait() (ccd.h): [0] status, [1] words read, [2..3] symbols, [39] pixels
+        the pipelined kernel redid in int64."""
+        out = np.zeros(64, dtype=np.int32)
+        check(lib().ccd_batch_slot_stats(self._h, slot, out.ctypes.data), "ccd_batch_slot_stats")
+        return out
+
     # ---- results -------------------------------------------------------------------------------
     def slot_kernels(self, slot: int) -> int:
-        """bit 0: pipelined entropy kernel, bit 1: fused synthesis kernel, bit 2: fused upsampling + synthesis kernel."""
+        """bit 0: pipelined entropy kernel, bit 1: fused synthesis kernel, bit 2: fused upsampling + synthesis kernel,
+        bit 3: the ARM on the matrix cores."""
         return check(lib().ccd_batch_slot_kernels(self._h, slot), "ccd_batch_slot_kernels")
 
     def latent(self, slot: int, grid: int) -> np.ndarray:
@@ -126,6 +139,8 @@ class DecodeBatch:
     def output_device(self, slot: int) -> _DevArray:
         h = self.header(slot)
         ptr = lib().ccd_batch_output(self._h, slot)
+        if not ptr:
+            raise ValueError("slot has no float output (keep_float=False and integer planes written directly)")
         return _DevArray(ptr, (1, h.out_channels, h.img_size[0], h.img_size[1]), "<f4", self)
 
     def plane_device(self, slot: int, plane: int) -> _DevArray:

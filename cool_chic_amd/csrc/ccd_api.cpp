@@ -144,6 +144,7 @@ struct ccd_batch {
     void* d_fdec_work = nullptr;
     int opt_fused_dec = 1;               // CCD_OPT_FUSED_DEC
     int opt_keep_float = 1;              // CCD_OPT_KEEP_FLOAT
+    int opt_range_bits = 0;              // CCD_OPT_RANGE_BITS (tests: lowered limits of the dynamic operand check)
     int opt_mfma_arm = 0;                // CCD_OPT_MFMA_ARM (off: bit-exact but slower than the vector-ALU producers)
     // upsampling: step k of every slot's pyramid in one launch
     struct UpsStep { int first_z, n_z, max_w, max_h; };
@@ -279,7 +280,7 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     }
     int max_w = 0;
     for (int g = 0; g < h.n_grids; ++g) max_w = std::max(max_w, static_cast<int>(h.grid_w[g]));
-    s.use_pipe = !b->force_generic && entropy_pipe_supports(h.total_context_arm, h.n_hidden_layers_arm + 1, net.arm.narrow ? 1 : 0, max_w);
+    s.use_pipe = !b->force_generic && entropy_pipe_supports(h.total_context_arm, h.n_hidden_layers_arm + 1, (net.arm.w32 && net.feat_i32) ? 1 : 0, max_w);
     {
         long long max_w_abs = 0;
         for (const FixedLayer& L : net.arm.layers) for (int64_t w : L.w) max_w_abs = std::max<long long>(max_w_abs, w < 0 ? -w : w);
@@ -321,7 +322,9 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
             feat_px = std::max(feat_px, static_cast<size_t>(h.grid_h[fg]) * h.grid_w[fg]);
         }
     }
-    const size_t o_feat = A.reserve(feat_px * std::max(h.output_feature_ifce, 1) * 4);
+    // int32 planes (generic kernel) or int16 planes + int32 side planes in the second half (pipelined kernel)
+    const size_t feat_elems = feat_px * std::max(h.output_feature_ifce, 1);
+    const size_t o_feat = A.reserve(feat_elems * 8);
     const size_t o_status = A.reserve(512);
     const size_t dense_elems = static_cast<size_t>(s.dense_c) * s.dense_h * s.dense_w;
     size_t o_noise = 0, o_nstack[2] = {0, 0};
@@ -539,6 +542,10 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     E.arm = A.at<int64_t>(o_arm); E.arm_len = static_cast<int32_t>(arm_blob.size());
     E.ifce = A.at<int64_t>(o_ifce);
     E.ifce_feat = A.at<int32_t>(o_feat);
+    E.ifce_wide = A.at<int32_t>(o_feat) + feat_elems;
+    E.feat_bits = b->opt_range_bits ? std::min(std::max(b->opt_range_bits & 0xff, 8), 15) : 15;
+    E.act_bits = b->opt_range_bits ? std::min(std::max((b->opt_range_bits >> 8) & 0xff, 16), 31) : 31;
+    E.ifce_w32 = net.ifce_w32 ? 1 : 0;
     E.scale_table = b->d_scale_table;
     E.rcp_table = b->d_rcp_table;
     E.status = A.at<int32_t>(o_status);
@@ -891,6 +898,7 @@ int ccd_batch_set_option(ccd_batch* b, int option, int value) {
         case CCD_OPT_FUSED_DEC: b->opt_fused_dec = value; return CCD_OK;
         case CCD_OPT_KEEP_FLOAT: b->opt_keep_float = value; return CCD_OK;
         case CCD_OPT_MFMA_ARM: b->opt_mfma_arm = value; return CCD_OK;
+        case CCD_OPT_RANGE_BITS: b->opt_range_bits = value; return CCD_OK;
         default: return CCD_ERR_ARG;
     }
 }
@@ -1125,7 +1133,7 @@ int ccd_network_fits_fast_path(const uint8_t* cc_header, size_t n_hdr, const uin
     if (rc < 0) return rc;
     int max_w = 0;
     for (int g = 0; g < h->n_grids; ++g) max_w = std::max(max_w, static_cast<int>(h->grid_w[g]));
-    return entropy_pipe_supports(h->total_context_arm, h->n_hidden_layers_arm + 1, net.arm.narrow ? 1 : 0, max_w) ? 1 : 0;
+    return entropy_pipe_supports(h->total_context_arm, h->n_hidden_layers_arm + 1, (net.arm.w32 && net.feat_i32) ? 1 : 0, max_w) ? 1 : 0;
 }
 
 int ccd_debug_fd_profile(uint64_t* out16, int reset) {

@@ -1226,6 +1226,76 @@ __device__ __forceinline__ void mf_exact_task(const PipeCtx& C, int32_t* tile, i
     }
 }
 
+// ---- exactness of the 32-bit operands --------------------------------------------------------------------------------
+// The reference's ARM is wrapping int64 for any weights and data (armint.py:180-203).  The producers below multiply
+// int32 x int32 -> int64 (v_mad_i64_i32) and sum in wrapping int64: the same numbers whenever every OPERAND is exact in
+// 32 bits.  Weights: decided on the host (FixedArm::w32, else the slot runs ccd_entropy.hip).  Latents << 16: always.
+// IFCE features << 16 and hidden activations depend on the data: a feature with |f| >= 2^feat_bits is a sentinel in the
+// int16 plane (its value sits in the int32 side plane), an activation >= 2^act_bits shows in the high words the MLP ORs
+// together; one ballot per task, and a pixel that met either is redone here in plain 64 x 64 -> 64 arithmetic before its
+// table indices are published.  Never taken on the streams seen so far (features reach ~2^10, activations ~2^21); tests
+// lower the two limits to drive ordinary streams through it (EntropyParams::feat_bits / act_bits).
+constexpr int16_t kFeatSentinel = -32768;
+
+// One pixel's ARM in plain wrapping int64, the whole wave on it: lane k holds input / activation k (dim <= 32), lane o
+// computes output o of a layer with the activations broadcast one by one.  Every context of the pixel is decoded by now
+// (the caller is past the late wait).  Returns the two output sums (before >> 24) to every lane.  (As a real call it cost
+// the kernel 208 bytes of scratch per lane and the decoder its scalar operands; inlined it costs nothing outside its branch.)
+struct ExactArgs {
+    const EntropyParams* P;
+    uint32_t s_w, s_b, s_ring;  // LDS byte offsets
+    int n_w_hidden, dim, n_layers, n_sp, in_pad;
+    int W, fin, fw, feat_plane, ring_mask;
+};
+struct ExactOut { int64_t mu, ls; };
+__device__ __forceinline__ ExactOut exact_pixel(const ExactArgs& A, int y, int x) {
+    const EntropyParams& P = *A.P;
+    const int lane = threadIdx.x & 63;
+    const int dim = A.dim, n_layers = A.n_layers, n_sp = A.n_sp, in_pad = A.in_pad;
+    const int32_t* s_w = reinterpret_cast<const int32_t*>(ccd_pipe_smem + A.s_w);
+    const int64_t* s_b = reinterpret_cast<const int64_t*>(ccd_pipe_smem + A.s_b);
+    const int8_t* s_ring = reinterpret_cast<const int8_t*>(ccd_pipe_smem + A.s_ring);
+    uint64_t xin = 0;
+    if (lane < dim) {
+        int64_t v = 0;
+        if (lane < n_sp) {
+            const int yy = y - P.ctx_dy[lane], xx = x + P.ctx_dx[lane];
+            if (yy >= 0 && xx >= 0 && xx < A.W) v = s_ring[(yy & A.ring_mask) * 64 + ((xx + 10 * yy) & 63)];
+        } else if (A.fin > 0) {
+            const int fo = (lane - n_sp) * A.feat_plane + (y >> 1) * A.fw + (x >> 1);
+            v = reinterpret_cast<const int16_t*>(P.ifce_feat)[fo];
+            // side plane: the raw Q8 sum; the reference sends it through float32 and back (coolchic.py:142-144)
+            if (v == kFeatSentinel) v = static_cast<int64_t>(static_cast<float>(P.ifce_wide[fo]));
+        }
+        xin = static_cast<uint64_t>(v) << 16;  // armint.py:193
+    }
+    auto bcast = [&](uint64_t v, int k) {
+        const uint32_t lo = static_cast<uint32_t>(__shfl(static_cast<int>(static_cast<uint32_t>(v)), k));
+        const uint32_t hi = static_cast<uint32_t>(__shfl(static_cast<int>(static_cast<uint32_t>(v >> 32)), k));
+        return (static_cast<uint64_t>(hi) << 32) | lo;
+    };
+    // rows of Wt[out][in_pad] starting at `wt`, biases at `bias`; lanes >= n_out compute a discarded copy of the last row
+    auto layer = [&](const int32_t* wt, const int64_t* bias, int n_out, uint64_t xv) {
+        const int o = min(lane, n_out - 1);
+        uint64_t acc = static_cast<uint64_t>(bias[o]);
+#pragma unroll 1
+        for (int k = 0; k < dim; ++k) acc += bcast(xv, k) * static_cast<uint64_t>(static_cast<int64_t>(wt[o * in_pad + k]));
+        return acc;
+    };
+    const uint64_t stab = layer(s_w + A.n_w_hidden + 2 * in_pad, s_b + (n_layers - 1) * dim + 2, 2, xin);
+    uint64_t xv = xin;
+#pragma unroll 1
+    for (int l = 0; l < n_layers - 1; ++l) {
+        const int64_t a = static_cast<int64_t>(layer(s_w + l * dim * in_pad, s_b + l * dim, dim, xv));
+        xv = static_cast<uint64_t>((a < 0 ? 0 : a) >> 16);
+    }
+    const uint64_t out = layer(s_w + A.n_w_hidden, s_b + (n_layers - 1) * dim, 2, xv) + stab;
+    ExactOut r;
+    r.mu = static_cast<int64_t>(bcast(out, 0));
+    r.ls = static_cast<int64_t>(bcast(out, 1));
+    return r;
+}
+
 // MF: this grid's tasks run the ARM on the matrix cores; DYN_RING: the kernel's ring of decoded symbols has
 // EntropyParams::ring_rows rows instead of kRingRows (every grid of a matrix-core kernel, whichever producer serves it).
 template <int NV, int kLpp, bool MF, bool DYN_RING>
@@ -1249,6 +1319,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     const int q = MF ? (lane >> 4) : lane % kLpp;    // lane within the pixel's group (MF: K-slot group of the matrix operands)
     const int ring_mask = DYN_RING ? uni(C.ring_mask) : kRingRows - 1, n_if = uni(C.n_if), mf_bits = uni(P.mfma);
     (void)n_if; (void)mf_bits;
+    const uint32_t act_shift = static_cast<uint32_t>(uni(P.act_bits)) - 16u;  // activation a >> 16 >= 2^act_bits <=> (a >> 32) >> (act_bits - 16) != 0
+    (void)act_shift;
     const int4* act_row = reinterpret_cast<const int4*>(act + px * in_pad);
     // Per-lane constants of the gather: the lane always fetches inputs k = q + kLpp t.  Read through the parameter block
     // inside the task loop they were global loads on every task's path.
@@ -1318,6 +1390,11 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     if (!MF && px < cnt && k >= n_sp && k < dim && fin > 0)
                         fv[t] = ifce_feat[(k - n_sp) * feat_plane + (y >> 1) * fw + (x >> 1)];
                 }
+                // dynamic operand check (see exact_pixel): the hidden activations' high words are ORed into `act_hi` as they
+                // are produced
+                uint32_t act_hi = 0;  // bit 31 (never set by a non-negative activation): a sentinel among the lane's features
+#pragma unroll
+                for (int t = 0; t < NOUT; ++t) act_hi |= fv[t] == kFeatSentinel ? 0x80000000u : 0u;
                 // ---- Two waits.  Of all contexts only the left neighbour (y, x - 1) lies in the previous step (pixel i of this
                 // step reads pixel i of that one, pixel i + 1 when the step start moved down a row in between); (y, x - 2) lies
                 // two steps back, everything else at least five.  So the task gathers every other input, runs the stabiliser and
@@ -1614,6 +1691,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         mad64(acc0[t], xleft, wleft[t]);
                         const int o = q + kLpp * t;
                         const int64_t a = acc0[t] < 0 ? 0 : acc0[t];
+                        act_hi |= static_cast<uint32_t>(a >> 32);
                         if (o < in_pad) act[px * in_pad + o] = o < dim ? static_cast<int32_t>(a >> 16) : 0;
                     }
 #pragma unroll
@@ -1647,6 +1725,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     for (int t = 0; t < NOUT; ++t) {
                         const int o = q + kLpp * t;
                         const int64_t a = acc[t] < 0 ? 0 : acc[t];
+                        act_hi |= static_cast<uint32_t>(a >> 32);
                         if (o < in_pad) act[px * in_pad + o] = o < dim ? static_cast<int32_t>(a >> 16) : 0;
                     }
 #pragma unroll
@@ -1657,6 +1736,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // output layer (q = 0: mu, q = 1: log-scale) -> table indices -> per-pixel table parameters
                 const int mpx = slot * kBpx + half * kTaskPix + px;  // table row of the pixel
                 int32_t idx = 0;
+                int64_t acc = 0;
                 if (q < 2) {
                     const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + q * in_pad);
                     int64_t ao[2] = {C.s_b[(n_layers - 1) * dim + q] + stab, 0};
@@ -1669,7 +1749,26 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         int64_t& a = ao[v & 1];
                         mad64(a, xv[v].x, w.x); mad64(a, xv[v].y, w.y); mad64(a, xv[v].z, w.z); mad64(a, xv[v].w, w.w);
                     }
-                    const int64_t acc = ao[0] + ao[1];
+                    acc = ao[0] + ao[1];
+                }
+                // ---- an operand of some pixel was not exact in 32 bits (never on the streams seen so far): that pixel again,
+                // in plain int64, before anything of it is published
+                const unsigned long long bad_lanes = __ballot((act_hi >> act_shift) != 0u && px < cnt);
+                if (bad_lanes != 0ull) {
+                    int n_redo = 0;
+                    for (int p = 0; p < cnt; ++p) {
+                        if (((bad_lanes >> (p * kLpp)) & ((1ull << kLpp) - 1ull)) == 0ull) continue;
+                        ExactArgs A;
+                        A.P = C.P; A.s_w = C.s_w.off; A.s_b = C.s_b.off; A.s_ring = C.s_ring.off;
+                        A.n_w_hidden = C.n_w_hidden; A.dim = dim; A.n_layers = n_layers; A.n_sp = n_sp; A.in_pad = in_pad;
+                        A.W = W; A.fin = fin; A.fw = fw; A.feat_plane = feat_plane; A.ring_mask = ring_mask;
+                        const ExactOut r = exact_pixel(A, it.y0 + i0 + p, it.x0 - 10 * (i0 + p));
+                        if (px == p && q < 2) acc = q == 0 ? r.mu : r.ls;
+                        ++n_redo;
+                    }
+                    if (lane == 0) atomicAdd(reinterpret_cast<int*>(P.status) + 39, n_redo);  // status[39]: pixels redone (tests)
+                }
+                if (q < 2) {
                     const int64_t q8 = acc >> 24;
                     const int64_t off = q8 + (q == 0 ? kMuOffset : kScaleOffset);
                     const int64_t hi = q == 0 ? kNumMu - 1 : kNumScale - 1;
@@ -1859,7 +1958,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         mf_build_tables(C, in_pad, C.s_a, tid);
     }
     if (tid < kSlots) C.s_ready[tid] = 0;
-    if (tid == 0) { *C.s_consumed = 0; *C.s_abort = 0; }
+    if (tid == 0) { *C.s_consumed = 0; *C.s_abort = 0; P.status[39] = 0; }
 
     DecState S;
     S.range = ~uint64_t{0}; S.dist = 0; S.word_pos = 2; S.wbase = 2; S.wbuf = 0; S.n_decoded = 0;
@@ -1913,14 +2012,17 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
             }
             __syncthreads();
             const bool zero_input = g == P.n_grids - 1;  // first grid: the stack is one all-zero channel (coolchic.py:95-96)
-            int16_t* feat = reinterpret_cast<int16_t*>(P.ifce_feat);  // int16 planes: |feature| < 2^15 under `narrow`
-            if (fin <= kIfceFastIn && n_if <= 8) {
+            int16_t* feat = reinterpret_cast<int16_t*>(P.ifce_feat);  // int16 planes; larger features: sentinel + side plane
+            const int64_t feat_lim = int64_t{1} << P.feat_bits;
+            const int feat_hi_shift = P.feat_bits - 8;  // feat_bits in 8..15
+            if (fin <= kIfceFastIn && n_if <= 8 && P.ifce_w32) {
                 // The usual shape (<= 12 coarser grids incl. hyperlatents, <= 8 features).  The generic loop below waits for one
                 // L2 round trip per input channel and position (~10 k ticks per position, measured); here a position's `fin`
                 // bytes are requested together, one position ahead, through explicit global pointers (a FLAT access can only be
-                // waited for with vmcnt(0), i.e. together with the previous position's stores).  Under `narrow` |weight| < 2^17
-                // and |input << 16| < 2^23: one v_mad_i64_i32 per product gives the reference's int64 sums exactly, and the
-                // .to(torch.float) / back round trip around F.interpolate (coolchic.py:142-144) is the identity (|feature| < 2^15).
+                // waited for with vmcnt(0), i.e. together with the previous position's stores).  The weights fit int32
+                // (EntropyParams::ifce_w32) and |input << 16| < 2^23: one v_mad_i64_i32 per product gives the reference's wrapping
+                // int64 sums exactly; the .to(torch.float) / back round trip around F.interpolate (coolchic.py:142-144) is the
+                // identity for the int16 plane and applied by the reader of the side plane (exact_pixel).
                 // The loop body is straight-line code on purpose: with branches in it the compiler falls back to
                 // s_waitcnt vmcnt(0) everywhere.  Channels >= fin read channel fin - 1 again and meet zero weights; features
                 // >= n_if are computed and not stored (the store's predicate is a lane mask).
@@ -1933,6 +2035,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                 }
                 __syncthreads();
                 const glb_ptr<int16_t> featg = (glb_ptr<int16_t>)feat;
+                const glb_ptr<int32_t> wideg = (glb_ptr<int32_t>)P.ifce_wide;
                 const int plane = fh * fw;
                 // source descriptors: wave-uniform, read from LDS once (inside the loop each costs an LDS round trip per position)
                 glb_ptr<const int8_t> srcp[kIfceFastIn];
@@ -1974,8 +2077,16 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                         acc[4] += x * w1.x; acc[5] += x * w1.y; acc[6] += x * w1.z; acc[7] += x * w1.w;
                     }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        if (j < n_if_lane) featg[min(j, n_if - 1) * plane + p] = static_cast<int16_t>(acc[j] >> 24);
+                    for (int j = 0; j < 8; ++j) {
+                        // |feature| >= 2^feat_bits: sentinel in the int16 plane, the value itself in the int32 side plane
+                        // (exactness notes above exact_pixel); both stores are predicated per lane, not branched around.
+                        // 32-bit tests: q8 = acc >> 24 lies in [-2^b, 2^b) iff the bits of acc from 24 + b up are all equal.
+                        const int32_t hi = static_cast<int32_t>(acc[j] >> 32), q32 = static_cast<int32_t>(acc[j] >> 24);
+                        const bool big = static_cast<uint32_t>((hi >> feat_hi_shift) + 1) > 1u || (q32 & 0xffff) == 0x8000;
+                        const int fo = min(j, n_if - 1) * plane + p;
+                        if (j < n_if_lane) featg[fo] = big ? kFeatSentinel : static_cast<int16_t>(q32);
+                        if (j < n_if_lane && big) wideg[fo] = q32;
+                    }
                 }
             } else
             for (int p = tid; p < fh * fw; p += kPipeThreads) {
@@ -1997,8 +2108,9 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                     for (int j = 0; j < 8; ++j) {
                         if (o0 + j < n_if) {
                             const int64_t q8 = static_cast<int64_t>(acc[j]) >> 24;
-                            // .to(torch.float) / back to int64 round trip around F.interpolate (coolchic.py:142-144)
-                            feat[(o0 + j) * fh * fw + p] = static_cast<int16_t>(static_cast<int64_t>(static_cast<float>(q8)));
+                            const bool big = static_cast<uint64_t>(q8 + feat_lim - 1) >= static_cast<uint64_t>(2 * feat_lim - 1);
+                            feat[(o0 + j) * fh * fw + p] = big ? kFeatSentinel : static_cast<int16_t>(q8);
+                            if (big) P.ifce_wide[(o0 + j) * fh * fw + p] = static_cast<int32_t>(q8);
                         }
                     }
                 }
@@ -2102,16 +2214,18 @@ int entropy_pipe_ring_rows(int max_grid_w) {
     return r;
 }
 
-bool entropy_pipe_supports(int dim, int n_layers, int narrow, int max_grid_w) {
+// `operands_ok`: the static part of the 32-bit operand envelope (FixedArm::w32 && Network::feat_i32, ccd_format.cpp); the
+// data-dependent part is checked on the device (exact_pixel).  The vector-ALU kernel always carries the full ring.
+bool entropy_pipe_supports(int dim, int n_layers, int operands_ok, int max_grid_w) {
     const int ring = entropy_pipe_ring_rows(max_grid_w);
-    return narrow && dim <= 4 * kMaxNV && n_layers <= 8 && ring > 0 && entropy_pipe_lds_bytes(dim, n_layers, ring, 0) <= 160 * 1024;
+    return operands_ok && dim <= 4 * kMaxNV && n_layers <= 8 && ring > 0 && entropy_pipe_lds_bytes(dim, n_layers, kRingRows, 0) <= 160 * 1024;
 }
 
 // The matrix-core evaluation of the ARM (see the MF notes above producer_grid); max_abs_weight over every ARM layer
 // and the stabiliser.
 bool entropy_pipe_supports_mfma(int dim, int n_layers, int n_ifce_out, int narrow, int max_grid_w, long long max_abs_weight) {
     const int ring = entropy_pipe_ring_rows(max_grid_w);
-    return entropy_pipe_supports(dim, n_layers, narrow, max_grid_w) && dim <= 20 && n_layers >= 2 && n_ifce_out <= 8 &&
+    return narrow && ring > 0 && dim <= 20 && n_layers >= 2 && n_layers <= 8 && n_ifce_out <= 8 &&
            max_abs_weight < (1ll << 23) && entropy_pipe_lds_bytes(dim, n_layers, ring, 1) <= 160 * 1024;
 }
 

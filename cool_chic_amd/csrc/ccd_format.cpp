@@ -397,6 +397,32 @@ int decode_network(const ccd_cc_header& h, const uint8_t* bytes_nn, size_t n_nn,
         // fractional bits, and a feature above 2^24 would also lose bits in the reference's float
         // round trip (coolchic.py:142-144) - outside the narrow envelope either way.
         net.arm.narrow = analyse_bounds(net.arm, in_bound, 24, nullptr) && worst_feature < (u128{1} << 24);
+        // ---- the pipelined kernel's envelope: static on the weights, dynamic on the data -------------
+        const u128 lim32 = (u128{1} << 31) - 1;
+        net.arm.w32 = true;
+        for (const FixedLayer& L : net.arm.layers) for (int64_t w : L.w) if (mag(w) > lim32) net.arm.w32 = false;
+        for (int64_t w : net.arm.ws) if (mag(w) > lim32) net.arm.w32 = false;
+        net.ifce_w32 = true;
+        for (int g = 0; g < h.n_grids; ++g)
+            if (w[g]) for (int64_t v : net.ifce[g].layers[0].w) if (mag(v) > lim32) net.ifce_w32 = false;
+        net.feat_i32 = worst_feature < (u128{1} << 30);
+        net.arm.dyn_feat = worst_feature >= (u128{1} << 15);
+        {   // worst hidden activation (after >> 16) with the worst-case features: can it leave int32?
+            std::vector<u128> x(dim);
+            for (int i = 0; i < dim; ++i) x[i] = std::min(in_bound[i], u128{1} << 40) << 16;
+            net.arm.dyn_act = !net.arm.w32;  // (weights beyond int32 never reach the pipelined kernel; keeps the sums below inside u128)
+            for (size_t l = 0; net.arm.w32 && l + 1 < net.arm.layers.size(); ++l) {
+                const FixedLayer& L = net.arm.layers[l];
+                std::vector<u128> y(L.n_out);
+                for (int o = 0; o < L.n_out; ++o) {
+                    u128 acc = mag(L.b[o]);
+                    for (int i = 0; i < L.n_in; ++i) acc += std::min(x[i], u128{1} << 62) * mag(L.w[static_cast<size_t>(i) * L.n_out + o]);
+                    y[o] = (acc >> 16) + 1;
+                    if (y[o] > lim32) net.arm.dyn_act = true;
+                }
+                x = y;
+            }
+        }
     }
     // ---- Upsampling ------------------------------------------------------------------------------
     net.n_ups = n_ups; net.ups_k = h.ups_k_size; net.pre_k = h.ups_preconcat_k_size;

@@ -48,9 +48,17 @@ struct FixedArm {
     std::vector<int64_t> ws, bs;     // stabiliser [dim][n_out], [n_out] (zeros when absent)
     int n_out = 2;
     // true when every operand fits int32 and no accumulator can leave int64 without wrapping, for
-    // inputs bounded by |latent| <= 64 and the worst-case IFCE features: the kernel may then use
-    // 32x32->64 multiply-adds; otherwise it runs full 64-bit wrap-around arithmetic like torch.
+    // inputs bounded by |latent| <= 64 and the WORST-CASE IFCE features (every context at +-64 with the
+    // sign that hurts): the static envelope of the matrix-core variant of the pipelined kernel.
     bool narrow = false;
+    // The pipelined kernel's own, much wider envelope.  It multiplies int32 x int32 -> int64 and sums
+    // in wrapping int64, which is the reference's arithmetic (armint.py:180-203, torch int64 wraps)
+    // whenever the OPERANDS are exact in 32 bits: weights (static, decided here), latents << 16
+    // (always), IFCE features << 16 and hidden activations (data dependent: checked per task on the
+    // device, the offending pixel is redone in plain int64).  w32: every ARM / stabiliser weight
+    // fits int32.  dyn_feat / dyn_act: the worst case of a feature / hidden activation does not fit
+    // 16 / 32 bits, i.e. the device checks can fire at all (they run regardless).
+    bool w32 = false, dyn_feat = false, dyn_act = false;
 };
 
 struct SynLayerParams {
@@ -64,6 +72,8 @@ struct Network {
     FixedArm arm;
     std::vector<FixedArm> ifce;          // one per grid (dim == 0 when the grid has no IFCE)
     std::vector<int64_t> ifce_feat_bound;  // per grid: worst-case |feature| (Q8)
+    bool ifce_w32 = false;               // every IFCE weight fits int32 (the register-resident feature pass)
+    bool feat_i32 = false;               // the worst-case feature fits the int32 side plane of the pipelined kernel (< 2^30)
     int n_ups = 0, ups_k = 0, pre_k = 0;
     std::vector<float> ups_w;            // [n_ups][ups_k] symmetric 1-D kernels (upsampling.py:42-64)
     std::vector<float> pre_w;            // [n_ups][pre_k]

@@ -557,7 +557,13 @@ struct ccd_png {
     uint32_t* d_row_adler = nullptr; // [rows][2]
     uint32_t* d_meta = nullptr;      // [pictures][8]
     uint32_t* h_meta = nullptr;      // pinned copy of d_meta
-    PngJob* d_jobs = nullptr;
+    // job table: two pinned host copies and two device copies used alternately, each guarded by an event recorded behind the
+    // kernels that read it - a pack neither blocks on the stream nor hands the runtime a pageable buffer
+    PngJob* d_jobs[2] = {nullptr, nullptr};
+    PngJob* h_jobs[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool ev_used[2] = {false, false};
+    int flip = 0;
     uint32_t x2n[32];
     int pending = 0;                 // pictures of the pack in flight
 };
@@ -592,7 +598,11 @@ void ccd_png_destroy(ccd_png* p) {
     if (p->d_blk_bits) (void)hipFree(p->d_blk_bits);
     if (p->d_row_adler) (void)hipFree(p->d_row_adler);
     if (p->d_meta) (void)hipFree(p->d_meta);
-    if (p->d_jobs) (void)hipFree(p->d_jobs);
+    for (int k = 0; k < 2; ++k) {
+        if (p->d_jobs[k]) (void)hipFree(p->d_jobs[k]);
+        if (p->h_jobs[k]) (void)hipHostFree(p->h_jobs[k]);
+        if (p->ev[k]) (void)hipEventDestroy(p->ev[k]);
+    }
     if (p->h_meta) (void)hipHostFree(p->h_meta);
     delete p;
 }
@@ -622,12 +632,27 @@ int ccd_png_pack_batch(ccd_png* p, const ccd_png_item* items, int n, void* strea
         }
         if (!grow(&p->d_scan, &p->scan_cap, scan_need) || !grow(&p->d_codes, &p->codes_cap, blocks * 257) ||
             !grow(&p->d_blk_bits, &p->bits_cap, blocks) || !grow(&p->d_row_adler, &p->adler_cap, rows * 2) ||
-            !grow(&p->d_jobs, &p->jobs_cap, static_cast<size_t>(n)) || !grow(&p->d_meta, &p->meta_cap, static_cast<size_t>(n) * 8))
+            !grow(&p->d_meta, &p->meta_cap, static_cast<size_t>(n) * 8))
             return CCD_ERR_NOMEM;
+        if (static_cast<size_t>(n) > p->jobs_cap) {
+            for (int k = 0; k < 2; ++k) {
+                size_t cap = p->jobs_cap;
+                if (!grow(&p->d_jobs[k], &cap, static_cast<size_t>(n))) return CCD_ERR_NOMEM;
+                if (p->h_jobs[k]) (void)hipHostFree(p->h_jobs[k]);
+                p->h_jobs[k] = nullptr;
+                if (hipHostMalloc(reinterpret_cast<void**>(&p->h_jobs[k]), static_cast<size_t>(n) * sizeof(PngJob), hipHostMallocDefault) != hipSuccess)
+                    return CCD_ERR_NOMEM;
+                if (!p->ev[k] && hipEventCreateWithFlags(&p->ev[k], hipEventDisableTiming) != hipSuccess) return CCD_ERR_HIP;
+                p->ev_used[k] = false;  // the stream was drained above
+            }
+            p->jobs_cap = static_cast<size_t>(n);
+        }
     }
-    // job table (pageable source: the runtime stages it before the call returns)
-    PngJob* jobs = new (std::nothrow) PngJob[n];
-    if (!jobs) return CCD_ERR_NOMEM;
+    const int jk = p->flip;
+    p->flip ^= 1;
+    // this copy of the table was last read two packs ago: normally long finished
+    if (p->ev_used[jk] && hipEventSynchronize(p->ev[jk]) != hipSuccess) return CCD_ERR_HIP;
+    PngJob* jobs = p->h_jobs[jk];
     size_t scan_off = 0, blk_off = 0, row_off = 0;
     for (int i = 0; i < n; ++i) {
         const ccd_png_item& it = items[i];
@@ -648,17 +673,13 @@ int ccd_png_pack_batch(ccd_png* p, const ccd_png_item* items, int n, void* strea
         blk_off += J.nblk;
         row_off += it.h;
     }
-    // `jobs` is pageable and freed below: a synchronous copy (the table is a few hundred bytes per picture), so that the
-    // host buffer is certainly consumed when the call returns.  The device buffer may still be read by the previous
-    // batch's kernels on `st`: order the copy behind them.
-    hipError_t e = hipStreamSynchronize(st);
-    if (e == hipSuccess) e = hipMemcpy(p->d_jobs, jobs, static_cast<size_t>(n) * sizeof(PngJob), hipMemcpyHostToDevice);
+    hipError_t e = hipMemcpyAsync(p->d_jobs[jk], jobs, static_cast<size_t>(n) * sizeof(PngJob), hipMemcpyHostToDevice, st);
     int rc = e == hipSuccess ? CCD_OK : CCD_ERR_HIP;
     for (int first = 0; first < n && rc == CCD_OK; first += kMaxBatch) {
         const int cnt = std::min(kMaxBatch, n - first);
         PngBatch B;
         std::memset(&B, 0, sizeof(B));
-        B.img = p->d_jobs + first;
+        B.img = p->d_jobs[jk] + first;
         B.n = cnt;
         std::memcpy(B.x2n, p->x2n, sizeof(B.x2n));
         for (int i = 0; i < cnt; ++i) {
@@ -674,7 +695,8 @@ int ccd_png_pack_batch(ccd_png* p, const ccd_png_item* items, int n, void* strea
         hipLaunchKernelGGL(png_crc_final_kernel, dim3(cnt), dim3(64), 0, st, B);
         if (hipGetLastError() != hipSuccess) rc = CCD_ERR_HIP;
     }
-    delete[] jobs;
+    if (hipEventRecord(p->ev[jk], st) != hipSuccess) rc = CCD_ERR_HIP;
+    p->ev_used[jk] = true;
     if (rc != CCD_OK) return rc;
     if (hipMemcpyAsync(p->h_meta, p->d_meta, static_cast<size_t>(n) * 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st) != hipSuccess)
         return CCD_ERR_HIP;

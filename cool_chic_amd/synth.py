@@ -21,7 +21,10 @@ from . import writer
 from ._lib import CCHeader
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-GOLDEN = os.path.join(os.path.dirname(_HERE), "tests", "golden")
+# donor streams (the reference's kodim14.cool, the reference-encoded 5-frame video), their latent grids and network
+# integers: package data written by tools/make_package_data.py
+DONORS = os.path.join(_HERE, "data", "donors.npz")
+_donors = None
 
 # (H, W) per picture of CLIC20-pro-valid: H * W = the TSV's n_pixels, rows in the TSV's order
 CLIC41_SIZES = [(1363, 2048), (1339, 2048), (1188, 2048), (1361, 2048), (1365, 2048), (1020, 1464), (1361, 2048), (1365, 2048),
@@ -44,10 +47,21 @@ def _pool(n: int) -> ThreadPoolExecutor:
     return ThreadPoolExecutor(max_workers=max(1, min(n, 32, os.cpu_count() or 4)))  # the writer's ARM walk releases the GIL
 
 
+class _Donor:
+    """Arrays of one donor stream: d["cc0.latent3"], d["cc0.nn_ints"]."""
+
+    def __init__(self, z, name):
+        self._z, self._p = z, name + "."
+
+    def __getitem__(self, key):
+        return self._z[self._p + key]
+
+
 def _golden(name: str):
-    with open(os.path.join(GOLDEN, name + ".cool"), "rb") as f:
-        bs = f.read()
-    return bs, np.load(os.path.join(GOLDEN, name + ".npz"))
+    global _donors
+    if _donors is None:
+        _donors = np.load(DONORS)
+    return _donors[name + ".cool"].tobytes(), _Donor(_donors, name)
 
 
 def split_image_stream(bs: bytes) -> Triple:
@@ -141,11 +155,12 @@ def hierarchical_gop(intra_period: int) -> List[Tuple[int, str, List[int], int]]
     return out
 
 
-def gop1080p(intra_period: int = 32, size: Tuple[int, int] = (1080, 1920)) -> Tuple[bytes, dict]:
+def gop1080p(intra_period: int = 32, size: Tuple[int, int] = (1080, 1920), i_frames: str = "vid5") -> Tuple[bytes, dict]:
     """BASELINE configs[3]: a 1920x1080 YUV 4:2:0 8-bit GOP of intra_period + 1 frames (I0, I<period>, hierarchical B in
-    between): the networks and headers of the reference-encoded `vid5` fixture (I = intra/hop, B at depth 1 =
-    residue/mop + motion/mop, deeper B = lop, samples/encode.py:23-70), residue cool-chics grown to the "auto" levels of
-    the picture size, latents tiled.  Returns (stream, info)."""
+    between): the networks and headers of the reference-encoded `vid5` donor, frame by role (its I frame; its depth-1 B
+    frame = residue + motion; its deeper B frames), residue cool-chics grown to the "auto" levels of the picture size,
+    latents tiled.  i_frames="hop" swaps the I frames' cool-chic for kodim14's HOP network (samples/encode.py:23-70 codes
+    the intra frames of real sequences with intra/hop; vid5 was encoded with the --debug preset).  Returns (stream, info)."""
     from .bitstream.decode import _split_frame
     from .bitstream.header import VideoHeader
 
@@ -162,10 +177,11 @@ def gop1080p(intra_period: int = 32, size: Tuple[int, int] = (1080, 1920)) -> Tu
             role[key] = (fh.c, [(ch.raw, nn, [z[f"cc{cc_idx + j}.latent{g}"] for g in range(ch.c.n_grids)], z[f"cc{cc_idx + j}.nn_ints"])
                                 for j, (ch, nn, _) in enumerate(ccs)])
         cc_idx += len(ccs)
-    # I frames: intra/hop (samples/encode.py:30-36) = kodim14's architecture and trained network (vid5's own I frame is a
-    # 60-iteration LOP network whose integer ARM leaves the 32-bit envelope of the production entropy kernel)
-    _, k_hdr, k_nn, _, k_ints, k_lat = _kodim14()
-    role["I"] = (role["I"][0], [(k_hdr, k_nn, k_lat, k_ints)])
+    if i_frames == "hop":
+        # I frames as samples/encode.py:30-36 configures them for real sequences: intra/hop = kodim14's architecture and
+        # trained network.  The default keeps vid5's own I-frame cool-chic (the --debug preset's LOP network).
+        _, k_hdr, k_nn, _, k_ints, k_lat = _kodim14()
+        role["I"] = (role["I"][0], [(k_hdr, k_nn, k_lat, k_ints)])
     H, W = size
     order = hierarchical_gop(intra_period)
 

@@ -132,7 +132,8 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage);
 int ccd_batch_wait(ccd_batch* b, void* stream);
 int ccd_batch_slot_status(const ccd_batch* b, int slot);
 /* Raw per-slot counters of the entropy kernel after ccd_batch_wait: [0] status, [1] payload words read,
- * [2..3] symbols decoded (lo, hi); [4..63] profiling cycle counters when built with -DCCD_PIPE_PROFILE.
+ * [2..3] symbols decoded (lo, hi); [39] pixels the pipelined kernel redid in int64 (dynamic operand check); the other
+ * words [4..63] are profiling cycle counters when built with -DCCD_PIPE_PROFILE.
  * `out64` receives 64 words. */
 int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64);
 /* Which kernels serve this slot: bit 0 = pipelined entropy kernel (else the generic int64 one),
@@ -152,8 +153,12 @@ int ccd_batch_slot_kernels(const ccd_batch* b, int slot);
  *                       v_mfma_i32_16x16x64_i8 (exact limb-split int8).  Results are identical bit for bit either way; on
  *                       MI355X the matrix-core variant is the slower one, it is kept as a measured
  *                       alternative.  Values 2..22 lower the activation width above which a task is redone in plain
- *                       int64 - normally 23 bits - so that tests reach that path. */
-enum { CCD_OPT_FUSED_DEC = 1, CCD_OPT_KEEP_FLOAT = 2, CCD_OPT_MFMA_ARM = 3 };
+ *                       int64 - normally 23 bits - so that tests reach that path.
+ *   CCD_OPT_RANGE_BITS  0 (default): production limits of the pipelined entropy kernel's dynamic operand check (an IFCE feature
+ *                       with |f| >= 2^15 or a hidden activation >= 2^31 sends its pixel through the int64 redo).  Tests pass
+ *                       feat_bits | act_bits << 8 (8..15, 16..31) to lower the limits and drive ordinary streams through the
+ *                       redo; results are identical bit for bit.  ccd_batch_slot_stats word [39] counts the redone pixels. */
+enum { CCD_OPT_FUSED_DEC = 1, CCD_OPT_KEEP_FLOAT = 2, CCD_OPT_MFMA_ARM = 3, CCD_OPT_RANGE_BITS = 4 };
 int ccd_batch_set_option(ccd_batch* b, int option, int value);
 
 /* Device pointers of a slot's results (valid until the batch is destroyed / re-run): */
@@ -263,9 +268,11 @@ int ccd_compute_rate(int device, void* stream, const float* x, const float* mu, 
 int ccd_debug_laplace_bounds(int device, const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* s,
                              int64_t n, uint32_t* left, uint32_t* right);
 
-/* Host only: 1 when this cool-chic's ARM runs on the pipelined entropy kernel (every operand of the integer MLP provably
- * fits 32 bits for |latent| <= 64 and the worst-case IFCE features, no accumulator can wrap, picture not wider than the
- * symbol ring), 0 when it needs the generic 64-bit kernel (~7x slower), < 0 on a malformed header / payload. */
+/* Host only: 1 when this cool-chic's ARM runs on the pipelined entropy kernel: every ARM / stabiliser weight fits int32, the
+ * worst-case IFCE feature fits the kernel's int32 side plane (< 2^30), <= 32 ARM inputs, <= 8 layers, picture not wider than
+ * the symbol ring (5 060).  What depends on the data - IFCE features and hidden activations as 32-bit operands - is checked
+ * per task on the device and the pixel redone in plain int64 (never taken on any stream seen so far).  0 when it needs the
+ * generic 64-bit kernel (~7x slower; no network the reference encoder produced does), < 0 on a malformed header / payload. */
 int ccd_network_fits_fast_path(const uint8_t* cc_header, size_t n_hdr, const uint8_t* bytes_nn, size_t n_nn);
 
 /* Profile builds only (-DCCD_FD_PROFILE): cycles per phase of the fused float kernel, summed over wave 0 of every

@@ -33,22 +33,30 @@ def _decode(gpu, triples, bitdepth, fdt, **opts):
     return b
 
 
-@pytest.mark.parametrize("path", ["fused", "unfused"])
+@pytest.mark.parametrize("path", ["production", "mfma", "unfused"])
 @pytest.mark.parametrize("name", IMAGE_STREAMS)
 def test_stream_parity(gpu, oracle, name, path):
-    """path = "fused": the production path - the ARM's layers on the matrix cores where the stream allows (limb-split int8),
-    upsampling + synthesis + integer samples in one kernel (ccd_fused.hip, every preset architecture); "unfused": the ARM on
-    the vector ALU, per-level upsampling launches + synthesis kernel, which also exposes the dense stack."""
+    """path = "production": the library defaults - the pipelined entropy kernel with the ARM on the vector ALU, upsampling +
+    synthesis + integer samples in one kernel (ccd_fused.hip, every preset architecture); "mfma": the same with the ARM's
+    layers on the matrix cores where the stream allows (limb-split int8; the measured, slower alternative); "unfused":
+    per-level upsampling launches + synthesis kernel, which also exposes the dense stack."""
     bs, z, j = load_golden(name)
     _, frames = oracle.split_stream(bs)
     fh, ccs = frames[0]
     ref = oracle.decode_coolchic(*ccs[0])
-    b = _decode(gpu, ccs[:1], fh.bitdepth, fh.frame_data_type, fused_dec=(path == "fused"), mfma_arm=int(path == "fused"))
+    opts = {"production": {}, "mfma": {"mfma_arm": 1}, "unfused": {"fused_dec": False, "mfma_arm": 0}}[path]
+    b = _decode(gpu, ccs[:1], fh.bitdepth, fh.frame_data_type, **opts)
     try:
-        if path == "fused" and name != "cr192":  # common randomness is outside the fused kernel's envelope
+        # every network the reference encoder produced runs the pipelined entropy kernel (the generic int64 kernel is the
+        # safety net for weights beyond int32, reached in tests through CCD_FORCE_GENERIC)
+        assert b.slot_kernels(0) & 1, "the pipelined entropy kernel must serve this stream"
+        assert b.slot_stats(0)[39] == 0, "no pixel of a reference-encoded stream needs the int64 redo"
+        if path != "unfused" and name != "cr192":  # common randomness is outside the fused kernel's envelope
             assert b.slot_kernels(0) & 4, "the fused float kernel must serve this stream"
-        if path == "fused" and name == "kodim14":
+        if path == "mfma" and name == "kodim14":
             assert b.slot_kernels(0) & 8, "the ARM of the reference's sample stream must run on the matrix cores"
+        if path == "production":
+            assert not b.slot_kernels(0) & 8
         if path == "unfused":
             assert not b.slot_kernels(0) & 12
         # integer stage: every latent grid bit-exact with the oracle AND the reference fixture
@@ -90,6 +98,29 @@ def test_mfma_arm_exact_redo(gpu, oracle, name, bits):
         assert b.slot_status(0) == 0
         for g in range(len([k for k in z.files if k.startswith("cc0.latent")])):
             assert np.array_equal(b.latent(0, g), z[f"cc0.latent{g}"]), f"grid {g} vs reference fixture"
+    finally:
+        b.close()
+
+
+@pytest.mark.parametrize("bits", [(8, 31), (15, 16), (8, 16), (12, 21)])
+@pytest.mark.parametrize("name", ["kodim14", "rgb192", "yuv444_10b"])
+def test_dynamic_operand_redo(gpu, oracle, name, bits):
+    """The pipelined entropy kernel multiplies 32-bit operands; IFCE features and hidden activations that do not fit send
+    their pixel through an int64 redo (exact_pixel).  No real stream gets there (features reach ~2^10 of 2^15, activations
+    ~2^21 of 2^31), so the two limits are lowered until many / a few pixels do: the latents must not change.
+    rgb192 and yuv444_10b are networks whose WORST-CASE feature exceeds 2^15 (the r02 static envelope sent them to the
+    generic kernel)."""
+    bs, z, j = load_golden(name)
+    fh, ccs = oracle.split_stream(bs)[1][0]
+    b = _decode(gpu, ccs[:1], fh.bitdepth, fh.frame_data_type, range_bits=bits)
+    try:
+        assert b.slot_kernels(0) & 1
+        assert b.slot_status(0) == 0
+        n_redo = int(b.slot_stats(0)[39])
+        if bits != (12, 21):
+            assert n_redo > 0, "the lowered limits must drive pixels through the redo"
+        for g in range(len([k for k in z.files if k.startswith("cc0.latent")])):
+            assert np.array_equal(b.latent(0, g), z[f"cc0.latent{g}"]), f"grid {g} vs reference fixture ({n_redo} pixels redone)"
     finally:
         b.close()
 

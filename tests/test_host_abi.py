@@ -243,3 +243,20 @@ def test_header_readers_survive_garbage():
                        (lib().ccd_read_cc_header, CCHeader())):
             rc = fn(raw, len(raw), C.byref(st))
             assert rc < 0 or 0 < rc <= len(raw)
+
+
+@pytest.mark.parametrize("name", IMAGE_STREAMS + ["vid5"])
+def test_every_reference_network_fits_the_pipelined_kernel(oracle, name):
+    """ccd_network_fits_fast_path (host only): the static envelope of the pipelined entropy kernel is on the WEIGHTS (int32);
+    what depends on the data is checked on the device.  Every network the reference encoder produced in the build container
+    is inside it - the r02 worst-case envelope sent rgb192 / cr192, yuv444_10b and vid5's I frame to the generic kernel."""
+    from cool_chic_amd import writer
+
+    bs, z, j = load_golden(name)
+    _, frames = oracle.split_stream(bs)
+    n = 0
+    for fh, ccs in frames:
+        for hdr, nn, lat in ccs:
+            assert writer.fits_fast_path(hdr, nn), f"{name}: cool-chic {n}"
+            n += 1
+    assert n == (9 if name == "vid5" else 1)
