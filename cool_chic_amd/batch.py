@@ -29,13 +29,13 @@ class DecodeBatch:
     OPT_FUSED_DEC, OPT_KEEP_FLOAT, OPT_MFMA_ARM, OPT_RANGE_BITS = 1, 2, 3, 4  # include/ccd.h
 
     def __init__(self, device: int = 0, fused_dec: Optional[bool] = None, keep_float: Optional[bool] = None,
-                 mfma_arm: Optional[int] = None, range_bits: Optional[Tuple[int, int]] = None):
+                 mfma_arm: Optional[int] = None, range_bits: Optional[int] = None):
         """fused_dec=False: unfused float path (materialises dense()); keep_float=False: rgb / yuv444 intra slots
         write integer planes only (output() is then unavailable for them); mfma_arm=1: the integer ARM on the matrix
-        cores where the stream allows (2..22: test hook, see ccd.h); range_bits=(feature bits, activation bits): test
-        hook that lowers the limits of the pipelined entropy kernel's dynamic operand check.
+        cores where the stream allows (2..22: test hook, see ccd.h); range_bits=8..14: test hook that lowers the feature
+        limit of the pipelined entropy kernel's dynamic operand check.
         None = library default: fused_dec on, keep_float on, mfma_arm OFF (the vector-ALU ARM is the faster one),
-        production limits (15, 31)."""
+        production limit (15 bits)."""
         self._h = C.c_void_p()
         check(lib().ccd_batch_create(int(device), C.byref(self._h)), "ccd_batch_create")
         self.device = int(device)
@@ -46,7 +46,7 @@ class DecodeBatch:
         if mfma_arm is not None:
             check(lib().ccd_batch_set_option(self._h, self.OPT_MFMA_ARM, int(mfma_arm)), "ccd_batch_set_option")
         if range_bits is not None:
-            check(lib().ccd_batch_set_option(self._h, self.OPT_RANGE_BITS, int(range_bits[0]) | int(range_bits[1]) << 8), "ccd_batch_set_option")
+            check(lib().ccd_batch_set_option(self._h, self.OPT_RANGE_BITS, int(range_bits)), "ccd_batch_set_option")
         self._meta: List[Tuple[int, int]] = []
 
     def close(self):

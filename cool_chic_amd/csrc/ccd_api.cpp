@@ -144,7 +144,7 @@ struct ccd_batch {
     void* d_fdec_work = nullptr;
     int opt_fused_dec = 1;               // CCD_OPT_FUSED_DEC
     int opt_keep_float = 1;              // CCD_OPT_KEEP_FLOAT
-    int opt_range_bits = 0;              // CCD_OPT_RANGE_BITS (tests: lowered limits of the dynamic operand check)
+    int opt_range_bits = 0;              // CCD_OPT_RANGE_BITS (tests: lowered feature limit of the dynamic operand check)
     int opt_mfma_arm = 0;                // CCD_OPT_MFMA_ARM (off: bit-exact but slower than the vector-ALU producers)
     // upsampling: step k of every slot's pyramid in one launch
     struct UpsStep { int first_z, n_z, max_w, max_h; };
@@ -280,7 +280,7 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     }
     int max_w = 0;
     for (int g = 0; g < h.n_grids; ++g) max_w = std::max(max_w, static_cast<int>(h.grid_w[g]));
-    s.use_pipe = !b->force_generic && entropy_pipe_supports(h.total_context_arm, h.n_hidden_layers_arm + 1, (net.arm.w32 && net.feat_i32) ? 1 : 0, max_w);
+    s.use_pipe = !b->force_generic && entropy_pipe_supports(h.total_context_arm, h.n_hidden_layers_arm + 1, (net.arm.w32 && net.feat_i32 && !net.arm.dyn_act) ? 1 : 0, max_w);
     {
         long long max_w_abs = 0;
         for (const FixedLayer& L : net.arm.layers) for (int64_t w : L.w) max_w_abs = std::max<long long>(max_w_abs, w < 0 ? -w : w);
@@ -543,8 +543,7 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     E.ifce = A.at<int64_t>(o_ifce);
     E.ifce_feat = A.at<int32_t>(o_feat);
     E.ifce_wide = A.at<int32_t>(o_feat) + feat_elems;
-    E.feat_bits = b->opt_range_bits ? std::min(std::max(b->opt_range_bits & 0xff, 8), 15) : 15;
-    E.act_bits = b->opt_range_bits ? std::min(std::max((b->opt_range_bits >> 8) & 0xff, 16), 31) : 31;
+    E.feat_bits = b->opt_range_bits ? std::min(std::max(b->opt_range_bits, 8), 15) : 15;
     E.ifce_w32 = net.ifce_w32 ? 1 : 0;
     E.scale_table = b->d_scale_table;
     E.rcp_table = b->d_rcp_table;
@@ -1133,7 +1132,7 @@ int ccd_network_fits_fast_path(const uint8_t* cc_header, size_t n_hdr, const uin
     if (rc < 0) return rc;
     int max_w = 0;
     for (int g = 0; g < h->n_grids; ++g) max_w = std::max(max_w, static_cast<int>(h->grid_w[g]));
-    return entropy_pipe_supports(h->total_context_arm, h->n_hidden_layers_arm + 1, (net.arm.w32 && net.feat_i32) ? 1 : 0, max_w) ? 1 : 0;
+    return entropy_pipe_supports(h->total_context_arm, h->n_hidden_layers_arm + 1, (net.arm.w32 && net.feat_i32 && !net.arm.dyn_act) ? 1 : 0, max_w) ? 1 : 0;
 }
 
 int ccd_debug_fd_profile(uint64_t* out16, int reset) {

@@ -35,12 +35,12 @@ struct EntropyParams {
     const double* rcp_table;   // RN(1 / (double)scale): correctly rounded reciprocals for the f64 quotient
     int32_t* status;         // [0] error code, [1] words consumed, [2..3] symbols decoded (lo, hi)
     int32_t ring_rows;       // rows of the decoded-symbol ring in LDS: power of two >= widest grid / 10 + 6
-    // Pipelined kernel, dynamic operand checks (ccd_entropy_pipe.hip, "exactness"): features are kept as int16 planes in
+    // Pipelined kernel, dynamic operand check (ccd_entropy_pipe.hip, "exactness"): features are kept as int16 planes in
     // `ifce_feat`; a feature with |f| >= 2^feat_bits is stored as the sentinel -32768 there and in full in `ifce_wide`
-    // (int32 planes of the same shape); a pixel that meets a sentinel, or a hidden activation >= 2^act_bits, is redone
-    // in plain int64.  15 / 31 in production; tests lower them to force the redo path on ordinary streams.
+    // (int32 planes of the same shape); a pixel that meets a sentinel is redone in plain int64.  15 in production; tests
+    // lower it (8..14) to force the redo path on ordinary streams.
     int32_t* ifce_wide;
-    int32_t feat_bits, act_bits;
+    int32_t feat_bits;
     int32_t ifce_w32;        // every IFCE weight fits int32: the register-resident feature pass may be used
     int32_t mfma;            // > 0: the ARM's layers run on the matrix cores (limb-split int8, ccd_entropy_pipe.hip); the value
                              // is the number of bits a hidden activation may have before the task is redone in int64 (23)

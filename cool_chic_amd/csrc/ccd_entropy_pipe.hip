@@ -1229,12 +1229,14 @@ __device__ __forceinline__ void mf_exact_task(const PipeCtx& C, int32_t* tile, i
 // ---- exactness of the 32-bit operands --------------------------------------------------------------------------------
 // The reference's ARM is wrapping int64 for any weights and data (armint.py:180-203).  The producers below multiply
 // int32 x int32 -> int64 (v_mad_i64_i32) and sum in wrapping int64: the same numbers whenever every OPERAND is exact in
-// 32 bits.  Weights: decided on the host (FixedArm::w32, else the slot runs ccd_entropy.hip).  Latents << 16: always.
-// IFCE features << 16 and hidden activations depend on the data: a feature with |f| >= 2^feat_bits is a sentinel in the
-// int16 plane (its value sits in the int32 side plane), an activation >= 2^act_bits shows in the high words the MLP ORs
-// together; one ballot per task, and a pixel that met either is redone here in plain 64 x 64 -> 64 arithmetic before its
-// table indices are published.  Never taken on the streams seen so far (features reach ~2^10, activations ~2^21); tests
-// lower the two limits to drive ordinary streams through it (EntropyParams::feat_bits / act_bits).
+// 32 bits.  Decided on the host from the weights alone (ccd_format.cpp; else the slot runs ccd_entropy.hip): every weight
+// fits int32, and no hidden activation can leave int32 even for worst-case inputs (every network seen so far has a margin
+// of >= 2^3 there).  Latents << 16: always exact.  IFCE features << 16 depend on the data - the worst case of a real
+// network exceeds 2^15 (three of the six networks the reference encoder produced in the build container), its features
+// reach ~2^10: a feature with |f| >= 2^feat_bits is a sentinel in the int16 plane and its value sits in the int32 side
+// plane; a task learns of a sentinel when it loads its features, before it waits for anything, and a pixel that met one
+// is redone here in plain 64 x 64 -> 64 arithmetic.  Never taken on the streams seen so far; tests lower feat_bits to
+// drive ordinary streams through it (EntropyParams::feat_bits).
 constexpr int16_t kFeatSentinel = -32768;
 
 // One pixel's ARM in plain wrapping int64, the whole wave on it: lane k holds input / activation k (dim <= 32), lane o
@@ -1319,8 +1321,6 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     const int q = MF ? (lane >> 4) : lane % kLpp;    // lane within the pixel's group (MF: K-slot group of the matrix operands)
     const int ring_mask = DYN_RING ? uni(C.ring_mask) : kRingRows - 1, n_if = uni(C.n_if), mf_bits = uni(P.mfma);
     (void)n_if; (void)mf_bits;
-    const uint32_t act_shift = static_cast<uint32_t>(uni(P.act_bits)) - 16u;  // activation a >> 16 >= 2^act_bits <=> (a >> 32) >> (act_bits - 16) != 0
-    (void)act_shift;
     const int4* act_row = reinterpret_cast<const int4*>(act + px * in_pad);
     // Per-lane constants of the gather: the lane always fetches inputs k = q + kLpp t.  Read through the parameter block
     // inside the task loop they were global loads on every task's path.
@@ -1390,11 +1390,12 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     if (!MF && px < cnt && k >= n_sp && k < dim && fin > 0)
                         fv[t] = ifce_feat[(k - n_sp) * feat_plane + (y >> 1) * fw + (x >> 1)];
                 }
-                // dynamic operand check (see exact_pixel): the hidden activations' high words are ORed into `act_hi` as they
-                // are produced
-                uint32_t act_hi = 0;  // bit 31 (never set by a non-negative activation): a sentinel among the lane's features
+                // dynamic operand check (see exact_pixel): a sentinel among the task's features.  Known BEFORE the waits, so the
+                // critical path only carries one scalar test of this mask.
+                bool feat_bad = false;
 #pragma unroll
-                for (int t = 0; t < NOUT; ++t) act_hi |= fv[t] == kFeatSentinel ? 0x80000000u : 0u;
+                for (int t = 0; t < NOUT; ++t) feat_bad |= fv[t] == kFeatSentinel;
+                const unsigned long long bad_lanes = MF ? 0ull : __ballot(feat_bad);
                 // ---- Two waits.  Of all contexts only the left neighbour (y, x - 1) lies in the previous step (pixel i of this
                 // step reads pixel i of that one, pixel i + 1 when the step start moved down a row in between); (y, x - 2) lies
                 // two steps back, everything else at least five.  So the task gathers every other input, runs the stabiliser and
@@ -1691,7 +1692,6 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         mad64(acc0[t], xleft, wleft[t]);
                         const int o = q + kLpp * t;
                         const int64_t a = acc0[t] < 0 ? 0 : acc0[t];
-                        act_hi |= static_cast<uint32_t>(a >> 32);
                         if (o < in_pad) act[px * in_pad + o] = o < dim ? static_cast<int32_t>(a >> 16) : 0;
                     }
 #pragma unroll
@@ -1725,7 +1725,6 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     for (int t = 0; t < NOUT; ++t) {
                         const int o = q + kLpp * t;
                         const int64_t a = acc[t] < 0 ? 0 : acc[t];
-                        act_hi |= static_cast<uint32_t>(a >> 32);
                         if (o < in_pad) act[px * in_pad + o] = o < dim ? static_cast<int32_t>(a >> 16) : 0;
                     }
 #pragma unroll
@@ -1736,7 +1735,6 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // output layer (q = 0: mu, q = 1: log-scale) -> table indices -> per-pixel table parameters
                 const int mpx = slot * kBpx + half * kTaskPix + px;  // table row of the pixel
                 int32_t idx = 0;
-                int64_t acc = 0;
                 if (q < 2) {
                     const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + q * in_pad);
                     int64_t ao[2] = {C.s_b[(n_layers - 1) * dim + q] + stab, 0};
@@ -1749,26 +1747,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         int64_t& a = ao[v & 1];
                         mad64(a, xv[v].x, w.x); mad64(a, xv[v].y, w.y); mad64(a, xv[v].z, w.z); mad64(a, xv[v].w, w.w);
                     }
-                    acc = ao[0] + ao[1];
-                }
-                // ---- an operand of some pixel was not exact in 32 bits (never on the streams seen so far): that pixel again,
-                // in plain int64, before anything of it is published
-                const unsigned long long bad_lanes = __ballot((act_hi >> act_shift) != 0u && px < cnt);
-                if (bad_lanes != 0ull) {
-                    int n_redo = 0;
-                    for (int p = 0; p < cnt; ++p) {
-                        if (((bad_lanes >> (p * kLpp)) & ((1ull << kLpp) - 1ull)) == 0ull) continue;
-                        ExactArgs A;
-                        A.P = C.P; A.s_w = C.s_w.off; A.s_b = C.s_b.off; A.s_ring = C.s_ring.off;
-                        A.n_w_hidden = C.n_w_hidden; A.dim = dim; A.n_layers = n_layers; A.n_sp = n_sp; A.in_pad = in_pad;
-                        A.W = W; A.fin = fin; A.fw = fw; A.feat_plane = feat_plane; A.ring_mask = ring_mask;
-                        const ExactOut r = exact_pixel(A, it.y0 + i0 + p, it.x0 - 10 * (i0 + p));
-                        if (px == p && q < 2) acc = q == 0 ? r.mu : r.ls;
-                        ++n_redo;
-                    }
-                    if (lane == 0) atomicAdd(reinterpret_cast<int*>(P.status) + 39, n_redo);  // status[39]: pixels redone (tests)
-                }
-                if (q < 2) {
+                    const int64_t acc = ao[0] + ao[1];
                     const int64_t q8 = acc >> 24;
                     const int64_t off = q8 + (q == 0 ? kMuOffset : kScaleOffset);
                     const int64_t hi = q == 0 ? kNumMu - 1 : kNumScale - 1;
@@ -1781,6 +1760,35 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                             meta.rcp[mpx] = C.s_rcp[idx];
                         }
                     }
+                }
+                // ---- a feature of some pixel was not exact in 16 bits (never on the streams seen so far): that pixel again,
+                // in plain int64; its table parameters replace what the lines above wrote from the sentinel
+                if (__builtin_expect(bad_lanes != 0ull, 0)) {
+                    int n_redo = 0;
+                    for (int p = 0; p < cnt; ++p) {
+                        if (((bad_lanes >> (p * kLpp)) & ((1ull << kLpp) - 1ull)) == 0ull) continue;
+                        // opaque copies: nothing derived from them is hoisted out of this cold block into the task loop
+                        ExactArgs A;
+                        A.P = C.P; A.s_w = uni(C.s_w.off); A.s_b = uni(C.s_b.off); A.s_ring = uni(C.s_ring.off);
+                        A.n_w_hidden = uni(C.n_w_hidden); A.dim = dim; A.n_layers = n_layers; A.n_sp = n_sp; A.in_pad = in_pad;
+                        A.W = W; A.fin = fin; A.fw = fw; A.feat_plane = feat_plane; A.ring_mask = ring_mask;
+                        asm volatile("" : "+s"(A.P), "+s"(A.s_w), "+s"(A.s_b), "+s"(A.s_ring), "+s"(A.n_w_hidden), "+s"(A.dim), "+s"(A.n_layers));
+                        asm volatile("" : "+s"(A.n_sp), "+s"(A.W), "+s"(A.fin), "+s"(A.fw), "+s"(A.feat_plane), "+s"(A.ring_mask));
+                        const ExactOut r = exact_pixel(A, it.y0 + i0 + p, it.x0 - 10 * (i0 + p));
+                        if (px == p && q < 2) {
+                            const int64_t off = ((q == 0 ? r.mu : r.ls) >> 24) + (q == 0 ? kMuOffset : kScaleOffset);
+                            const int64_t hi = q == 0 ? kNumMu - 1 : kNumScale - 1;
+                            idx = static_cast<int32_t>(off < 0 ? 0 : (off > hi ? hi : off));
+                            if (q == 0) {
+                                meta.mu_idx[mpx] = idx;
+                            } else {
+                                meta.b[mpx] = static_cast<double>(C.s_scale[idx]);
+                                meta.rcp[mpx] = C.s_rcp[idx];
+                            }
+                        }
+                        ++n_redo;
+                    }
+                    if (lane == 0) atomicAdd(reinterpret_cast<int*>(P.status) + 39, n_redo);  // status[39]: pixels redone (tests)
                 }
                 // bit (px * kLpp + 1) of the ballot: pixel px of the task takes a narrow window (wave-uniform, no LDS trip)
                 const unsigned long long narrow_lanes = __ballot(q == 1 && px < cnt && idx <= kNarrowMaxScale);

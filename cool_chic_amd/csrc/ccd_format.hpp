@@ -53,11 +53,11 @@ struct FixedArm {
     bool narrow = false;
     // The pipelined kernel's own, much wider envelope.  It multiplies int32 x int32 -> int64 and sums
     // in wrapping int64, which is the reference's arithmetic (armint.py:180-203, torch int64 wraps)
-    // whenever the OPERANDS are exact in 32 bits: weights (static, decided here), latents << 16
-    // (always), IFCE features << 16 and hidden activations (data dependent: checked per task on the
-    // device, the offending pixel is redone in plain int64).  w32: every ARM / stabiliser weight
-    // fits int32.  dyn_feat / dyn_act: the worst case of a feature / hidden activation does not fit
-    // 16 / 32 bits, i.e. the device checks can fire at all (they run regardless).
+    // whenever the OPERANDS are exact in 32 bits.  w32: every ARM / stabiliser weight fits int32.
+    // dyn_act: a hidden activation could leave int32 for worst-case inputs (no network seen so far;
+    // such a slot runs the generic kernel).  dyn_feat: the worst case of an IFCE feature does not
+    // fit 16 bits - informational, the device checks every feature it stores anyway and redoes the
+    // pixels that meet a wide one in plain int64.
     bool w32 = false, dyn_feat = false, dyn_act = false;
 };
 

@@ -154,10 +154,10 @@ int ccd_batch_slot_kernels(const ccd_batch* b, int slot);
  *                       MI355X the matrix-core variant is the slower one, it is kept as a measured
  *                       alternative.  Values 2..22 lower the activation width above which a task is redone in plain
  *                       int64 - normally 23 bits - so that tests reach that path.
- *   CCD_OPT_RANGE_BITS  0 (default): production limits of the pipelined entropy kernel's dynamic operand check (an IFCE feature
- *                       with |f| >= 2^15 or a hidden activation >= 2^31 sends its pixel through the int64 redo).  Tests pass
- *                       feat_bits | act_bits << 8 (8..15, 16..31) to lower the limits and drive ordinary streams through the
- *                       redo; results are identical bit for bit.  ccd_batch_slot_stats word [39] counts the redone pixels. */
+ *   CCD_OPT_RANGE_BITS  0 (default): production limit of the pipelined entropy kernel's dynamic operand check (an IFCE feature
+ *                       with |f| >= 2^15 sends its pixel through the int64 redo).  Tests pass 8..14 to lower the limit and
+ *                       drive ordinary streams through the redo; results are identical bit for bit.
+ *                       ccd_batch_slot_stats word [39] counts the redone pixels. */
 enum { CCD_OPT_FUSED_DEC = 1, CCD_OPT_KEEP_FLOAT = 2, CCD_OPT_MFMA_ARM = 3, CCD_OPT_RANGE_BITS = 4 };
 int ccd_batch_set_option(ccd_batch* b, int option, int value);
 
@@ -268,11 +268,12 @@ int ccd_compute_rate(int device, void* stream, const float* x, const float* mu, 
 int ccd_debug_laplace_bounds(int device, const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* s,
                              int64_t n, uint32_t* left, uint32_t* right);
 
-/* Host only: 1 when this cool-chic's ARM runs on the pipelined entropy kernel: every ARM / stabiliser weight fits int32, the
- * worst-case IFCE feature fits the kernel's int32 side plane (< 2^30), <= 32 ARM inputs, <= 8 layers, picture not wider than
- * the symbol ring (5 060).  What depends on the data - IFCE features and hidden activations as 32-bit operands - is checked
- * per task on the device and the pixel redone in plain int64 (never taken on any stream seen so far).  0 when it needs the
- * generic 64-bit kernel (~7x slower; no network the reference encoder produced does), < 0 on a malformed header / payload. */
+/* Host only: 1 when this cool-chic's ARM runs on the pipelined entropy kernel: every ARM / stabiliser weight fits int32, no
+ * hidden activation can leave int32 even for worst-case inputs, the worst-case IFCE feature fits the kernel's int32 side
+ * plane (< 2^30), <= 32 ARM inputs, <= 8 layers, picture not wider than the symbol ring (5 060).  What depends on the data -
+ * IFCE features as 16-bit operands - is checked per task on the device and the pixel redone in plain int64 (never taken on
+ * any stream seen so far).  0 when it needs the generic 64-bit kernel (~7x slower; no network the reference encoder produced
+ * does), < 0 on a malformed header / payload. */
 int ccd_network_fits_fast_path(const uint8_t* cc_header, size_t n_hdr, const uint8_t* bytes_nn, size_t n_nn);
 
 /* Profile builds only (-DCCD_FD_PROFILE): cycles per phase of the fused float kernel, summed over wave 0 of every

@@ -102,12 +102,13 @@ def test_mfma_arm_exact_redo(gpu, oracle, name, bits):
         b.close()
 
 
-@pytest.mark.parametrize("bits", [(8, 31), (15, 16), (8, 16), (12, 21)])
+@pytest.mark.parametrize("bits", [8, 9, 11])
 @pytest.mark.parametrize("name", ["kodim14", "rgb192", "yuv444_10b"])
 def test_dynamic_operand_redo(gpu, oracle, name, bits):
-    """The pipelined entropy kernel multiplies 32-bit operands; IFCE features and hidden activations that do not fit send
-    their pixel through an int64 redo (exact_pixel).  No real stream gets there (features reach ~2^10 of 2^15, activations
-    ~2^21 of 2^31), so the two limits are lowered until many / a few pixels do: the latents must not change.
+    """The pipelined entropy kernel multiplies 32-bit operands.  Weights and hidden activations are covered by the host's
+    analysis of the weights; IFCE features are checked on the device: one that does not fit int16 is a sentinel in the
+    feature plane and sends the pixels that read it through an int64 redo (exact_pixel).  No real stream gets there
+    (features reach ~2^10 of 2^15), so the limit is lowered until many / some / a few pixels do: the latents must not change.
     rgb192 and yuv444_10b are networks whose WORST-CASE feature exceeds 2^15 (the r02 static envelope sent them to the
     generic kernel)."""
     bs, z, j = load_golden(name)
@@ -117,8 +118,8 @@ def test_dynamic_operand_redo(gpu, oracle, name, bits):
         assert b.slot_kernels(0) & 1
         assert b.slot_status(0) == 0
         n_redo = int(b.slot_stats(0)[39])
-        if bits != (12, 21):
-            assert n_redo > 0, "the lowered limits must drive pixels through the redo"
+        if bits == 8:
+            assert n_redo > 0, "the lowered limit must drive pixels through the redo"
         for g in range(len([k for k in z.files if k.startswith("cc0.latent")])):
             assert np.array_equal(b.latent(0, g), z[f"cc0.latent{g}"]), f"grid {g} vs reference fixture ({n_redo} pixels redone)"
     finally:
