@@ -43,7 +43,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
-PROFILE_DIRS = ["profiles/r02", "profiles/r01"]
+PROFILE_DIRS = ["profiles/r03", "profiles/r02", "profiles/r01"]
 
 
 def build_kodak24(device: int = 0):
@@ -97,6 +97,47 @@ def wall_ms(fn, reps: int, device: int) -> float:
     return (time.perf_counter() - t0) / reps * 1e3
 
 
+HASHES_PATH = os.path.join(ROOT, "tests", "golden", "workload_hashes.json")
+_hashes = None
+
+
+def expected_hashes(name):
+    """Per stream of workload `name`: the sha256 of the integer planes the CPU oracle decodes from it (one per frame),
+    generated in the build container by tests/golden/gen/hash_workloads.py; None when the file is missing."""
+    global _hashes
+    if _hashes is None:
+        try:
+            with open(HASHES_PATH) as f:
+                _hashes = json.load(f)
+        except (OSError, ValueError):
+            _hashes = {}
+    return _hashes.get(name)
+
+
+def verify_frames(name, frames, stream_of=lambda i: i, video=False, streams=None):
+    """What was timed is what the oracle decodes: `frames` = [planes of frame i] (copied to the host AFTER the timed
+    region) hashed like tests/golden/gen/hash_workloads.py hashes the oracle's planes.  Image workloads: frame i is
+    stream stream_of(i); a video workload is one stream whose frames come in display order."""
+    import hashlib
+
+    from cool_chic_amd.synth import planes_sha256
+
+    exp = expected_hashes(name)
+    got = [planes_sha256(p) for p in frames]
+    out = {"frames_checked": len(got), "planes_sha256_of_set": hashlib.sha256("".join(got).encode()).hexdigest()[:32],
+           "against": "tests/golden/workload_hashes.json: integer planes of the CPU oracle for the same streams (hash_workloads.py)"}
+    if exp is None:
+        out.update({"ok": None, "note": "no expected hashes for this workload"})
+        return out
+    want = list(exp["planes_sha256"][0]) if video else [exp["planes_sha256"][stream_of(i)][0] for i in range(len(got))]
+    bad = [i for i in range(min(len(got), len(want))) if got[i] != want[i]]
+    out.update({"ok": not bad and len(got) == len(want), "mismatching_frames": bad[:8]})
+    if streams is not None:  # the inputs themselves are the ones the oracle saw
+        out["streams_identical"] = all(hashlib.sha256(st).hexdigest() == exp["streams_sha256"][0 if video else stream_of(i)]
+                                       for i, st in enumerate(streams))
+    return out
+
+
 def n_symbols(batch, n):
     return int(sum(batch.header(s).n_symbols for s in range(n)))
 
@@ -121,8 +162,9 @@ def image_leg(name, device, sh, stream, steps, cpu_budget, want_cpu):
     ms_float = event_ms(stream, lambda: (b.run(sh, stage=1), b.run(sh, stage=2)), max(1, steps // 2), device)
     b.wait(sh)
     nsym = n_symbols(b, len(triples))
+    verified = verify_frames(name, [b.planes(i) for i in range(len(triples))], streams=wl["streams"])
     b.close()
-    leg = {"frames": len(triples), "mpixels": sum(px) / 1e6, "value": sum(px) / ms / 1e3, "unit": "Mpixel/s", "n_gpus": 1, "steps": steps,
+    leg = {"frames": len(triples), "mpixels": sum(px) / 1e6, "verified": verified, "value": sum(px) / ms / 1e3, "unit": "Mpixel/s", "n_gpus": 1, "steps": steps,
            "ms_per_step": ms, "entropy_ms": ms_entropy, "float_ms": ms_float, "symbols": nsym,
            "entropy_msym_per_s": nsym / ms_entropy / 1e3, "largest_frame_mpx": max(px) / 1e6,
            "slots_on_generic_entropy_kernel": sum(1 for k in kernels if not k & 1),
@@ -178,7 +220,17 @@ def gop_leg(device, sh, stream, steps, cpu_budget, want_cpu):
 
     whole()
     ms_e2e = wall_ms(whole, max(1, steps // 2), device)
-    leg = {"frames": n_frames, "cool_chics": n_cc, "mpixels": px / 1e6, "value": px / ms_e2e / 1e3, "unit": "Mpixel/s", "n_gpus": 1,
+    # what ccd_decode_video returns, against the oracle's planes for the same stream
+    v = Video()
+    check(lib().ccd_decode_video(bs, len(bs), device, C.byref(v)), "ccd_decode_video")
+    frames_v = []
+    for i in range(v.n_frames):
+        f = v.frames[i]
+        shapes = [(f.h, f.w), (f.ch, f.cw), (f.ch, f.cw)]
+        frames_v.append([np.ctypeslib.as_array(f.plane[p], shape=shapes[p]).copy() for p in range(3)])
+    lib().ccd_video_free(C.byref(v))
+    verified = verify_frames("gop1080p33", frames_v, video=True, streams=[bs])
+    leg = {"frames": n_frames, "cool_chics": n_cc, "verified": verified, "mpixels": px / 1e6, "value": px / ms_e2e / 1e3, "unit": "Mpixel/s", "n_gpus": 1,
            "ms_per_step": ms_e2e, "what": "ccd_decode_video from the stream bytes: parse, upload, all cool-chics in one batch, "
            "reconstruction in coding order, integer planes back on the host",
            "resident_coolchics_ms": ms_cc, "resident_coolchics_mpx_per_s": px / ms_cc / 1e3, "entropy_ms": ms_entropy, "float_ms": ms_float,
@@ -201,16 +253,25 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--legs", default="all", help="comma list of clic41,gop1080p33,uhd4k,wide,png,e2e,float or all / none (rank 0, beside the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="N > 1: nccl = RCCL over xGMI (one GPU per rank); gloo = host-staged exchange, ranks may share a GPU "
+                         "(smoke run of the multi-rank path on a single-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X: there is no CPU fallback"
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()  # ranks may share a GPU: there is no device-to-device collective to collide
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group("gloo")
+    red_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"  # where the scalar reductions live
     all_legs = ["clic41", "gop1080p33", "uhd4k", "wide", "png", "e2e", "float"]
     legs = all_legs if args.legs == "all" else ([] if args.legs == "none" else args.legs.split(","))
     if world > 1 and args.legs == "all":
@@ -239,7 +300,7 @@ def main():
     planes = [torch.as_tensor(batch.plane_device(s, p), device=dev).reshape(-1) for s in range(n_frames) for p in range(3)]
     n_bytes = sum(int(p.numel()) * p.element_size() for p in planes)
     if world > 1:  # equal message sizes: pad to the largest share
-        t = torch.tensor([n_bytes], dtype=torch.int64, device=dev)
+        t = torch.tensor([n_bytes], dtype=torch.int64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         pad = int(t.item()) - n_bytes
         if pad:
@@ -248,10 +309,12 @@ def main():
     else:
         gatherer = None
 
+    gathered = [None]
+
     def step():
         batch.run(sh)
         if gatherer is not None:  # decoded integer planes of this rank's frames -> writer rank (RCCL over xGMI), inside the timed region
-            gatherer(planes)
+            gathered[0] = gatherer(planes)
 
     def fence():
         if world > 1:
@@ -268,13 +331,29 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     batch.wait(sh)
 
     res = None
     if rank == 0:
+        # ---- what was timed, against the CPU oracle (hashes of its integer planes for the same 24 streams): this rank's own
+        # frames from its batch, and - N > 1 - every rank's frames as they arrived in the gather of the last timed step
+        n_kodak = len(items)
+        own_index = (lambda k: (rank + k * world) % n_kodak) if args.scaling == "strong" else (lambda k: k % n_kodak)
+        verified = verify_frames("kodak24", [batch.planes(s) for s in range(n_frames)], stream_of=own_index,
+                                 streams=streams if args.scaling == "weak" else None)
+        if world > 1 and gathered[0] is not None:
+            fb = 3 * 512 * 768  # bytes of one frame's planes in a rank's message (all 8-bit 512 x 768 RGB)
+            frames_g, index_g = [], []
+            for r, msg in enumerate(gathered[0]):
+                host = msg.cpu().numpy()
+                n_r = len(shard_indices(copies * n_kodak, r, world)) if args.scaling == "strong" else n_kodak
+                for k in range(n_r):
+                    frames_g.append([host[k * fb + p * (fb // 3): k * fb + (p + 1) * (fb // 3)] for p in range(3)])
+                    index_g.append(((r + k * world) if args.scaling == "strong" else k) % n_kodak)
+            verified["gathered"] = verify_frames("kodak24", frames_g, stream_of=lambda i: index_g[i])
         # ---- per-stage timing with HIP events on the launch stream (roofline evidence); stage 1 (per-level upsampling) is
         # empty on the fused path
         stage_ms = {name: event_ms(stream, lambda st=st: batch.run(sh, stage=st), args.steps, local_rank)
@@ -333,6 +412,7 @@ def main():
             "parity": "integer stages bit-exact vs reference fixtures; float stages bit-exact vs CPU oracle; integer planes <=1 LSB on "
                       "<=2e-5 of samples vs the reference decoder's output = within the reference's own thread-count noise floor "
                       "(tests/test_gpu_parity.py)",
+            "verified": verified,
             "stage_ms_per_step": stage_ms,
             "slots_on_generic_entropy_kernel": sum(1 for k in kernels if not k & 1),
             "slots_on_unfused_float_path": sum(1 for k in kernels if not k & 4),
@@ -433,8 +513,9 @@ def main():
             n_wide = max(2, min(args.steps, 4))
             ms_w = wall_ms(lambda: wide.run(sh), n_wide, local_rank)
             wide.wait(sh)
+            wide_verified = verify_frames("kodak24", [wide.planes(s_) for s_ in range(8 * len(items))], stream_of=lambda i: i % len(items))
             res["more_frames_in_flight"] = {"frames_in_flight": 8 * len(items), "value": 8 * sum(h * w for *_, (h, w) in items) / ms_w / 1e3,
-                                            "unit": "Mpixel/s", "n_gpus": 1, "steps": n_wide, "ms_per_step": ms_w,
+                                            "unit": "Mpixel/s", "n_gpus": 1, "steps": n_wide, "ms_per_step": ms_w, "verified": wide_verified,
                                             "note": "kodak24 x 8 in one batch on rank 0: not the metric's configuration, shown for occupancy"}
             wide.close()
         # ---- the other BASELINE configurations, each on this one GPU

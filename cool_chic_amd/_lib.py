@@ -80,6 +80,7 @@ SIGNATURES = {
     "ccd_read_video_header": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(VideoHeader)]),
     "ccd_read_frame_header": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(FrameHeader)]),
     "ccd_read_cc_header": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(CCHeader)]),
+    "ccd_get_coding_structure": (C.c_int, [C.POINTER(VideoHeader), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "ccd_decode_coolchic": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_int]),
     "ccd_batch_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -130,6 +131,7 @@ SIGNATURES = {
     "ccd_png_finish": (C.c_int64, [C.c_void_p, C.c_void_p]),
     "ccd_png_pack_batch": (C.c_int, [C.c_void_p, C.POINTER(PngItem), C.c_int, C.c_void_p]),
     "ccd_png_finish_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "ccd_debug_laplace_sweep": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccd_debug_laplace_bounds": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                            C.c_void_p]),
 }

@@ -109,7 +109,8 @@ def decode_video(bitstream_path: str, decoded_path: Optional[str] = None, max_de
         # P / B frames: every cool-chic of every frame decodes in ONE batch (they do not depend on other frames,
         # decode.py:132-153); the frames are then reconstructed in coding order (ccd_decode_video does the same)
         start = time.time()
-        frames = _decode_gop(bitstream_bytes, max_decoding_order + 1, device, None, verbosity, sharded=False)
+        frames = _decode_gop(bitstream_bytes, max_decoding_order + 1, device, None, verbosity, sharded=False,
+                             structure=vh.get_coding_structure())
         print(f"Decoding {len(frames)} frame(s) time = {time.time() - start:6.2f} seconds.")
     # decode.py:84-89: one entry per display index of the sequence; frames beyond max_decoding_order stay None
     all_frames = {}
@@ -121,7 +122,7 @@ def decode_video(bitstream_path: str, decoded_path: Optional[str] = None, max_de
 
 
 def _decode_gop(rest: bytes, n_decode: int, device: int, group, verbosity: int = 0, collect: Optional[int] = 0,
-                sharded: bool = True) -> Dict[int, FrameData]:
+                sharded: bool = True, structure: Optional[list] = None) -> Dict[int, FrameData]:
     """The first `n_decode` frames (coding order) of the frame payload `rest`: {display index: FrameData}.
 
     With a process group, frame at coding index k belongs to rank k mod world_size: every rank decodes ALL cool-chics
@@ -146,6 +147,16 @@ def _decode_gop(rest: bytes, n_decode: int, device: int, group, verbosity: int =
     display = [fh.get_value("display_index") for fh, _ in parsed]
     if len(set(display)) != len(display):
         raise ValueError("two frames share a display index")
+    # decode.py:52-75: order and references are the VIDEO header's coding structure; the frame headers must agree with it
+    for k, (fh, _) in enumerate(parsed):
+        if structure is None:
+            break
+        want = structure[k]
+        if (fh.get_value("display_index"), fh.get_value("frame_type"), fh.get_value("index_references")) != \
+                (want["display_order"], want["frame_type"], want["index_references"]):
+            raise ValueError(f"frame {k} (coding order): header says {fh.get_value('frame_type')}{fh.get_value('display_index')} "
+                             f"refs {fh.get_value('index_references')}, the coding structure {want['frame_type']}{want['display_order']} "
+                             f"refs {want['index_references']}")
     coding_of_display = {d: k for k, d in enumerate(display)}
     references = []
     for k, (fh, _) in enumerate(parsed):
@@ -206,5 +217,5 @@ def decode_video_sharded(bitstream_path: str, device: int = 0, group=None, colle
         rest = f.read()
     vh = VideoHeader()
     rest = vh.read_header(rest)
-    frames = _decode_gop(rest, vh.get_value("n_frames"), device, group, collect=collect)
+    frames = _decode_gop(rest, vh.get_value("n_frames"), device, group, collect=collect, structure=vh.get_coding_structure())
     return {str(d): frames[d] for d in sorted(frames)}

@@ -45,6 +45,23 @@ class VideoHeader(_Header):
                 "p_pos": list(c.p_pos[: c.n_p_frames])}
 
 
+    def get_coding_structure(self):
+        """header.py:161 -> CodingStructure(n_frames, intra_pos, p_pos) (utils/codingstructure.py:226-436) through the C ABI:
+        the frames in CODING order as dicts {display_order, frame_type, index_references, depth}.  Raises ValueError where
+        the reference asserts (first frame not intra, last frame neither I nor P, a frame both I and P)."""
+        import numpy as np
+
+        n = self.c.n_frames
+        disp, typ, dep = (np.zeros(max(n, 1), dtype=np.int32) for _ in range(3))
+        refs = np.zeros((max(n, 1), 2), dtype=np.int32)
+        got = lib().ccd_get_coding_structure(C.byref(self.c), disp.ctypes.data, typ.ctypes.data, refs.ctypes.data, dep.ctypes.data)
+        if got < 0:
+            raise ValueError("the video header does not describe a coding structure the reference accepts "
+                             f"(n_frames={n}, intra_pos={self.get_value('intra_pos')}, p_pos={self.get_value('p_pos')})")
+        return [{"display_order": int(disp[k]), "frame_type": FRAME_TYPES[typ[k]], "index_references": [int(r) for r in refs[k] if r >= 0],
+                 "depth": int(dep[k])} for k in range(got)]
+
+
 class FrameHeader(_Header):
     _ctype = _lib.FrameHeader
     _reader = "ccd_read_frame_header"

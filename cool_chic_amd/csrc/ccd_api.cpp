@@ -22,6 +22,8 @@ bool entropy_pipe_supports(int dim, int n_layers, int narrow, int max_grid_w);
 hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, int mfma, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_laplace_bounds(const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* sym,
                                  const float* scale_table, int64_t n, uint32_t* left, uint32_t* right, hipStream_t stream);
+hipError_t launch_laplace_sweep_pipe(const float* scale_table, const double* rcp_table, int scale_first, int n_scales, uint32_t* out, hipStream_t stream);
+hipError_t launch_laplace_sweep_generic(const float* scale_table, int scale_first, int n_scales, uint32_t* out, hipStream_t stream);
 hipError_t launch_upsample_step(const UpsampleLevel* d_levels, const uint32_t* d_zmap, int n_z, int max_w, int max_h, hipStream_t stream);
 hipError_t launch_i8_to_f32(const int8_t* in, float* out, size_t n, hipStream_t stream);
 hipError_t launch_syn_layer(const float* in, const float* in2, const float* wt, const float* bias, float* out, int c_in,
@@ -175,6 +177,20 @@ int ccd_read_video_header(const uint8_t* p, size_t n, ccd_video_header* h) { ret
 int ccd_read_frame_header(const uint8_t* p, size_t n, ccd_frame_header* h) { return (p && h) ? read_frame_header(p, n, h) : CCD_ERR_ARG; }
 int ccd_read_cc_header(const uint8_t* p, size_t n, ccd_cc_header* h) { return (p && h) ? read_cc_header(p, n, h) : CCD_ERR_ARG; }
 
+int ccd_get_coding_structure(const ccd_video_header* h, int32_t* display_order, int32_t* frame_type, int32_t* refs, int32_t* depth) {
+    if (!h) return CCD_ERR_ARG;
+    std::vector<CodedFrame> cs;
+    const int rc = coding_structure(*h, cs);
+    if (rc < 0) return rc;
+    for (size_t i = 0; i < cs.size(); ++i) {
+        if (display_order) display_order[i] = cs[i].display_order;
+        if (frame_type) frame_type[i] = cs[i].frame_type;
+        if (refs) { refs[2 * i] = cs[i].n_refs > 0 ? cs[i].refs[0] : -1; refs[2 * i + 1] = cs[i].n_refs > 1 ? cs[i].refs[1] : -1; }
+        if (depth) depth[i] = cs[i].depth;
+    }
+    return static_cast<int>(cs.size());
+}
+
 void ccd_free(void* p) { std::free(p); }
 
 // -------------------------------------------------------------------------------------------------
@@ -248,9 +264,9 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     if (n_lat % 4) return CCD_ERR_VALUE;  // np.frombuffer(dtype=uint32) raises (rangecoder.py:81)
     // The header parses, but the reference cannot decode it: after ONE x2 nearest upsample + crop of the decoded stack its
     // torch.cat raises when consecutive grids differ by more than one level (latent and hyperlatent ranges that do not
-    // touch), and the transmitted grid count is the length of the size list (component/core/coolchic.py:170-185).  The
-    // entropy kernels index the coarser grid with (y >> 1, x >> 1): a larger gap would read past it.
-    if (h.n_latent_grids != h.n_grids) return CCD_ERR_VALUE;
+    // touch).  The entropy kernels index the coarser grid with (y >> 1, x >> 1): a larger gap would read past it.
+    // (The transmitted n_latent_grids is not checked: the reference recomputes the count from the resolutions and never
+    // reads the field, component/core/coolchic.py:170-185, header.py:354-377.)
     for (int g = 1; g < h.n_grids; ++g) {
         const bool same = h.grid_h[g] == h.grid_h[g - 1] && h.grid_w[g] == h.grid_w[g - 1];
         const bool half = h.grid_h[g] == (h.grid_h[g - 1] + 1) / 2 && h.grid_w[g] == (h.grid_w[g - 1] + 1) / 2;
@@ -914,6 +930,12 @@ const void* ccd_batch_plane(const ccd_batch* b, int slot, int plane, int* h, int
     return s.d_plane[plane];
 }
 
+// Results of a slot whose entropy stage reported an error (corrupt / truncated payload) are whatever the arena held: never
+// handed out.  (Status is known after ccd_batch_wait; before it the copy reflects the caller's own ordering.)
+static int slot_failed(const ccd_batch* b, int slot) {
+    return (b && slot >= 0 && slot < static_cast<int>(b->slots.size()) && b->slots[slot]->status < 0) ? b->slots[slot]->status : 0;
+}
+
 static int copy_out(ccd_batch* b, const void* src, void* dst, size_t bytes, void* stream) {
     if (!src || !dst) return CCD_ERR_ARG;
     HIP_TRY(hipSetDevice(b->device));
@@ -924,24 +946,28 @@ static int copy_out(ccd_batch* b, const void* src, void* dst, size_t bytes, void
 }
 
 int ccd_batch_copy_latent(ccd_batch* b, int slot, int grid, int8_t* host, void* stream) {
+    if (const int failed = slot_failed(b, slot)) return failed;
     const int8_t* p = ccd_batch_latent(b, slot, grid);
     if (!p) return CCD_ERR_ARG;
     const ccd_cc_header& h = b->slots[slot]->hdr;
     return copy_out(b, p, host, static_cast<size_t>(h.grid_h[grid]) * h.grid_w[grid], stream);
 }
 int ccd_batch_copy_plane(ccd_batch* b, int slot, int plane, void* host, void* stream) {
+    if (const int failed = slot_failed(b, slot)) return failed;
     int ph = 0, pw = 0;
     const void* p = ccd_batch_plane(b, slot, plane, &ph, &pw);
     if (!p) return CCD_ERR_ARG;
     return copy_out(b, p, host, static_cast<size_t>(ph) * pw * (b->slots[slot]->bitdepth == 8 ? 1 : 2), stream);
 }
 int ccd_batch_copy_output(ccd_batch* b, int slot, float* host, void* stream) {
+    if (const int failed = slot_failed(b, slot)) return failed;
     const float* p = ccd_batch_output(b, slot);
     if (!p) return CCD_ERR_ARG;
     const ccd_cc_header& h = b->slots[slot]->hdr;
     return copy_out(b, p, host, static_cast<size_t>(h.out_channels) * h.img_size[0] * h.img_size[1] * 4, stream);
 }
 int ccd_batch_copy_dense(ccd_batch* b, int slot, float* host, void* stream) {
+    if (const int failed = slot_failed(b, slot)) return failed;
     const float* p = ccd_batch_dense(b, slot);
     if (!p) return CCD_ERR_ARG;
     const Slot& s = *b->slots[slot];
@@ -1027,9 +1053,19 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
     // reconstruction then walks the frames in coding order (decode.py:67-81).
     std::vector<ccd_frame_header> fhs(n_frames);
     std::vector<int> first_slot(n_frames, 0);
+    // decode.py:52-75: the coding order and every frame's references come from the VIDEO header's coding structure; a frame
+    // header that says otherwise describes a stream the reference would decode differently (or not at all): rejected
+    std::vector<CodedFrame> cs;
+    rc = coding_structure(*vh, cs);
     for (int f = 0; f < n_frames && rc >= 0; ++f) {
         used = read_frame_header(bs + pos, n - pos, &fhs[f]);
         if (used < 0) { rc = used; break; }
+        {
+            const CodedFrame& want = cs[f];
+            bool same = fhs[f].display_index == want.display_order && fhs[f].frame_type == want.frame_type && fhs[f].n_refs == want.n_refs;
+            for (int k = 0; same && k < want.n_refs; ++k) same = fhs[f].index_references[k] == want.refs[k];
+            if (!same) { rc = CCD_ERR_VALUE; break; }
+        }
         pos += static_cast<size_t>(used);
         first_slot[f] = ccd_batch_size(b);
         const int n_cc = fhs[f].frame_type == 0 ? 1 : 2;  // residue (+ motion), decode.py:126-128
@@ -1161,6 +1197,24 @@ int ccd_debug_laplace_bounds(int device, const int32_t* mu_idx, const int32_t* s
     if (rc == CCD_OK && (hipMemcpy(left, d_l, nb, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(right, d_r, nb, hipMemcpyDeviceToHost) != hipSuccess))
         rc = CCD_ERR_HIP;
     (void)hipFree(d_mu); (void)hipFree(d_sc); (void)hipFree(d_s); (void)hipFree(d_l); (void)hipFree(d_r); (void)hipFree(d_tab);
+    return rc;
+}
+
+int ccd_debug_laplace_sweep(int device, int which, int scale_first, int n_scales, uint32_t* out) {
+    if (!out || scale_first < 0 || n_scales <= 0 || scale_first + n_scales > kNumScale || (which != 0 && which != 1)) return CCD_ERR_ARG;
+    ccd_batch* b = nullptr;  // owns the two Laplace-scale tables on the device
+    int rc = ccd_batch_create(device, &b);
+    if (rc < 0) return rc;
+    const size_t bytes = static_cast<size_t>(n_scales) * kNumMu * 127 * sizeof(uint32_t);
+    uint32_t* d_out = nullptr;
+    if (hipMalloc(&d_out, bytes) != hipSuccess) rc = CCD_ERR_NOMEM;
+    if (rc == CCD_OK) {
+        const hipError_t e = which == 0 ? launch_laplace_sweep_pipe(b->d_scale_table, b->d_rcp_table, scale_first, n_scales, d_out, nullptr)
+                                        : launch_laplace_sweep_generic(b->d_scale_table, scale_first, n_scales, d_out, nullptr);
+        if (e != hipSuccess || hipMemcpy(out, d_out, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = CCD_ERR_HIP;
+    }
+    if (d_out) (void)hipFree(d_out);
+    ccd_batch_destroy(b);
     return rc;
 }
 

@@ -284,4 +284,18 @@ hipError_t launch_laplace_bounds(const int32_t* mu_idx, const int32_t* scale_idx
     return hipGetLastError();
 }
 
+// the same sweep as launch_laplace_sweep_pipe (ccd_entropy_pipe.hip) for this kernel's laplace_left
+__global__ void laplace_sweep_generic_kernel(const float* scale_table, int scale_first, int n_scales, uint32_t* out) {
+    const int64_t n = static_cast<int64_t>(n_scales) * kNumMu * 127;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int s = static_cast<int>(i % 127) - 63;
+        const int64_t r = i / 127;
+        out[i] = laplace_left(static_cast<int>(r % kNumMu), scale_table[scale_first + static_cast<int>(r / kNumMu)], s);
+    }
+}
+hipError_t launch_laplace_sweep_generic(const float* scale_table, int scale_first, int n_scales, uint32_t* out, hipStream_t stream) {
+    hipLaunchKernelGGL(laplace_sweep_generic_kernel, dim3(256 * 16), dim3(256), 0, stream, scale_table, scale_first, n_scales, out);
+    return hipGetLastError();
+}
+
 }  // namespace ccd

@@ -2246,6 +2246,24 @@ static hipError_t launch_pipe_nv(const EntropyParams* d_slots, int n_slots, size
     return hipGetLastError();
 }
 
+// ---- debug: every left cumulative the producers can compute for a run of scale indices -------------------------------
+// out[(c - scale_first) * 32768 * 127 + mu_idx * 127 + (s + 63)] = window_left(mu, b, rcp, s) for s = -63 .. 63 (s = -64 is 0
+// and the right bound of s is the left bound of s + 1): 32768 x 2561 x 127 = 1.0658e10 values in all (tools/cdf_sweep.py).
+__global__ void laplace_sweep_pipe_kernel(const float* scale_table, const double* rcp_table, int scale_first, int n_scales, uint32_t* out) {
+    const int64_t n = static_cast<int64_t>(n_scales) * kNumMu * 127;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int s = static_cast<int>(i % 127) - 63;
+        const int64_t r = i / 127;
+        const int mu_idx = static_cast<int>(r % kNumMu), c = scale_first + static_cast<int>(r / kNumMu);
+        const double mu = -64.0 + static_cast<double>(mu_idx) * (1.0 / 256.0);
+        out[i] = window_left(mu, static_cast<double>(scale_table[c]), rcp_table[c], s);
+    }
+}
+hipError_t launch_laplace_sweep_pipe(const float* scale_table, const double* rcp_table, int scale_first, int n_scales, uint32_t* out, hipStream_t stream) {
+    hipLaunchKernelGGL(laplace_sweep_pipe_kernel, dim3(256 * 16), dim3(256), 0, stream, scale_table, rcp_table, scale_first, n_scales, out);
+    return hipGetLastError();
+}
+
 // All `n_slots` descriptors must share nv = ceil(dim / 4) and the mfma flag (the host groups the slots of a batch by both).
 hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, int mfma, size_t lds_bytes, hipStream_t stream) {
     if (n_slots <= 0) return hipSuccess;

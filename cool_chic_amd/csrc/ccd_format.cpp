@@ -170,6 +170,55 @@ int read_cc_header(const uint8_t* p, size_t n, ccd_cc_header* h) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Coding structure (utils/codingstructure.py:226-436): I frames at intra_pos, P frames at p_pos (each predicting
+// from the closest already placed frame before it), every remaining display index filled with hierarchical B frames:
+// scan for the first missing index, put a B frame in the MIDDLE of the gap it lies in (past + (future - past) / 2),
+// start over.  Coding order = order of creation.
+// ---------------------------------------------------------------------------------------------
+int coding_structure(const ccd_video_header& h, std::vector<CodedFrame>& out) {
+    out.clear();
+    const int n = h.n_frames;
+    if (n < 1 || h.n_intras < 1 || h.n_p_frames < 0) return CCD_ERR_VALUE;
+    std::vector<int> intra(h.intra_pos, h.intra_pos + h.n_intras), pp(h.p_pos, h.p_pos + h.n_p_frames);
+    std::sort(intra.begin(), intra.end());
+    std::sort(pp.begin(), pp.end());
+    // codingstructure.py:230-263: the asserts of __post_init__
+    if (intra.front() != 0) return CCD_ERR_VALUE;
+    if (intra.back() != n - 1 && (pp.empty() || pp.back() != n - 1)) return CCD_ERR_VALUE;
+    std::vector<int> slot(n, -1);  // display order -> index in `out`
+    auto place = [&](const CodedFrame& f) {
+        if (f.display_order < 0 || f.display_order >= n || slot[f.display_order] >= 0) return false;  // outside / twice (I and P)
+        slot[f.display_order] = static_cast<int>(out.size());
+        out.push_back(f);
+        return true;
+    };
+    auto past = [&](int d) { int r = -1; for (int i = d - 1; i >= 0 && r < 0; --i) if (slot[i] >= 0) r = i; return r; };
+    auto future = [&](int d) { int r = -1; for (int i = d + 1; i < n && r < 0; ++i) if (slot[i] >= 0) r = i; return r; };
+    for (int d : intra) {
+        CodedFrame f; f.display_order = d; f.frame_type = 0;
+        if (!place(f)) return CCD_ERR_VALUE;
+    }
+    for (int d : pp) {
+        CodedFrame f; f.display_order = d; f.frame_type = 1; f.n_refs = 1;
+        if (d < 0 || d >= n) return CCD_ERR_VALUE;
+        const int r = past(d);
+        if (r < 0) return CCD_ERR_VALUE;
+        f.refs[0] = r; f.depth = out[slot[r]].depth + 1;
+        if (!place(f)) return CCD_ERR_VALUE;
+    }
+    while (static_cast<int>(out.size()) < n) {
+        int i = 0;
+        while (i < n && slot[i] >= 0) ++i;
+        const int a = past(i), b = future(i);  // both exist: frames 0 and n - 1 are placed
+        if (a < 0 || b < 0) return CCD_ERR_VALUE;
+        CodedFrame f; f.display_order = a + (b - a) / 2; f.frame_type = 2; f.n_refs = 2; f.refs[0] = a; f.refs[1] = b;
+        f.depth = std::max(out[slot[a]].depth, out[slot[b]].depth) + 1;
+        if (!place(f)) return CCD_ERR_VALUE;
+    }
+    return CCD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Exp-Golomb payload
 // ---------------------------------------------------------------------------------------------
 int decode_exp_golomb(const uint8_t* p, size_t n, int n_pad_bits, const std::vector<int>& count,

@@ -33,6 +33,14 @@ private:
 };
 
 int read_video_header(const uint8_t* p, size_t n, ccd_video_header* h);
+
+// One frame of the coding structure a video header implies (utils/codingstructure.py:267-436): frames come in CODING order.
+struct CodedFrame {
+    int display_order = 0, frame_type = 0 /* 0 I, 1 P, 2 B */, n_refs = 0, refs[2] = {0, 0} /* display orders */, depth = 0;
+};
+// CodingStructure(n_frames, intra_pos, p_pos).frames sorted by coding order; CCD_ERR_VALUE where the reference asserts
+// (first frame not intra, last frame neither intra nor P, a frame both I and P) or cannot build the structure.
+int coding_structure(const ccd_video_header& h, std::vector<CodedFrame>& out);
 int read_frame_header(const uint8_t* p, size_t n, ccd_frame_header* h);
 int read_cc_header(const uint8_t* p, size_t n, ccd_cc_header* h);  // also fills the derived geometry
 

@@ -45,17 +45,23 @@ def gather_bytes(local: torch.Tensor, dst: int = 0, group=None) -> Optional[List
 
 class EqualSizeGather:
     """Gather of same-sized byte messages to `dst` with persistent buffers: no size exchange, no host synchronisation, no
-    per-call allocation (the steady-state path when every rank decodes frames of the same geometry)."""
+    per-call allocation (the steady-state path when every rank decodes frames of the same geometry).  With the "gloo"
+    backend (CPU tests, ranks sharing one GPU) the message is staged through pinned host memory: gloo gathers CPU tensors."""
 
     def __init__(self, n_bytes: int, device, dst: int = 0, group=None):
         self.dst, self.group = dst, group
         self.local = torch.empty(n_bytes, dtype=torch.uint8, device=device)
+        self.staged = dist.get_backend(group) == "gloo" and self.local.is_cuda
+        wire = torch.empty(n_bytes, dtype=torch.uint8, pin_memory=True) if self.staged else self.local
+        self.wire = wire
         world = dist.get_world_size(group)
-        self.bucket = [torch.empty_like(self.local) for _ in range(world)] if dist.get_rank(group) == dst else None
+        self.bucket = [torch.empty_like(wire) for _ in range(world)] if dist.get_rank(group) == dst else None
 
     def __call__(self, planes: Sequence[torch.Tensor]) -> Optional[List[torch.Tensor]]:
         torch.cat([p.contiguous().view(torch.uint8).reshape(-1) for p in planes], out=self.local)
-        dist.gather(self.local, self.bucket, dst=_global_rank(self.group, self.dst), group=self.group)
+        if self.staged:
+            self.wire.copy_(self.local)  # synchronous device -> host copy on the current stream
+        dist.gather(self.wire, self.bucket, dst=_global_rank(self.group, self.dst), group=self.group)
         return self.bucket
 
 

@@ -213,6 +213,17 @@ def gop1080p(intra_period: int = 32, size: Tuple[int, int] = (1080, 1920), i_fra
     return stream, info
 
 
+def planes_sha256(planes) -> str:
+    """sha256 over the integer planes of one frame in order (y u v / r g b), each as little-endian uint16 rows (8-bit planes
+    widened): the one definition shared by tests/golden/gen/hash_workloads.py (CPU oracle), bench.py and the GPU tests."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for p in planes:
+        h.update(np.ascontiguousarray(p, dtype="<u2").tobytes())
+    return h.hexdigest()
+
+
 def workload(name: str) -> Dict:
     """{"streams": [...], "sizes": [(H, W) per frame], "video": bool} for "kodak24" | "clic41" | "uhd4k" | "gop1080p33"."""
     if name == "kodak24":

@@ -100,6 +100,13 @@ int ccd_read_video_header(const uint8_t* p, size_t n, ccd_video_header* h);
 int ccd_read_frame_header(const uint8_t* p, size_t n, ccd_frame_header* h);
 int ccd_read_cc_header(const uint8_t* p, size_t n, ccd_cc_header* h);
 
+/* VideoHeader.get_coding_structure() (header.py:161 -> utils/codingstructure.py:226-436 CodingStructure.compute_coding_struct):
+ * the frames a video header implies, in CODING order.  Each array receives h->n_frames entries (refs: 2 per frame, display
+ * orders, -1 where unused; frame_type 0 I / 1 P / 2 B; depth as the reference counts it).  Returns n_frames, or
+ * CCD_ERR_VALUE where the reference asserts (first frame not intra, last frame neither intra nor P, a frame both I and P).
+ * ccd_decode_video decodes in this order and rejects a stream whose frame headers disagree with it. */
+int ccd_get_coding_structure(const ccd_video_header* h, int32_t* display_order, int32_t* frame_type, int32_t* refs, int32_t* depth);
+
 /* ---- one cool-chic: encode_decode_coolchic(mode="decode"), coolchic.py:29-207 ------------- */
 /* Decodes one cool-chic on `device` and writes the synthesis output [C][H][W] float32 (after the
  * final resize/crop, coolchic.py:187-192) to `out`, a device pointer if out_on_device else host.
@@ -267,6 +274,12 @@ int ccd_compute_rate(int device, void* stream, const float* x, const float* mu, 
  * left[i], right[i] as the entropy kernel sees them (exhaustive parity tests of the f64 CDF). */
 int ccd_debug_laplace_bounds(int device, const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* s,
                              int64_t n, uint32_t* left, uint32_t* right);
+
+/* Exhaustive form of the above (tools/cdf_sweep.py): the left cumulative of EVERY symbol s = -63 .. 63 for EVERY mu index and
+ * the scale indices [scale_first, scale_first + n_scales), computed on the GPU by the production kernel's table builder
+ * (which = 0: window_left, ccd_entropy_pipe.hip) or the generic kernel's (which = 1: laplace_left, ccd_entropy.hip).
+ * out (host) receives n_scales * 32768 * 127 words, [scale][mu_idx][s + 63]. */
+int ccd_debug_laplace_sweep(int device, int which, int scale_first, int n_scales, uint32_t* out);
 
 /* Host only: 1 when this cool-chic's ARM runs on the pipelined entropy kernel: every ARM / stabiliser weight fits int32, no
  * hidden activation can leave int32 even for worst-case inputs, the worst-case IFCE feature fits the kernel's int32 side

@@ -441,6 +441,24 @@ void ora_laplace_bounds(int mu_idx, int scale_idx, int s, uint32_t* left, uint32
                                     : (uint32_t)(free_w * laplace_cdf((double)s + 0.5, mu, b)) + slack + 1u;
 }
 
+/* Exhaustive check of a device's CDF (tools/cdf_sweep.py): dev[mu_idx * 127 + (s + 63)] must equal the left cumulative of
+ * every symbol s = -63 .. 63 under (mu_idx, scale_idx) as computed here with libm.  Returns the number of mismatches and
+ * records the first `cap` of them as (mu_idx, s, device value, libm value). */
+int64_t ora_laplace_lefts_check(int scale_idx, const uint32_t* dev, int64_t* bad, int cap) {
+    int64_t n_bad = 0;
+    for (int mu_idx = 0; mu_idx < 32768; ++mu_idx)
+        for (int s = AC_LO + 1; s <= AC_HI; ++s) {
+            uint32_t l;
+            ora_laplace_bounds(mu_idx, scale_idx, s, &l, NULL);
+            const uint32_t d = dev[(size_t)mu_idx * 127 + (size_t)(s - AC_LO - 1)];
+            if (d != l) {
+                if (n_bad < cap) { bad[4 * n_bad] = mu_idx; bad[4 * n_bad + 1] = s; bad[4 * n_bad + 2] = d; bad[4 * n_bad + 3] = l; }
+                ++n_bad;
+            }
+        }
+    return n_bad;
+}
+
 typedef struct {
     const uint8_t* bytes;
     size_t n_words, pos;

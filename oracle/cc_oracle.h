@@ -127,6 +127,8 @@ int ora_decode_exp_golomb(const uint8_t* p, size_t n, int n_pad, const int* coun
 /* ---- entropy model ---------------------------------------------------------------- */
 /* Leaky quantised Laplace (constriction 0.4.2): boundaries of symbol s. */
 void ora_laplace_bounds(int mu_idx, int scale_idx, int s, uint32_t* left, uint32_t* right);
+/* dev[mu_idx * 127 + (s + 63)], s = -63 .. 63, against libm for one scale index; mismatches -> bad[4 i ..] = (mu_idx, s, dev, libm) */
+int64_t ora_laplace_lefts_check(int scale_idx, const uint32_t* dev, int64_t* bad, int cap);
 float ora_scale_table(int idx);
 
 /* ---- one cool-chic: bitstream/component/coolchic.py:29-207 (mode="decode") ---------- */

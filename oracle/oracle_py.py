@@ -100,6 +100,8 @@ def lib():
                                             C.POINTER(C.c_int64)]
         L.ora_laplace_bounds.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.ora_laplace_bounds.restype = None
+        L.ora_laplace_lefts_check.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.ora_laplace_lefts_check.restype = C.c_int64
         L.ora_scale_table.argtypes = [C.c_int]
         L.ora_scale_table.restype = C.c_float
         L.ora_decode_coolchic.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t,
@@ -260,3 +262,13 @@ def rc_encode(symbols, mu_idx, scale_idx) -> bytes:
         return arr.tobytes()
     finally:
         L.ora_rc_encoder_free(e)
+
+
+def laplace_lefts_check(scale_idx: int, dev: np.ndarray, cap: int = 16):
+    """dev: uint32 [32768, 127] = a device's left cumulatives for every (mu_idx, s = -63 .. 63) at scale_idx.  Returns
+    (number of mismatches against libm, first mismatches as rows (mu_idx, s, device, libm)).  Releases the GIL."""
+    L = lib()
+    assert dev.dtype == np.uint32 and dev.shape == (32768, 127) and dev.flags.c_contiguous
+    bad = np.zeros((cap, 4), dtype=np.int64)
+    n = int(L.ora_laplace_lefts_check(int(scale_idx), dev.ctypes.data, bad.ctypes.data, cap))
+    return n, bad[:min(n, cap)]

@@ -260,3 +260,60 @@ def test_every_reference_network_fits_the_pipelined_kernel(oracle, name):
             assert writer.fits_fast_path(hdr, nn), f"{name}: cool-chic {n}"
             n += 1
     assert n == (9 if name == "vid5" else 1)
+
+
+def test_coding_structure_matches_reference():
+    """ccd_get_coding_structure (ccd_format.cpp::coding_structure) against what the reference's CodingStructure builds
+    (utils/codingstructure.py:267-436; dumped by tests/golden/gen/dump_coding_structures.py): coding order, frame types,
+    references and depths for ten (n_frames, intra_pos, p_pos) cases incl. the 33-frame GOP of BASELINE configs[3], the
+    reference-encoded 5-frame fixture and the docstring's "peculiar" structure."""
+    import json
+
+    from cool_chic_amd import writer
+    from cool_chic_amd.bitstream.header import VideoHeader
+
+    with open(os.path.join(ROOT, "tests", "golden", "coding_structures.json")) as f:
+        cases = json.load(f)
+    assert "gop33" in cases and "vid5" in cases
+    for name, c in cases.items():
+        vh = VideoHeader()
+        vh.read_header(writer.video_header_bytes(c["n_frames"], c["intra_pos"], c["p_pos"]))
+        assert vh.get_coding_structure() == c["coding_order"], name
+    # where the reference asserts (codingstructure.py:230-263)
+    for n, intra, p in ((4, [1, 3], []), (4, [0], []), (4, [0], [2]), (5, [0, 4], [4])):
+        vh = VideoHeader()
+        vh.read_header(writer.video_header_bytes(n, intra, p))
+        with pytest.raises(ValueError):
+            vh.get_coding_structure()
+
+
+def test_fixture_frame_headers_follow_the_coding_structure(oracle):
+    """The frame headers of the reference-encoded video agree with the structure its video header implies - the property
+    ccd_decode_video / decode_video now enforce."""
+    from cool_chic_amd.bitstream.header import VideoHeader
+
+    bs, z, j = load_golden("vid5")
+    vh = VideoHeader()
+    vh.read_header(bs)
+    cs = vh.get_coding_structure()
+    _, frames = oracle.split_stream(bs)
+    assert [(f["display_order"], "IPB".index(f["frame_type"]), f["index_references"]) for f in cs] == \
+           [(fh.display_index, fh.frame_type, list(fh.index_references[: fh.n_refs])) for fh, _ in frames]
+
+
+@pytest.mark.parametrize("bitdepth", [8, 10, 16])
+def test_ppm_writer_matches_reference(tmp_path, bitdepth):
+    """save_frame_data_to_file(.ppm) (io/io.py:84-90 -> io/format/ppm.py:161-203: "P6\\nW H\\nmax\\n", interleaved RGB,
+    two-byte samples MSB first above 8 bits) against the bytes the reference wrote for the same FrameData
+    (tests/golden/gen/dump_ppm.py): ranges' ends, 255 / 256 / 257 around the byte boundary, random samples."""
+    import torch
+
+    from cool_chic_amd.io import FrameData, save_frame_data_to_file
+
+    planes = np.load(os.path.join(ROOT, "tests", "golden", "ppm_planes.npz"))[f"ppm{bitdepth}"]
+    data = torch.from_numpy(planes.astype(np.float32) / np.float32(2 ** bitdepth - 1))[None]
+    out = tmp_path / "x.ppm"
+    save_frame_data_to_file(FrameData(bitdepth, "rgb", data), str(out))
+    with open(os.path.join(ROOT, "tests", "golden", f"ppm{bitdepth}.ppm"), "rb") as f:
+        want = f.read()
+    assert out.read_bytes() == want
