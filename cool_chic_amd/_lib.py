@@ -95,6 +95,9 @@ SIGNATURES = {
     "ccd_batch_slot_status": (C.c_int, [C.c_void_p, C.c_int]),
     "ccd_batch_slot_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "ccd_batch_slot_kernels": (C.c_int, [C.c_void_p, C.c_int]),
+    "ccd_batch_planes_layout": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "ccd_batch_copy_planes_async": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
+    "ccd_pool_trim": (None, [C.c_int]),
     "ccd_network_fits_fast_path": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "ccd_debug_fd_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ccd_batch_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),

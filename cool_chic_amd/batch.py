@@ -136,6 +136,35 @@ class DecodeBatch:
             res.append(out)
         return res
 
+    def all_planes(self, stream: int = 0) -> List[List[np.ndarray]]:
+        """Integer planes of EVERY slot on the host: one device -> host copy per slot (its three planes are one block) into
+        one pinned buffer, one wait - the writer's path for an image set.  Returns [slot][plane] numpy views of that buffer."""
+        import torch
+
+        n = len(self._meta)
+        total, off = C.c_size_t(), (C.c_size_t * 3)()
+        layout, base = [], 0
+        for s in range(n):
+            check(lib().ccd_batch_planes_layout(self._h, s, C.byref(total), off), "ccd_batch_planes_layout")
+            layout.append((base, [off[0], off[1], off[2]]))
+            base += total.value
+        host = torch.empty(base, dtype=torch.uint8, pin_memory=True)  # torch caches pinned blocks: no page-locking per call
+        ptrs = (C.c_void_p * n)(*[host.data_ptr() + b0 for b0, _ in layout])
+        st = C.c_void_p(stream or None)
+        check(lib().ccd_batch_copy_planes_async(self._h, 0, n, ptrs, st), "ccd_batch_copy_planes_async")
+        check(lib().ccd_batch_wait(self._h, st), "ccd_batch_wait")
+        arr = host.numpy()
+        out = []
+        for s, (b0, offs) in enumerate(layout):
+            bd, _ = self._meta[s]
+            dt = np.uint8 if bd == 8 else np.uint16
+            planes = []
+            for p in range(3):
+                h, w = self.plane_shape(s, p)
+                planes.append(arr[b0 + offs[p]: b0 + offs[p] + h * w * dt().itemsize].view(dt).reshape(h, w))
+            out.append(planes)
+        return out
+
     def output_device(self, slot: int) -> _DevArray:
         h = self.header(slot)
         ptr = lib().ccd_batch_output(self._h, slot)

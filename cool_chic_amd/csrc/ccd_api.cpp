@@ -4,7 +4,9 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -50,6 +52,7 @@ hipError_t launch_inter_recon(int frame_type, int h, int w, int n_taps, const in
                               const float* ref0, const float* ref1, float* out, hipStream_t stream);
 hipError_t launch_planes(const float* src, void* p0, void* p1, void* p2, int h, int w, int bitdepth, int frame_data_type,
                          hipStream_t stream);
+hipError_t launch_widen_u8(const uint8_t* in, uint16_t* out, size_t n, hipStream_t stream);
 
 static const uint32_t kScaleBits[kNumScale] = {
 #include "../../include/ccd_scale_table.inc"
@@ -66,19 +69,119 @@ using namespace ccd;
 
 namespace {
 
-// Bump allocator over one hipMalloc: every slot's buffers live in a single arena.
+// Process-wide caches of device blocks and pinned host blocks, per device: a batch is created, filled, run and destroyed
+// per image set, and hipMalloc / hipFree / hipHostMalloc of its arenas were a fifth of the time from bytes to planes
+// (24 hipFree = 4.4 ms per Kodak set; 64 arenas of 50-100 MB per 1080p GOP).  Blocks are handed out in size classes
+// (power of two up to 1 MB, then eighths of a power of two: <= 12.5 % slack) and come back on destroy; the cache is capped
+// (CCD_POOL_MAX_MB, default 32768; CCD_PINNED_POOL_MAX_MB, default 4096) - beyond the cap a block is really freed.
+// ccd_pool_trim() empties the caches.  The current device must be the block's device (callers hipSetDevice first).
+class BlockPool {
+public:
+    enum Kind { kDevice = 0, kPinned = 1 };
+    static size_t size_class(size_t bytes) {
+        if (bytes <= 4096) return 4096;
+        size_t p2 = 4096;
+        while (p2 < bytes) p2 <<= 1;
+        if (p2 <= (size_t{1} << 20)) return p2;
+        const size_t step = p2 >> 4;  // eighths of the power of two below
+        return (bytes + step - 1) / step * step;
+    }
+    void* acquire(int device, Kind kind, size_t bytes, size_t* got) {
+        const size_t cls = size_class(bytes);
+        *got = cls;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            auto& fl = free_[key(device, kind)];
+            auto it = fl.find(cls);
+            if (it != fl.end()) {
+                void* p = it->second;
+                fl.erase(it);
+                cached_[kind] -= cls;
+                return p;
+            }
+        }
+        void* p = nullptr;
+        const hipError_t e = kind == kDevice ? hipMalloc(&p, cls) : hipHostMalloc(&p, cls, hipHostMallocDefault);
+        if (e != hipSuccess) {  // out of memory with blocks of other classes cached: give them back and retry once
+            (void)hipGetLastError();
+            trim(device);
+            if ((kind == kDevice ? hipMalloc(&p, cls) : hipHostMalloc(&p, cls, hipHostMallocDefault)) != hipSuccess) return nullptr;
+        }
+        return p;
+    }
+    void release(int device, Kind kind, void* p, size_t cls) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            if (cached_[kind] + cls <= cap(kind)) {
+                free_[key(device, kind)].emplace(cls, p);
+                cached_[kind] += cls;
+                return;
+            }
+        }
+        if (kind == kDevice) (void)hipFree(p); else (void)hipHostFree(p);
+    }
+    void trim(int device) {
+        std::vector<std::pair<Kind, void*>> drop;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            for (int k = 0; k < 2; ++k) {
+                auto& fl = free_[key(device, static_cast<Kind>(k))];
+                for (auto& e : fl) { drop.emplace_back(static_cast<Kind>(k), e.second); cached_[k] -= e.first; }
+                fl.clear();
+            }
+        }
+        for (auto& d : drop) { if (d.first == kDevice) (void)hipFree(d.second); else (void)hipHostFree(d.second); }
+    }
+private:
+    static int key(int device, Kind kind) { return device * 2 + kind; }
+    static size_t cap(Kind kind) {
+        static const size_t caps[2] = {env_mb("CCD_POOL_MAX_MB", 32768), env_mb("CCD_PINNED_POOL_MAX_MB", 4096)};
+        return caps[kind];
+    }
+    static size_t env_mb(const char* name, size_t dflt) {
+        const char* e = std::getenv(name);
+        return (e ? static_cast<size_t>(std::strtoull(e, nullptr, 10)) : dflt) << 20;
+    }
+    std::mutex mu_;
+    std::map<int, std::multimap<size_t, void*>> free_;
+    size_t cached_[2] = {0, 0};
+};
+BlockPool& pool() { static BlockPool p; return p; }
+
+// A block from the pool with its class size (what release() needs).
+struct Block {
+    void* p = nullptr;
+    size_t cls = 0;
+    int device = 0;
+    BlockPool::Kind kind = BlockPool::kDevice;
+    bool get(int dev, BlockPool::Kind k, size_t bytes) { drop(); device = dev; kind = k; p = pool().acquire(dev, k, bytes, &cls); return p != nullptr; }
+    void drop() { if (p) pool().release(device, kind, p, cls); p = nullptr; cls = 0; }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+// Per device, for the life of the process: the two Laplace-scale tables and the stream uploads run on (so that parsing
+// slot k + 1 on the host overlaps the copy of slot k, and nothing waits for the caller's stream).
+struct DeviceShared {
+    float* d_scale_table = nullptr;
+    double* d_rcp_table = nullptr;
+    hipStream_t up_stream = nullptr;
+};
+int device_shared(int device, DeviceShared** out);
+
+// Bump allocator over one pooled device block: every slot's buffers live in a single arena.
 class Arena {
 public:
     size_t reserve(size_t bytes) { size_t off = total_; total_ += (bytes + 255) & ~size_t{255}; return off; }
-    int commit() {
+    int commit(int device) {
         if (total_ == 0) total_ = 256;
-        return hipMalloc(&base_, total_) == hipSuccess ? CCD_OK : CCD_ERR_NOMEM;
+        return blk_.get(device, BlockPool::kDevice, total_) ? CCD_OK : CCD_ERR_NOMEM;
     }
-    template <typename T> T* at(size_t off) const { return reinterpret_cast<T*>(static_cast<char*>(base_) + off); }
-    void release() { if (base_) (void)hipFree(base_); base_ = nullptr; }
+    template <typename T> T* at(size_t off) const { return reinterpret_cast<T*>(blk_.as<char>() + off); }
+    void release() { blk_.drop(); }
     size_t total() const { return total_; }
 private:
-    void* base_ = nullptr;
+    Block blk_;
     size_t total_ = 0;
 };
 
@@ -112,6 +215,8 @@ struct Slot {
     float* d_out = nullptr;      // [C][H][W] (== d_syn_out when no resize)
     void* d_plane[3] = {nullptr, nullptr, nullptr};
     int plane_h[3] = {0, 0, 0}, plane_w[3] = {0, 0, 0};
+    size_t plane_off[3] = {0, 0, 0}, planes_bytes = 0;  // the three planes sit in ONE block of the arena (one copy moves them)
+    Block staging;           // pinned host copy of the arena's head (status, payload, networks) for the asynchronous upload
     int32_t* d_status = nullptr;
     bool use_pipe = false;   // pipelined entropy kernel (32-bit operands) or the generic one
     bool use_mfma = false;   // ... with the ARM's layers on the matrix cores (limb-split int8)
@@ -128,6 +233,15 @@ struct ccd_batch {
     std::vector<std::unique_ptr<Slot>> slots;
     EntropyParams* d_params = nullptr;   // [pipe slots..., generic slots...]
     int n_params_uploaded = 0;
+    // every table the launches read (entropy descriptors, fused-kernel frames and work lists, pyramid steps) and the status
+    // words of all slots live in ONE pooled device block, staged through ONE pinned block: one copy up, one copy down
+    Block tables, tables_staging, status_host;
+    int32_t* d_status_all = nullptr;     // [slots][64]
+    hipEvent_t up_done = nullptr;        // recorded on the upload stream behind the last ccd_batch_add
+    hipStream_t up_stream = nullptr;     // the device's shared upload stream
+    hipStream_t last_stream = nullptr;   // the stream of the last ccd_batch_run_stage (drained before the arenas are recycled)
+    bool last_stream_valid = false;
+    bool uploads_unconfirmed = false;    // slots were added since the last ccd_batch_wait: launches order themselves behind up_done
     int n_pipe = 0, n_generic = 0;
     struct PipeGroup { int nv, mfma, first, n; size_t lds; };
     std::vector<PipeGroup> pipe_groups;
@@ -196,33 +310,58 @@ void ccd_free(void* p) { std::free(p); }
 // -------------------------------------------------------------------------------------------------
 // Batch
 // -------------------------------------------------------------------------------------------------
-int ccd_batch_create(int device, ccd_batch** out) {
-    if (!out) return CCD_ERR_ARG;
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return CCD_ERR_HIP;
-    HIP_TRY(hipSetDevice(device));
-    ccd_batch* b = new (std::nothrow) ccd_batch();
-    if (!b) return CCD_ERR_NOMEM;
-    b->device = device;
-    if (const char* e = std::getenv("CCD_FORCE_GENERIC")) b->force_generic = std::atoi(e);
-    if (const char* e = std::getenv("CCD_FUSED_DEC")) b->opt_fused_dec = std::atoi(e);
-    if (const char* e = std::getenv("CCD_MFMA_ARM")) b->opt_mfma_arm = std::atoi(e);
-    if (hipMalloc(&b->d_scale_table, sizeof(kScaleBits)) != hipSuccess) { delete b; return CCD_ERR_NOMEM; }
-    if (hipMemcpy(b->d_scale_table, kScaleBits, sizeof(kScaleBits), hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(b->d_scale_table); delete b; return CCD_ERR_HIP;
-    }
-    {
+namespace {
+std::mutex g_shared_mu;
+std::map<int, DeviceShared> g_shared;
+
+int device_shared(int device, DeviceShared** out) {
+    std::lock_guard<std::mutex> lock(g_shared_mu);
+    DeviceShared& d = g_shared[device];
+    if (!d.up_stream) {
+        float* st = nullptr;
+        double* rt = nullptr;
+        hipStream_t us = nullptr;
         std::vector<double> rcp(kNumScale);
         for (int i = 0; i < kNumScale; ++i) {
             float f;
             std::memcpy(&f, &kScaleBits[i], 4);
             rcp[i] = 1.0 / static_cast<double>(f);  // IEEE division on the host: correctly rounded
         }
-        if (hipMalloc(&b->d_rcp_table, sizeof(double) * kNumScale) != hipSuccess ||
-            hipMemcpy(b->d_rcp_table, rcp.data(), sizeof(double) * kNumScale, hipMemcpyHostToDevice) != hipSuccess) {
-            (void)hipFree(b->d_scale_table); if (b->d_rcp_table) (void)hipFree(b->d_rcp_table); delete b; return CCD_ERR_HIP;
+        if (hipMalloc(&st, sizeof(kScaleBits)) != hipSuccess || hipMalloc(&rt, sizeof(double) * kNumScale) != hipSuccess) {
+            if (st) (void)hipFree(st);
+            return CCD_ERR_NOMEM;
         }
+        if (hipMemcpy(st, kScaleBits, sizeof(kScaleBits), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(rt, rcp.data(), sizeof(double) * kNumScale, hipMemcpyHostToDevice) != hipSuccess ||
+            hipStreamCreateWithFlags(&us, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipFree(st); (void)hipFree(rt);
+            return CCD_ERR_HIP;
+        }
+        d.d_scale_table = st; d.d_rcp_table = rt; d.up_stream = us;
     }
+    *out = &d;
+    return CCD_OK;
+}
+}  // namespace
+
+int ccd_batch_create(int device, ccd_batch** out) {
+    if (!out) return CCD_ERR_ARG;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return CCD_ERR_HIP;
+    HIP_TRY(hipSetDevice(device));
+    DeviceShared* sh = nullptr;
+    const int rc = device_shared(device, &sh);
+    if (rc < 0) return rc;
+    ccd_batch* b = new (std::nothrow) ccd_batch();
+    if (!b) return CCD_ERR_NOMEM;
+    b->device = device;
+    if (const char* e = std::getenv("CCD_FORCE_GENERIC")) b->force_generic = std::atoi(e);
+    if (const char* e = std::getenv("CCD_FUSED_DEC")) b->opt_fused_dec = std::atoi(e);
+    if (const char* e = std::getenv("CCD_MFMA_ARM")) b->opt_mfma_arm = std::atoi(e);
+    b->d_scale_table = sh->d_scale_table;
+    b->d_rcp_table = sh->d_rcp_table;
+    b->up_stream = sh->up_stream;
+    if (hipEventCreateWithFlags(&b->up_done, hipEventDisableTiming) != hipSuccess) { delete b; return CCD_ERR_HIP; }
     *out = b;
     return CCD_OK;
 }
@@ -230,16 +369,18 @@ int ccd_batch_create(int device, ccd_batch** out) {
 void ccd_batch_destroy(ccd_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
-    for (auto& s : b->slots) s->arena.release();
-    if (b->d_params) (void)hipFree(b->d_params);
-    if (b->d_fused) (void)hipFree(b->d_fused);
-    if (b->d_fdec) (void)hipFree(b->d_fdec);
-    if (b->d_fdec_work) (void)hipFree(b->d_fdec_work);
-    if (b->d_levels) (void)hipFree(b->d_levels);
-    if (b->d_zmap) (void)hipFree(b->d_zmap);
-    if (b->d_scale_table) (void)hipFree(b->d_scale_table);
-    if (b->d_rcp_table) (void)hipFree(b->d_rcp_table);
+    // blocks go back to the pool for the next batch: nothing of this one may still be in flight
+    if (b->up_done) { (void)hipEventSynchronize(b->up_done); (void)hipEventDestroy(b->up_done); }
+    if (b->last_stream_valid) (void)hipStreamSynchronize(b->last_stream);
+    for (auto& s : b->slots) { s->arena.release(); s->staging.drop(); }
+    b->tables.drop(); b->tables_staging.drop(); b->status_host.drop();
     delete b;
+}
+
+void ccd_pool_trim(int device) {
+    if (hipSetDevice(device) != hipSuccess) return;
+    (void)hipDeviceSynchronize();
+    pool().trim(device);
 }
 
 int ccd_batch_size(const ccd_batch* b) { return b ? static_cast<int>(b->slots.size()) : CCD_ERR_ARG; }
@@ -324,40 +465,34 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     if (bitdepth != 0 && h.out_channels < 3) return CCD_ERR_ARG;
 
     // ---- arena layout --------------------------------------------------------------------------------
+    // The head of the arena - status block, payload words, integer networks, synthesis parameters - is what the host
+    // uploads: contiguous, staged in one pinned block, moved by ONE asynchronous copy (zeros included: the status words and
+    // the two payload words the decoder may read past the end).  Everything behind it is written by kernels before it is read.
     Arena& A = s.arena;
     const size_t n_words = n_lat / 4;
+    const size_t o_status = A.reserve(512);
     const size_t o_words = A.reserve((n_words + 2) * 4);
     const size_t o_arm = A.reserve(arm_blob.size() * 8);
     const size_t o_ifce = A.reserve(std::max<size_t>(ifce_blob.size(), 1) * 8);
-    std::vector<size_t> o_lat(h.n_grids);
     size_t feat_px = 1;
-    for (int g = 0; g < h.n_grids; ++g) {
-        o_lat[g] = A.reserve(static_cast<size_t>(h.grid_h[g]) * h.grid_w[g]);
+    for (int g = 0; g < h.n_grids; ++g)
         if (h.input_features_ifce[g] > 0) {
             const int fg = (g == h.n_grids - 1) ? g : g + 1;
             feat_px = std::max(feat_px, static_cast<size_t>(h.grid_h[fg]) * h.grid_w[fg]);
         }
-    }
-    // int32 planes (generic kernel) or int16 planes + int32 side planes in the second half (pipelined kernel)
-    const size_t feat_elems = feat_px * std::max(h.output_feature_ifce, 1);
-    const size_t o_feat = A.reserve(feat_elems * 8);
-    const size_t o_status = A.reserve(512);
     const size_t dense_elems = static_cast<size_t>(s.dense_c) * s.dense_h * s.dense_w;
-    size_t o_noise = 0, o_nstack[2] = {0, 0};
+    size_t n_noise = 0, nstack_elems[2] = {1, 1};
     if (s.cr) {
-        size_t n_noise = 0;
         for (int i = 0; i < n_levels; ++i) {
             s.lvl_h.push_back(h.grid_h[lat_grids[i]]); s.lvl_w.push_back(h.grid_w[lat_grids[i]]);
             s.noise_off.push_back(n_noise);
             n_noise += static_cast<size_t>(s.lvl_h[i]) * s.lvl_w[i];
         }
         s.noise_off.push_back(n_noise);
-        o_noise = A.reserve(n_noise * 4);
         // intermediate stacks: level 1 holds n_levels-1 planes, level 2 n_levels-2 planes (the finest goes to dense)
         for (int k = 0; k < 2; ++k) {
             const int lv = k + 1;
-            const size_t elems = lv < n_levels ? static_cast<size_t>(n_levels - lv) * s.lvl_h[lv] * s.lvl_w[lv] : 1;
-            o_nstack[k] = A.reserve(elems * 4);
+            nstack_elems[k] = lv < n_levels ? static_cast<size_t>(n_levels - lv) * s.lvl_h[lv] * s.lvl_w[lv] : 1;
         }
     }
     size_t stack_b_elems = 1;
@@ -500,6 +635,17 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
         }
     }
     const size_t o_synp = A.reserve(syn_blob.size() * 4);
+    const size_t head_bytes = A.total();
+    std::vector<size_t> o_lat(h.n_grids);
+    for (int g = 0; g < h.n_grids; ++g) o_lat[g] = A.reserve(static_cast<size_t>(h.grid_h[g]) * h.grid_w[g]);
+    // int32 planes (generic kernel) or int16 planes + int32 side planes in the second half (pipelined kernel)
+    const size_t feat_elems = feat_px * std::max(h.output_feature_ifce, 1);
+    const size_t o_feat = A.reserve(feat_elems * 8);
+    size_t o_noise = 0, o_nstack[2] = {0, 0};
+    if (s.cr) {
+        o_noise = A.reserve(n_noise * 4);
+        for (int k = 0; k < 2; ++k) o_nstack[k] = A.reserve(nstack_elems[k] * 4);
+    }
     const size_t plane_px = static_cast<size_t>(s.dense_h) * s.dense_w;
     // per-layer scratch of the generic synthesis path and the dense stacks of the unfused upsampling: only when that path runs
     const bool need_dense = !s.use_fused_dec;
@@ -511,28 +657,40 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     const size_t o_stab = A.reserve(need_layers ? plane_px * std::max(h.out_channels, 1) * 4 : 16);
     const size_t o_synout = A.reserve(plane_px * std::max(h.out_channels, 1) * 4);
     const size_t o_out = need_resize ? A.reserve(static_cast<size_t>(H) * W * h.out_channels * 4) : o_synout;
-    size_t o_plane[3] = {0, 0, 0};
+    // the three integer planes in one block (plane p at a 256-byte aligned offset): one copy takes them to the host
+    size_t o_planes = 0;
     const size_t sample_bytes = bitdepth == 8 ? 1 : 2;
     if (bitdepth) {
+        size_t off = 0;
         for (int p = 0; p < 3; ++p) {
             const bool chroma420 = (frame_data_type == 1 && p > 0);
             s.plane_h[p] = chroma420 ? H / 2 : H;
             s.plane_w[p] = chroma420 ? W / 2 : W;
-            o_plane[p] = A.reserve(static_cast<size_t>(s.plane_h[p]) * s.plane_w[p] * sample_bytes + 16);
+            s.plane_off[p] = off;
+            off += (static_cast<size_t>(s.plane_h[p]) * s.plane_w[p] * sample_bytes + 16 + 255) & ~size_t{255};
         }
+        s.planes_bytes = off;
+        o_planes = A.reserve(off);
     }
-    rc = A.commit();
+    rc = A.commit(b->device);
     if (rc < 0) return rc;
 
-    // ---- uploads (inputs become resident in HBM here) ----------------------------------------------------
-    auto fail = [&](int code) { A.release(); return code; };
-    // zeros where something is read before it is written: payload tail, status block (everything up to it is small);
-    // the float planes and integer planes are fully written by the kernels
-    if (hipMemset(A.at<char>(0), 0, o_status + 512) != hipSuccess) return fail(CCD_ERR_HIP);
-    if (n_words && hipMemcpy(A.at<void>(o_words), bytes_latent, n_words * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(CCD_ERR_HIP);
-    if (hipMemcpy(A.at<void>(o_arm), arm_blob.data(), arm_blob.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail(CCD_ERR_HIP);
-    if (!ifce_blob.empty() && hipMemcpy(A.at<void>(o_ifce), ifce_blob.data(), ifce_blob.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail(CCD_ERR_HIP);
-    if (!syn_blob.empty() && hipMemcpy(A.at<void>(o_synp), syn_blob.data(), syn_blob.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return fail(CCD_ERR_HIP);
+    // ---- upload (inputs become resident in HBM here): the head, staged in pinned memory, one asynchronous copy on the
+    // device's upload stream; launches order themselves behind it with an event (ccd_batch_run_stage) ----------------
+    auto fail = [&](int code) { A.release(); s.staging.drop(); return code; };
+    if (!s.staging.get(b->device, BlockPool::kPinned, head_bytes)) return fail(CCD_ERR_NOMEM);
+    {
+        char* st = s.staging.as<char>();
+        std::memset(st + o_status, 0, 512);
+        if (n_words) std::memcpy(st + o_words, bytes_latent, n_words * 4);
+        std::memset(st + o_words + n_words * 4, 0, 8);
+        std::memcpy(st + o_arm, arm_blob.data(), arm_blob.size() * 8);
+        if (!ifce_blob.empty()) std::memcpy(st + o_ifce, ifce_blob.data(), ifce_blob.size() * 8);
+        if (!syn_blob.empty()) std::memcpy(st + o_synp, syn_blob.data(), syn_blob.size() * 4);
+        if (hipMemcpyAsync(A.at<void>(0), st, head_bytes, hipMemcpyHostToDevice, b->up_stream) != hipSuccess) return fail(CCD_ERR_HIP);
+        if (hipEventRecord(b->up_done, b->up_stream) != hipSuccess) return fail(CCD_ERR_HIP);
+        b->uploads_unconfirmed = true;
+    }
 
     // ---- entropy stage description -----------------------------------------------------------------------
     EntropyParams& E = s.ep;
@@ -600,7 +758,7 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     s.d_stab = A.at<float>(o_stab);
     s.d_syn_out = A.at<float>(o_synout);
     s.d_out = A.at<float>(o_out);
-    for (int p = 0; p < 3; ++p) s.d_plane[p] = bitdepth ? A.at<void>(o_plane[p]) : nullptr;
+    for (int p = 0; p < 3; ++p) s.d_plane[p] = bitdepth ? A.at<void>(o_planes + s.plane_off[p]) : nullptr;
     if (s.use_fused_syn) {
         SynthFused& F = s.fused;
         F.dense = s.d_dense; F.params = s.d_syn_params; F.h = s.dense_h; F.w = s.dense_w;
@@ -629,11 +787,11 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     return static_cast<int>(b->slots.size()) - 1;
 }
 
-static int upload_params(ccd_batch* b) {
+static int upload_params(ccd_batch* b, hipStream_t st) {
     const int n = static_cast<int>(b->slots.size());
     if (b->n_params_uploaded == n) return CCD_OK;
-    if (b->d_params) { (void)hipFree(b->d_params); b->d_params = nullptr; }
     std::vector<EntropyParams> host;
+    std::vector<int> host_slot;  // slot of host[k]: its status words are words [64 slot, 64 slot + 64) of the batch's status array
     b->pipe_groups.clear();  // the pipelined kernel is instantiated per input width nv = ceil(dim / 4): one launch per width
     for (int nv = 1; nv <= 8; ++nv)
         for (int mf = 0; mf < 2; ++mf) {
@@ -641,17 +799,14 @@ static int upload_params(ccd_batch* b) {
             size_t lds = 0;
             for (int i = 0; i < n; ++i) {
                 const Slot& sl = *b->slots[i];
-                if (sl.use_pipe && (sl.ep.dim + 3) / 4 == nv && (sl.use_mfma ? 1 : 0) == mf) { host.push_back(sl.ep); lds = std::max(lds, sl.lds_pipe); }
+                if (sl.use_pipe && (sl.ep.dim + 3) / 4 == nv && (sl.use_mfma ? 1 : 0) == mf) { host.push_back(sl.ep); host_slot.push_back(i); lds = std::max(lds, sl.lds_pipe); }
             }
             if (static_cast<int>(host.size()) > first) b->pipe_groups.push_back({nv, mf, first, static_cast<int>(host.size()) - first, lds});
         }
     b->n_pipe = static_cast<int>(host.size());
-    for (int i = 0; i < n; ++i) if (!b->slots[i]->use_pipe) host.push_back(b->slots[i]->ep);
+    for (int i = 0; i < n; ++i) if (!b->slots[i]->use_pipe) { host.push_back(b->slots[i]->ep); host_slot.push_back(i); }
     b->n_generic = n - b->n_pipe;
-    if (hipMalloc(&b->d_params, sizeof(EntropyParams) * std::max(n, 1)) != hipSuccess) return CCD_ERR_NOMEM;
-    if (n && hipMemcpy(b->d_params, host.data(), sizeof(EntropyParams) * n, hipMemcpyHostToDevice) != hipSuccess) return CCD_ERR_HIP;
     // fused synthesis: one launch per (CP, C) group over all of its frames
-    if (b->d_fused) { (void)hipFree(b->d_fused); b->d_fused = nullptr; }
     b->fused_groups.clear();
     std::vector<SynthFused> fused;
     for (int i = 0; i < n; ++i) {
@@ -674,18 +829,12 @@ static int upload_params(ccd_batch* b) {
             ++g.n;
         }
     }
-    if (!fused.empty()) {
-        if (hipMalloc(&b->d_fused, sizeof(SynthFused) * fused.size()) != hipSuccess) return CCD_ERR_NOMEM;
-        if (hipMemcpy(b->d_fused, fused.data(), sizeof(SynthFused) * fused.size(), hipMemcpyHostToDevice) != hipSuccess) return CCD_ERR_HIP;
-    }
     // fused float path: frames grouped by (levels, channels); a workgroup takes a run of `per_wg` tiles of one frame
-    if (b->d_fdec) { (void)hipFree(b->d_fdec); b->d_fdec = nullptr; }
-    if (b->d_fdec_work) { (void)hipFree(b->d_fdec_work); b->d_fdec_work = nullptr; }
     b->fdec_groups.clear();
+    struct Work { int32_t frame, tile_first, tile_count, pad; };
+    std::vector<FusedDec> frames;
+    std::vector<Work> work;
     {
-        struct Work { int32_t frame, tile_first, tile_count, pad; };
-        std::vector<FusedDec> frames;
-        std::vector<Work> work;
         for (int i = 0; i < n; ++i) {
             const Slot& s = *b->slots[i];
             if (!s.use_fused_dec) continue;
@@ -714,18 +863,8 @@ static int upload_params(ccd_batch* b) {
             }
             g.n_work = static_cast<int>(work.size()) - g.first_work;
         }
-        if (!frames.empty()) {
-            if (hipMalloc(&b->d_fdec, sizeof(FusedDec) * frames.size()) != hipSuccess ||
-                hipMalloc(&b->d_fdec_work, sizeof(Work) * work.size()) != hipSuccess)
-                return CCD_ERR_NOMEM;
-            if (hipMemcpy(b->d_fdec, frames.data(), sizeof(FusedDec) * frames.size(), hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemcpy(b->d_fdec_work, work.data(), sizeof(Work) * work.size(), hipMemcpyHostToDevice) != hipSuccess)
-                return CCD_ERR_HIP;
-        }
     }
     // upsampling steps: step k (k-th from the coarsest level) of all slots together
-    if (b->d_levels) { (void)hipFree(b->d_levels); b->d_levels = nullptr; }
-    if (b->d_zmap) { (void)hipFree(b->d_zmap); b->d_zmap = nullptr; }
     b->ups_steps.clear();
     std::vector<UpsampleLevel> levels;
     std::vector<uint32_t> zmap;
@@ -747,14 +886,42 @@ static int upload_params(ccd_batch* b) {
         st.n_z = static_cast<int>(zmap.size()) - st.first_z;
         b->ups_steps.push_back(st);
     }
-    if (!levels.empty()) {
-        if (hipMalloc(&b->d_levels, sizeof(UpsampleLevel) * levels.size()) != hipSuccess ||
-            hipMalloc(&b->d_zmap, sizeof(uint32_t) * zmap.size()) != hipSuccess)
-            return CCD_ERR_NOMEM;
-        if (hipMemcpy(b->d_levels, levels.data(), sizeof(UpsampleLevel) * levels.size(), hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(b->d_zmap, zmap.data(), sizeof(uint32_t) * zmap.size(), hipMemcpyHostToDevice) != hipSuccess)
-            return CCD_ERR_HIP;
+    // ---- one pooled device block for every table and the status words of all slots, filled by ONE copy from ONE pinned block
+    auto up256 = [](size_t v) { return (v + 255) & ~size_t{255}; };
+    const size_t o_params = 0;
+    const size_t o_fusedt = o_params + up256(sizeof(EntropyParams) * std::max(n, 1));
+    const size_t o_fdec = o_fusedt + up256(sizeof(SynthFused) * std::max<size_t>(fused.size(), 1));
+    const size_t o_work = o_fdec + up256(sizeof(FusedDec) * std::max<size_t>(frames.size(), 1));
+    const size_t o_levels = o_work + up256(sizeof(Work) * std::max<size_t>(work.size(), 1));
+    const size_t o_zmap = o_levels + up256(sizeof(UpsampleLevel) * std::max<size_t>(levels.size(), 1));
+    const size_t o_stat = o_zmap + up256(sizeof(uint32_t) * std::max<size_t>(zmap.size(), 1));
+    const size_t total = o_stat + up256(static_cast<size_t>(std::max(n, 1)) * 64 * sizeof(int32_t));
+    // the previous tables may still be read by launches in flight on the caller's stream (a batch that grew between runs)
+    if (b->tables.p && b->last_stream_valid) HIP_TRY(hipStreamSynchronize(b->last_stream));
+    if (!b->tables.get(b->device, BlockPool::kDevice, total) || !b->tables_staging.get(b->device, BlockPool::kPinned, total) ||
+        !b->status_host.get(b->device, BlockPool::kPinned, static_cast<size_t>(std::max(n, 1)) * 64 * sizeof(int32_t)))
+        return CCD_ERR_NOMEM;
+    char* dev = b->tables.as<char>();
+    char* stg = b->tables_staging.as<char>();
+    b->d_params = reinterpret_cast<EntropyParams*>(dev + o_params);
+    b->d_fused = reinterpret_cast<SynthFused*>(dev + o_fusedt);
+    b->d_fdec = reinterpret_cast<FusedDec*>(dev + o_fdec);
+    b->d_fdec_work = dev + o_work;
+    b->d_levels = reinterpret_cast<UpsampleLevel*>(dev + o_levels);
+    b->d_zmap = reinterpret_cast<uint32_t*>(dev + o_zmap);
+    b->d_status_all = reinterpret_cast<int32_t*>(dev + o_stat);
+    for (int k = 0; k < n; ++k) {
+        host[k].status = b->d_status_all + static_cast<size_t>(host_slot[k]) * 64;
+        b->slots[host_slot[k]]->d_status = host[k].status;
     }
+    if (n) std::memcpy(stg + o_params, host.data(), sizeof(EntropyParams) * n);
+    if (!fused.empty()) std::memcpy(stg + o_fusedt, fused.data(), sizeof(SynthFused) * fused.size());
+    if (!frames.empty()) std::memcpy(stg + o_fdec, frames.data(), sizeof(FusedDec) * frames.size());
+    if (!work.empty()) std::memcpy(stg + o_work, work.data(), sizeof(Work) * work.size());
+    if (!levels.empty()) std::memcpy(stg + o_levels, levels.data(), sizeof(UpsampleLevel) * levels.size());
+    if (!zmap.empty()) std::memcpy(stg + o_zmap, zmap.data(), sizeof(uint32_t) * zmap.size());
+    std::memset(stg + o_stat, 0, total - o_stat);
+    HIP_TRY(hipMemcpyAsync(dev, stg, total, hipMemcpyHostToDevice, st));
     b->n_params_uploaded = n;
     return CCD_OK;
 }
@@ -835,8 +1002,10 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
     if (!b) return CCD_ERR_ARG;
     HIP_TRY(hipSetDevice(b->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    int rc = upload_params(b);
+    if (b->uploads_unconfirmed) HIP_TRY(hipStreamWaitEvent(st, b->up_done, 0));  // the slots' uploads (ccd_batch_add) come first
+    int rc = upload_params(b, st);
     if (rc < 0) return rc;
+    b->last_stream = st; b->last_stream_valid = true;
     if (stage == 0) {
         for (const auto& g : b->pipe_groups) HIP_TRY(launch_entropy_pipe(b->d_params + g.first, g.n, g.nv, g.mfma, g.lds, st));
         HIP_TRY(launch_entropy(b->d_params + b->n_pipe, b->n_generic, b->lds_generic, st));
@@ -870,14 +1039,25 @@ int ccd_batch_run(ccd_batch* b, void* stream) {
 int ccd_batch_wait(ccd_batch* b, void* stream) {
     if (!b) return CCD_ERR_ARG;
     HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
-    int first = CCD_OK;
-    for (auto& sp : b->slots) {
-        HIP_TRY(hipMemcpy(sp->host_status, sp->d_status, sizeof(sp->host_status), hipMemcpyDeviceToHost));
-        sp->status = sp->host_status[0];
-        if (first == CCD_OK && sp->status != CCD_OK) first = sp->status;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t n = b->slots.size();
+    if (n && static_cast<size_t>(b->n_params_uploaded) == n && b->d_status_all) {
+        // the status words of all slots are one array: one copy into pinned memory, one wait
+        HIP_TRY(hipMemcpyAsync(b->status_host.p, b->d_status_all, n * 64 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        b->uploads_unconfirmed = false;  // every launch behind the uploads has finished
+        const int32_t* hs = b->status_host.as<int32_t>();
+        int first = CCD_OK;
+        for (size_t i = 0; i < n; ++i) {
+            Slot& sl = *b->slots[i];
+            std::memcpy(sl.host_status, hs + i * 64, sizeof(sl.host_status));
+            sl.status = sl.host_status[0];
+            if (first == CCD_OK && sl.status != CCD_OK) first = sl.status;
+        }
+        return first;
     }
-    return first;
+    HIP_TRY(hipStreamSynchronize(st));  // nothing was run yet
+    return CCD_OK;
 }
 
 int ccd_batch_slot_status(const ccd_batch* b, int slot) {
@@ -959,6 +1139,29 @@ int ccd_batch_copy_plane(ccd_batch* b, int slot, int plane, void* host, void* st
     if (!p) return CCD_ERR_ARG;
     return copy_out(b, p, host, static_cast<size_t>(ph) * pw * (b->slots[slot]->bitdepth == 8 ? 1 : 2), stream);
 }
+int ccd_batch_planes_layout(const ccd_batch* b, int slot, size_t* total_bytes, size_t* off3) {
+    if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
+    const Slot& s = *b->slots[slot];
+    if (!s.d_plane[0]) return CCD_ERR_ARG;  // added with bitdepth = 0
+    if (total_bytes) *total_bytes = s.planes_bytes;
+    if (off3) for (int p = 0; p < 3; ++p) off3[p] = s.plane_off[p];
+    return CCD_OK;
+}
+
+int ccd_batch_copy_planes_async(ccd_batch* b, int first_slot, int n_slots, void* const* host_blocks, void* stream) {
+    if (!b || !host_blocks || first_slot < 0 || n_slots < 0 || first_slot + n_slots > static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = CCD_OK;
+    for (int i = 0; i < n_slots; ++i) {
+        const Slot& s = *b->slots[first_slot + i];
+        if (!s.d_plane[0] || !host_blocks[i]) { if (rc == CCD_OK) rc = CCD_ERR_ARG; continue; }
+        if (s.status < 0) { if (rc == CCD_OK) rc = s.status; continue; }  // a failed slot's planes are never handed out
+        if (hipMemcpyAsync(host_blocks[i], s.d_plane[0], s.planes_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return CCD_ERR_HIP;
+    }
+    return rc;
+}
+
 int ccd_batch_copy_output(ccd_batch* b, int slot, float* host, void* stream) {
     if (const int failed = slot_failed(b, slot)) return failed;
     const float* p = ccd_batch_output(b, slot);
@@ -1000,12 +1203,31 @@ int ccd_decode_coolchic(const uint8_t* cc_header, size_t n_hdr, const uint8_t* b
     return rc;
 }
 
+// ccd_decode_video hands out every plane of every frame inside ONE pinned host block (filled by one copy); its handle rides
+// in a hidden ccd_frame behind the last one.
 void ccd_video_free(ccd_video* v) {
     if (!v || !v->frames) return;
-    for (int i = 0; i < v->n_frames; ++i)
-        for (int p = 0; p < 3; ++p) std::free(v->frames[i].plane[p]);
+    Block* blk = reinterpret_cast<Block*>(v->frames[v->n_frames].plane[0]);
+    if (blk) { blk->drop(); delete blk; }
     std::free(v->frames);
     v->frames = nullptr; v->n_frames = 0;
+}
+
+// decode.py:156-206 for one P / B frame on `st`, no allocation, no wait: tmp = 9 h w floats (two references and the result as
+// 4:4:4 f32 planes).
+static int inter_reconstruct_on(hipStream_t st, float* tmp, int frame_type, int h, int w, int bitdepth, int frame_data_type,
+                                const float* residue, const float* motion, const void* const* ref0_planes, const void* const* ref1_planes,
+                                const int32_t* global_flow, int warp_filter_size, void* const* out_planes) {
+    float* ref0 = tmp;
+    float* ref1 = tmp + static_cast<size_t>(3) * h * w;
+    float* out = tmp + static_cast<size_t>(6) * h * w;
+    int gf[4] = {global_flow[0], global_flow[1], frame_type == 2 ? global_flow[2] : 0, frame_type == 2 ? global_flow[3] : 0};
+    if (launch_planes_to_444(ref0_planes[0], ref0_planes[1], ref0_planes[2], ref0, h, w, bitdepth, frame_data_type, st) != hipSuccess) return CCD_ERR_HIP;
+    if (frame_type == 2 &&
+        launch_planes_to_444(ref1_planes[0], ref1_planes[1], ref1_planes[2], ref1, h, w, bitdepth, frame_data_type, st) != hipSuccess) return CCD_ERR_HIP;
+    if (launch_inter_recon(frame_type, h, w, warp_filter_size, gf, residue, motion, ref0, frame_type == 2 ? ref1 : ref0, out, st) != hipSuccess) return CCD_ERR_HIP;
+    if (launch_planes(out, out_planes[0], out_planes[1], out_planes[2], h, w, bitdepth, frame_data_type, st) != hipSuccess) return CCD_ERR_HIP;
+    return CCD_OK;
 }
 
 int ccd_inter_reconstruct(int device, void* stream, int frame_type, int h, int w, int bitdepth, int frame_data_type,
@@ -1019,21 +1241,12 @@ int ccd_inter_reconstruct(int device, void* stream, int frame_type, int h, int w
     if (warp_filter_size < 2 || warp_filter_size > 16 || (warp_filter_size & 1)) return CCD_ERR_VALUE;
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t frame_bytes = static_cast<size_t>(3) * h * w * sizeof(float);
-    float* tmp = nullptr;
-    if (hipMalloc(&tmp, 3 * frame_bytes) != hipSuccess) return CCD_ERR_NOMEM;
-    float* ref0 = tmp;
-    float* ref1 = tmp + static_cast<size_t>(3) * h * w;
-    float* out = tmp + static_cast<size_t>(6) * h * w;
-    int rc = CCD_OK;
-    int gf[4] = {global_flow[0], global_flow[1], frame_type == 2 ? global_flow[2] : 0, frame_type == 2 ? global_flow[3] : 0};
-    if (launch_planes_to_444(ref0_planes[0], ref0_planes[1], ref0_planes[2], ref0, h, w, bitdepth, frame_data_type, st) != hipSuccess) rc = CCD_ERR_HIP;
-    if (rc == CCD_OK && frame_type == 2 &&
-        launch_planes_to_444(ref1_planes[0], ref1_planes[1], ref1_planes[2], ref1, h, w, bitdepth, frame_data_type, st) != hipSuccess) rc = CCD_ERR_HIP;
-    if (rc == CCD_OK && launch_inter_recon(frame_type, h, w, warp_filter_size, gf, residue, motion, ref0, frame_type == 2 ? ref1 : ref0, out, st) != hipSuccess) rc = CCD_ERR_HIP;
-    if (rc == CCD_OK && launch_planes(out, out_planes[0], out_planes[1], out_planes[2], h, w, bitdepth, frame_data_type, st) != hipSuccess) rc = CCD_ERR_HIP;
+    Block tmp;
+    if (!tmp.get(device, BlockPool::kDevice, static_cast<size_t>(9) * h * w * sizeof(float))) return CCD_ERR_NOMEM;
+    int rc = inter_reconstruct_on(st, tmp.as<float>(), frame_type, h, w, bitdepth, frame_data_type, residue, motion, ref0_planes, ref1_planes,
+                                  global_flow, warp_filter_size, out_planes);
     if (hipStreamSynchronize(st) != hipSuccess) rc = CCD_ERR_HIP;
-    (void)hipFree(tmp);
+    tmp.drop();
     return rc;
 }
 
@@ -1085,13 +1298,15 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
     if (rc >= 0) rc = ccd_batch_run(b, nullptr);
     if (rc >= 0) rc = ccd_batch_wait(b, nullptr);
     // ---- frame reconstruction in coding order; device planes of every decoded frame are kept for references ------
-    struct DevFrame { void* plane[3] = {nullptr, nullptr, nullptr}; int h = 0, w = 0, ch = 0, cw = 0, bitdepth = 0, fdt = 0; bool owned = false, seen = false; };
+    struct DevFrame { void* plane[3] = {nullptr, nullptr, nullptr}; int h = 0, w = 0, ch = 0, cw = 0, bitdepth = 0, fdt = 0; bool seen = false; Block own; };
     std::vector<DevFrame> dev(n_frames);  // by display index
+    Block tmp;  // two references and the result as 4:4:4 f32 planes, reused by every inter frame (one stream: ordered)
+    size_t tmp_elems = 0;
     for (int f = 0; f < n_frames && rc >= 0; ++f) {
         const ccd_frame_header& fh = fhs[f];
         if (fh.display_index < 0 || fh.display_index >= n_frames) { rc = CCD_ERR_VALUE; break; }
         DevFrame& d = dev[fh.display_index];
-        if (d.seen) { rc = CCD_ERR_VALUE; break; }  // two frames with one display index: the second would overwrite (and leak) the first
+        if (d.seen) { rc = CCD_ERR_VALUE; break; }  // two frames with one display index: the second would overwrite the first
         d.seen = true;
         const Slot& s0 = *b->slots[first_slot[f]];
         d.h = s0.hdr.img_size[0]; d.w = s0.hdr.img_size[1]; d.bitdepth = fh.bitdepth; d.fdt = fh.frame_data_type;
@@ -1106,6 +1321,7 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
             const Slot& s1 = *b->slots[first_slot[f] + 1];
             const int need_res = fh.frame_type == 1 ? 4 : 5, need_mot = fh.frame_type == 1 ? 2 : 4;
             if (s0.hdr.out_channels < need_res || s1.hdr.out_channels < need_mot || s1.hdr.img_size[0] != d.h || s1.hdr.img_size[1] != d.w) { rc = CCD_ERR_VALUE; break; }
+            if (fh.warp_filter_size < 2 || fh.warp_filter_size > 16 || (fh.warp_filter_size & 1)) { rc = CCD_ERR_VALUE; break; }  // warp.py:41-56
             const void* refs[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
             for (int k = 0; k < fh.n_refs && rc >= 0; ++k) {
                 const int ri = fh.index_references[k];
@@ -1117,42 +1333,68 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
             }
             if (rc < 0) break;
             const size_t sb = d.bitdepth == 8 ? 1 : 2;
-            for (int p = 0; p < 3 && rc >= 0; ++p) {
-                const size_t px = p == 0 ? static_cast<size_t>(d.h) * d.w : static_cast<size_t>(d.ch) * d.cw;
-                if (hipMalloc(&d.plane[p], px * sb + 16) != hipSuccess) rc = CCD_ERR_NOMEM;
+            const size_t luma = (static_cast<size_t>(d.h) * d.w * sb + 16 + 255) & ~size_t{255};
+            const size_t chroma = (static_cast<size_t>(d.ch) * d.cw * sb + 16 + 255) & ~size_t{255};
+            if (!d.own.get(device, BlockPool::kDevice, luma + 2 * chroma)) { rc = CCD_ERR_NOMEM; break; }
+            d.plane[0] = d.own.as<char>(); d.plane[1] = d.own.as<char>() + luma; d.plane[2] = d.own.as<char>() + luma + chroma;
+            const size_t need = static_cast<size_t>(9) * d.h * d.w;
+            if (need > tmp_elems) {
+                if (tmp.p && hipStreamSynchronize(nullptr) != hipSuccess) { rc = CCD_ERR_HIP; break; }  // frames in flight still use the smaller one
+                if (!tmp.get(device, BlockPool::kDevice, need * sizeof(float))) { rc = CCD_ERR_NOMEM; break; }
+                tmp_elems = need;
             }
-            d.owned = true;
-            if (rc >= 0)
-                rc = ccd_inter_reconstruct(device, nullptr, fh.frame_type, d.h, d.w, d.bitdepth, d.fdt, s0.d_out, s1.d_out, refs[0],
-                                           fh.frame_type == 2 ? refs[1] : nullptr, fh.global_flow, fh.warp_filter_size, d.plane);
+            rc = inter_reconstruct_on(nullptr, tmp.as<float>(), fh.frame_type, d.h, d.w, d.bitdepth, d.fdt, s0.d_out, s1.d_out, refs[0],
+                                      fh.frame_type == 2 ? refs[1] : nullptr, fh.global_flow, fh.warp_filter_size, d.plane);
         }
     }
     // every display index must have been produced (a gap would leave a frame without planes)
     for (int i = 0; i < n_frames && rc >= 0; ++i) if (!dev[i].seen) rc = CCD_ERR_VALUE;
+    // ---- all planes as u16 in one device block -> one pinned host block -> the caller (one copy, one wait) -------------
+    Block wide;
+    Block* host = nullptr;
     if (rc >= 0) {
-        v->frames = static_cast<ccd_frame*>(std::calloc(std::max(n_frames, 1), sizeof(ccd_frame)));
-        v->n_frames = n_frames;
-        for (int f = 0; f < n_frames && rc >= 0; ++f) {
-            const int di = fhs[f].display_index;
-            const DevFrame& d = dev[di];
-            ccd_frame& fr = v->frames[di];
-            fr.display_index = di; fr.frame_type = fhs[f].frame_type; fr.frame_data_type = d.fdt; fr.bitdepth = d.bitdepth;
-            fr.h = d.h; fr.w = d.w; fr.ch = d.ch; fr.cw = d.cw;
-            for (int p = 0; p < 3 && rc >= 0; ++p) {
-                const size_t px = p == 0 ? static_cast<size_t>(d.h) * d.w : static_cast<size_t>(d.ch) * d.cw;
-                fr.plane[p] = static_cast<uint16_t*>(std::malloc(px * 2 + 2));
-                if (!fr.plane[p]) { rc = CCD_ERR_NOMEM; break; }
-                if (d.bitdepth == 8) {
-                    std::vector<uint8_t> tmp(px);
-                    if (hipMemcpy(tmp.data(), d.plane[p], px, hipMemcpyDeviceToHost) != hipSuccess) rc = CCD_ERR_HIP;
-                    for (size_t i = 0; i < px; ++i) fr.plane[p][i] = tmp[i];
-                } else if (hipMemcpy(fr.plane[p], d.plane[p], px * 2, hipMemcpyDeviceToHost) != hipSuccess) rc = CCD_ERR_HIP;
+        size_t total = 0;
+        std::vector<size_t> off(static_cast<size_t>(n_frames) * 3);
+        for (int i = 0; i < n_frames; ++i)
+            for (int p = 0; p < 3; ++p) {
+                off[static_cast<size_t>(i) * 3 + p] = total;
+                total += ((p == 0 ? static_cast<size_t>(dev[i].h) * dev[i].w : static_cast<size_t>(dev[i].ch) * dev[i].cw) * 2 + 63) & ~size_t{63};
             }
+        host = new (std::nothrow) Block();
+        v->frames = static_cast<ccd_frame*>(std::calloc(static_cast<size_t>(n_frames) + 1, sizeof(ccd_frame)));
+        if (!host || !v->frames || !wide.get(device, BlockPool::kDevice, std::max<size_t>(total, 64)) ||
+            !host->get(device, BlockPool::kPinned, std::max<size_t>(total, 64)))
+            rc = CCD_ERR_NOMEM;
+        for (int i = 0; i < n_frames && rc >= 0; ++i)
+            for (int p = 0; p < 3 && rc >= 0; ++p) {
+                const size_t px = p == 0 ? static_cast<size_t>(dev[i].h) * dev[i].w : static_cast<size_t>(dev[i].ch) * dev[i].cw;
+                uint16_t* dst = reinterpret_cast<uint16_t*>(wide.as<char>() + off[static_cast<size_t>(i) * 3 + p]);
+                const hipError_t e = dev[i].bitdepth == 8 ? launch_widen_u8(static_cast<const uint8_t*>(dev[i].plane[p]), dst, px, nullptr)
+                                                          : hipMemcpyAsync(dst, dev[i].plane[p], px * 2, hipMemcpyDeviceToDevice, nullptr);
+                if (e != hipSuccess) rc = CCD_ERR_HIP;
+            }
+        if (rc >= 0 && (hipMemcpyAsync(host->p, wide.p, total, hipMemcpyDeviceToHost, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess))
+            rc = CCD_ERR_HIP;
+        if (rc >= 0) {
+            v->n_frames = n_frames;
+            v->frames[n_frames].plane[0] = reinterpret_cast<uint16_t*>(host);  // hidden: the block every plane points into (ccd_video_free)
+            for (int f = 0; f < n_frames; ++f) {
+                const int di = fhs[f].display_index;
+                const DevFrame& d = dev[di];
+                ccd_frame& fr = v->frames[di];
+                fr.display_index = di; fr.frame_type = fhs[f].frame_type; fr.frame_data_type = d.fdt; fr.bitdepth = d.bitdepth;
+                fr.h = d.h; fr.w = d.w; fr.ch = d.ch; fr.cw = d.cw;
+                for (int p = 0; p < 3; ++p) fr.plane[p] = reinterpret_cast<uint16_t*>(host->as<char>() + off[static_cast<size_t>(di) * 3 + p]);
+            }
+        } else {
+            if (host) { host->drop(); delete host; }
+            std::free(v->frames);
+            v->frames = nullptr; v->n_frames = 0;
         }
-        if (rc < 0) ccd_video_free(v);
     }
-    for (auto& d : dev)
-        if (d.owned) for (int p = 0; p < 3; ++p) if (d.plane[p]) (void)hipFree(d.plane[p]);
+    (void)hipStreamSynchronize(nullptr);  // nothing may still read the blocks that go back to the pool
+    for (auto& d : dev) d.own.drop();
+    tmp.drop(); wide.drop();
     ccd_batch_destroy(b);
     return rc < 0 ? rc : CCD_OK;
 }

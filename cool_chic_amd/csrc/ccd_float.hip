@@ -14,6 +14,8 @@
 // This file holds the generic (any architecture the header can describe) kernels.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "ccd_device.hpp"
 
 namespace ccd {
@@ -475,6 +477,18 @@ hipError_t launch_planes(const float* src, void* p0, void* p1, void* p2, int h, 
     else
         hipLaunchKernelGGL(planes_kernel<uint16_t>, grid, dim3(256), 0, stream, src, static_cast<uint16_t*>(p0),
                            static_cast<uint16_t*>(p1), static_cast<uint16_t*>(p2), h, w, yuv420, maxv);
+    return hipGetLastError();
+}
+
+// u8 planes -> u16 (ccd_decode_video hands out u16 samples whatever the bit depth): done on the device so that the host
+// receives the final layout in one copy
+__global__ void widen_u8_kernel(const uint8_t* in, uint16_t* out, size_t n) {
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<size_t>(gridDim.x) * blockDim.x) out[i] = in[i];
+}
+hipError_t launch_widen_u8(const uint8_t* in, uint16_t* out, size_t n, hipStream_t stream) {
+    if (!n) return hipSuccess;
+    const unsigned blocks = static_cast<unsigned>(std::min<size_t>((n + 255) / 256, 4096));
+    hipLaunchKernelGGL(widen_u8_kernel, dim3(blocks), dim3(256), 0, stream, in, out, n);
     return hipGetLastError();
 }
 

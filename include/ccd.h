@@ -180,6 +180,16 @@ int ccd_batch_copy_latent(ccd_batch* b, int slot, int grid, int8_t* host, void* 
 int ccd_batch_copy_plane(ccd_batch* b, int slot, int plane, void* host, void* stream);
 int ccd_batch_copy_output(ccd_batch* b, int slot, float* host, void* stream);
 int ccd_batch_copy_dense(ccd_batch* b, int slot, float* host, void* stream);
+/* The writer's path (decode.py:84-89 hands every frame to a file writer): a slot's three integer planes sit in ONE block of
+ * device memory, plane p at byte offset off3[p] (256-byte aligned) of total_bytes.  ccd_batch_copy_planes_async enqueues one
+ * device -> host copy per slot of [first_slot, first_slot + n_slots) into host_blocks[i] (same layout; pinned memory makes
+ * them true DMA transfers) and returns without waiting: the caller waits on `stream` (ccd_batch_wait).  A slot whose decode
+ * failed is skipped and its error returned. */
+int ccd_batch_planes_layout(const ccd_batch* b, int slot, size_t* total_bytes, size_t* off3);
+int ccd_batch_copy_planes_async(ccd_batch* b, int first_slot, int n_slots, void* const* host_blocks, void* stream);
+/* Device and pinned-host blocks of destroyed batches are cached per device for the next batch (a batch per image set is the
+ * normal use); this returns them to the runtime.  CCD_POOL_MAX_MB / CCD_PINNED_POOL_MAX_MB cap the caches (32768 / 4096). */
+void ccd_pool_trim(int device);
 
 /* ---- whole file: decode_video(), decode.py:26-91 ----------------------------------------- */
 typedef struct {

@@ -11,10 +11,10 @@ for rep in range(3):
     t1 = time.perf_counter()
     for hdr, nn, lat, _ in items: b.add(hdr, nn, lat, 8, 0)
     t2 = time.perf_counter()
-    b.run(); b.wait()
+    b.run()
     t3 = time.perf_counter()
-    out = [b.planes(s) for s in range(len(items))]
+    out = b.all_planes()
     t4 = time.perf_counter()
     b.close()
     t5 = time.perf_counter()
-    print("create %.2f add %.2f run+wait %.2f planes %.2f close %.2f total %.2f ms" % tuple(1e3 * x for x in (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5 - t0)))
+    print("create %.2f add %.2f launch %.2f wait+planes %.2f close %.2f total %.2f ms" % tuple(1e3 * x for x in (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, t5 - t0)))
