@@ -103,6 +103,41 @@ def kodak24() -> Tuple[List[bytes], List[Tuple[int, int]]]:
     return streams, sizes
 
 
+def kodak24_wide_envelope() -> Tuple[List[bytes], List[Tuple[int, int]]]:
+    """kodak24 with a network OUTSIDE the r02 static envelope of the pipelined entropy kernel: the IFCE rows (weights and
+    bias, every grid) that produce kodim14's LAST feature are doubled - that feature doubles, its worst case becomes 2^15.5
+    >= 2^15 like the reference-encoded rgb192 / yuv444_10b / vid5-I networks - and the ARM's first-layer and stabiliser
+    column that reads it is halved (one feature only: halving small integers is lossy).  Every stream is re-encoded against
+    that network.  bench.py times it next to kodak24 (`wide_envelope_network`)."""
+    _, hdr, _, donor, ints, latents = _kodim14()
+    lay = writer.network_layout(donor)
+    g = np.split(np.asarray(ints, dtype=np.int64).copy(), np.cumsum(lay)[:-1])
+    dim, n_if = donor.total_context_arm, donor.output_feature_ifce
+    pos = 0
+    for k, f in enumerate(x for x in donor.input_features_ifce[:donor.n_grids] if x > 0):  # ifce.w per grid: [n_if][f]
+        g[2][pos + (n_if - 1) * f: pos + n_if * f] *= 2
+        g[3][k * n_if + n_if - 1] *= 2
+        pos += n_if * f
+    first = g[0][:dim * dim].reshape(dim, dim)            # arm.mlp.0 weight [out][in]: the IFCE columns are the last n_if
+    first[:, dim - 1] = np.round(first[:, dim - 1] / 2.0)
+    if donor.linear_stabiliser_arm:
+        stab = g[0][-2 * dim:].reshape(2, dim)            # stabiliser_branch weight [2][in] is the last weight tensor of the ARM
+        stab[:, dim - 1] = np.round(stab[:, dim - 1] / 2.0)
+    nn = writer.encode_network(donor, np.concatenate(g).astype(np.int32))  # also sets the payload size / padding in `donor`
+    hdr = writer.cc_header_bytes(donor)
+    _, levels = writer.grid_sizes((512, 768), hdr)
+    jobs = [(1000 + i, i in (3, 8, 9, 16, 17, 18)) for i in range(24)]
+
+    def make(job):
+        seed, portrait = job
+        v = writer.variant_latents(latents, levels, seed, portrait) if seed != 1000 else list(latents)
+        return writer.encode_stream(hdr, nn, v, img_size=(768, 512) if portrait else (512, 768))
+
+    with _pool(len(jobs)) as ex:
+        streams = list(ex.map(make, jobs))
+    return streams, [((768, 512) if p else (512, 768)) for _, p in jobs]
+
+
 def _image_arch(donor: CCHeader, h: int, w: int) -> CCHeader:
     v = auto_resolution(h * w)
     return writer.derive_arch(donor, img_size=(h, w), latent_resolution=(0, v), hyperlatent_resolution=(4, v),
@@ -228,6 +263,9 @@ def workload(name: str) -> Dict:
     """{"streams": [...], "sizes": [(H, W) per frame], "video": bool} for "kodak24" | "clic41" | "uhd4k" | "gop1080p33"."""
     if name == "kodak24":
         s, z = kodak24()
+        return {"streams": s, "sizes": z, "video": False}
+    if name == "kodak24_wide_envelope":
+        s, z = kodak24_wide_envelope()
         return {"streams": s, "sizes": z, "video": False}
     if name == "clic41":
         s, z = clic41()

@@ -788,7 +788,7 @@ def test_streams_the_reference_cannot_decode_are_rejected(gpu, oracle):
     assert decode(rebuild(lambda k, di, fdt: (0 if k == 4 else di, fdt))) == -2    # display index 0 twice
 
 
-@pytest.mark.parametrize("name", ["kodak24", "clic41", "uhd4k", "gop1080p33"])
+@pytest.mark.parametrize("name", ["kodak24", "kodak24_wide_envelope", "clic41", "uhd4k", "gop1080p33"])
 def test_workloads_match_the_oracle(gpu, name):
     """EVERY stream of EVERY benchmark workload (cool_chic_amd/synth.py: BASELINE.json configs[1..4] at full size - 24
     Kodak frames, the 41 CLIC sizes, the 4K frame, the 33-frame depth-5 hierarchical 1080p GOP with its 64 cool-chics):
