@@ -98,7 +98,7 @@ class DecodeBatch:
     # ---- results -------------------------------------------------------------------------------
     def slot_kernels(self, slot: int) -> int:
         """bit 0: pipelined entropy kernel, bit 1: fused synthesis kernel, bit 2: fused upsampling + synthesis kernel,
-        bit 3: the ARM on the matrix cores."""
+        bit 3: the ARM on the matrix cores, bit 4: the pipelined kernel's instantiation with the device check of IFCE features."""
         return check(lib().ccd_batch_slot_kernels(self._h, slot), "ccd_batch_slot_kernels")
 
     def latent(self, slot: int, grid: int) -> np.ndarray:

@@ -1300,7 +1300,7 @@ __device__ __forceinline__ ExactOut exact_pixel(const ExactArgs& A, int y, int x
 
 // MF: this grid's tasks run the ARM on the matrix cores; DYN_RING: the kernel's ring of decoded symbols has
 // EntropyParams::ring_rows rows instead of kRingRows (every grid of a matrix-core kernel, whichever producer serves it).
-template <int NV, int kLpp, bool MF, bool DYN_RING>
+template <int NV, int kLpp, bool MF, bool DYN_RING, bool DYN>
 __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned long long* prof) {
     constexpr int in_pad = 4 * NV;
     constexpr int kTaskPix = 64 / kLpp;
@@ -1394,8 +1394,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // critical path only carries one scalar test of this mask.
                 bool feat_bad = false;
 #pragma unroll
-                for (int t = 0; t < NOUT; ++t) feat_bad |= fv[t] == kFeatSentinel;
-                const unsigned long long bad_lanes = MF ? 0ull : __ballot(feat_bad);
+                for (int t = 0; t < NOUT; ++t) feat_bad |= DYN && fv[t] == kFeatSentinel;
+                const unsigned long long bad_lanes = (MF || !DYN) ? 0ull : __ballot(feat_bad);
                 // ---- Two waits.  Of all contexts only the left neighbour (y, x - 1) lies in the previous step (pixel i of this
                 // step reads pixel i of that one, pixel i + 1 when the step start moved down a row in between); (y, x - 2) lies
                 // two steps back, everything else at least five.  So the task gathers every other input, runs the stabiliser and
@@ -1763,7 +1763,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 }
                 // ---- a feature of some pixel was not exact in 16 bits (never on the streams seen so far): that pixel again,
                 // in plain int64; its table parameters replace what the lines above wrote from the sentinel
-                if (__builtin_expect(bad_lanes != 0ull, 0)) {
+                if (DYN && __builtin_expect(bad_lanes != 0ull, 0)) {
                     int n_redo = 0;
                     for (int p = 0; p < cnt; ++p) {
                         if (((bad_lanes >> (p * kLpp)) & ((1ull << kLpp) - 1ull)) == 0ull) continue;
@@ -1898,7 +1898,11 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 
 // One kernel per input width NV = ceil(dim / 4): a single instantiation keeps the register file for the variant that runs
 // (all widths in one kernel cost 444 SGPR spills and VGPR scratch in every path).
-template <int NV, bool MF>
+// DYN: the IFCE features of this network can leave 16 bits (its worst case does, FixedArm::dyn_feat) - the feature pass stores
+// sentinels + the int32 side plane and the producers carry the check and the int64 redo (exact_pixel).  Networks whose worst
+// case provably fits run the DYN = false instantiation: the same kernel without that code (its mere presence in the task loop
+// costs ~2 %, profiles/r03/ab_entropy_dynamic_operand_check.txt).
+template <int NV, bool MF, bool DYN>
 __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const EntropyParams* slots_desc) {
     unsigned char* const smem = ccd_pipe_smem;
     const EntropyParams& P = slots_desc[blockIdx.x];
@@ -2092,8 +2096,8 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                         const int32_t hi = static_cast<int32_t>(acc[j] >> 32), q32 = static_cast<int32_t>(acc[j] >> 24);
                         const bool big = static_cast<uint32_t>((hi >> feat_hi_shift) + 1) > 1u || (q32 & 0xffff) == 0x8000;
                         const int fo = min(j, n_if - 1) * plane + p;
-                        if (j < n_if_lane) featg[fo] = big ? kFeatSentinel : static_cast<int16_t>(q32);
-                        if (j < n_if_lane && big) wideg[fo] = q32;
+                        if (j < n_if_lane) featg[fo] = (DYN && big) ? kFeatSentinel : static_cast<int16_t>(q32);
+                        if (DYN && j < n_if_lane && big) wideg[fo] = q32;
                     }
                 }
             } else
@@ -2117,8 +2121,8 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                         if (o0 + j < n_if) {
                             const int64_t q8 = static_cast<int64_t>(acc[j]) >> 24;
                             const bool big = static_cast<uint64_t>(q8 + feat_lim - 1) >= static_cast<uint64_t>(2 * feat_lim - 1);
-                            feat[(o0 + j) * fh * fw + p] = big ? kFeatSentinel : static_cast<int16_t>(q8);
-                            if (big) P.ifce_wide[(o0 + j) * fh * fw + p] = static_cast<int32_t>(q8);
+                            feat[(o0 + j) * fh * fw + p] = (DYN && big) ? kFeatSentinel : static_cast<int16_t>(q8);
+                            if (DYN && big) P.ifce_wide[(o0 + j) * fh * fw + p] = static_cast<int32_t>(q8);
                         }
                     }
                 }
@@ -2157,7 +2161,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         } else {
             // the matrix-core evaluation only serves the 8-pixel tasks of wide grids: its chain has the same length whatever
             // the number of pixels, while the vector-ALU code of a 4- / 2-pixel task spreads a pixel over 16 / 32 lanes
-            seq_end = C.task_pix == 8 ? producer_grid<NV, 8, MF, MF>(C, prof) : (C.task_pix == 4 ? producer_grid<NV, 16, false, MF>(C, prof) : producer_grid<NV, 32, false, MF>(C, prof));
+            seq_end = C.task_pix == 8 ? producer_grid<NV, 8, MF, MF, DYN>(C, prof) : (C.task_pix == 4 ? producer_grid<NV, 16, false, MF, DYN>(C, prof) : producer_grid<NV, 32, false, MF, DYN>(C, prof));
         }
         const unsigned long long t_b = PROF_T();
         __syncthreads();  // also makes the decoder's global writes of this grid visible to every wave
@@ -2237,15 +2241,6 @@ bool entropy_pipe_supports_mfma(int dim, int n_layers, int n_ifce_out, int narro
            max_abs_weight < (1ll << 23) && entropy_pipe_lds_bytes(dim, n_layers, ring, 1) <= 160 * 1024;
 }
 
-template <int NV, bool MF>
-static hipError_t launch_pipe_nv(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(entropy_pipe_kernel<NV, MF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((entropy_pipe_kernel<NV, MF>), dim3(n_slots), dim3(kPipeThreads), lds_bytes, stream, d_slots);
-    return hipGetLastError();
-}
-
 // ---- debug: every left cumulative the producers can compute for a run of scale indices -------------------------------
 // out[(c - scale_first) * 32768 * 127 + mu_idx * 127 + (s + 63)] = window_left(mu, b, rcp, s) for s = -63 .. 63 (s = -64 is 0
 // and the right bound of s is the left bound of s + 1): 32768 x 2561 x 127 = 1.0658e10 values in all (tools/cdf_sweep.py).
@@ -2264,28 +2259,51 @@ hipError_t launch_laplace_sweep_pipe(const float* scale_table, const double* rcp
     return hipGetLastError();
 }
 
-// All `n_slots` descriptors must share nv = ceil(dim / 4) and the mfma flag (the host groups the slots of a batch by both).
-hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, int mfma, size_t lds_bytes, hipStream_t stream) {
+template <int NV, bool MF, bool DYN>
+static hipError_t launch_pipe_nv(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(entropy_pipe_kernel<NV, MF, DYN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((entropy_pipe_kernel<NV, MF, DYN>), dim3(n_slots), dim3(kPipeThreads), lds_bytes, stream, d_slots);
+    return hipGetLastError();
+}
+
+// All `n_slots` descriptors must share nv = ceil(dim / 4), the mfma flag and the dyn flag (the host groups the slots of a batch by
+// all three).  The matrix-core variant's envelope implies dyn = 0.
+hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, int mfma, int dyn, size_t lds_bytes, hipStream_t stream) {
     if (n_slots <= 0) return hipSuccess;
     if (mfma) {
         switch (nv) {
-            case 1: return launch_pipe_nv<1, true>(d_slots, n_slots, lds_bytes, stream);
-            case 2: return launch_pipe_nv<2, true>(d_slots, n_slots, lds_bytes, stream);
-            case 3: return launch_pipe_nv<3, true>(d_slots, n_slots, lds_bytes, stream);
-            case 4: return launch_pipe_nv<4, true>(d_slots, n_slots, lds_bytes, stream);
-            case 5: return launch_pipe_nv<5, true>(d_slots, n_slots, lds_bytes, stream);
+            case 1: return launch_pipe_nv<1, true, false>(d_slots, n_slots, lds_bytes, stream);
+            case 2: return launch_pipe_nv<2, true, false>(d_slots, n_slots, lds_bytes, stream);
+            case 3: return launch_pipe_nv<3, true, false>(d_slots, n_slots, lds_bytes, stream);
+            case 4: return launch_pipe_nv<4, true, false>(d_slots, n_slots, lds_bytes, stream);
+            case 5: return launch_pipe_nv<5, true, false>(d_slots, n_slots, lds_bytes, stream);
+            default: return hipErrorInvalidValue;
+        }
+    }
+    if (dyn) {
+        switch (nv) {
+            case 1: return launch_pipe_nv<1, false, true>(d_slots, n_slots, lds_bytes, stream);
+            case 2: return launch_pipe_nv<2, false, true>(d_slots, n_slots, lds_bytes, stream);
+            case 3: return launch_pipe_nv<3, false, true>(d_slots, n_slots, lds_bytes, stream);
+            case 4: return launch_pipe_nv<4, false, true>(d_slots, n_slots, lds_bytes, stream);
+            case 5: return launch_pipe_nv<5, false, true>(d_slots, n_slots, lds_bytes, stream);
+            case 6: return launch_pipe_nv<6, false, true>(d_slots, n_slots, lds_bytes, stream);
+            case 7: return launch_pipe_nv<7, false, true>(d_slots, n_slots, lds_bytes, stream);
+            case 8: return launch_pipe_nv<8, false, true>(d_slots, n_slots, lds_bytes, stream);
             default: return hipErrorInvalidValue;
         }
     }
     switch (nv) {
-        case 1: return launch_pipe_nv<1, false>(d_slots, n_slots, lds_bytes, stream);
-        case 2: return launch_pipe_nv<2, false>(d_slots, n_slots, lds_bytes, stream);
-        case 3: return launch_pipe_nv<3, false>(d_slots, n_slots, lds_bytes, stream);
-        case 4: return launch_pipe_nv<4, false>(d_slots, n_slots, lds_bytes, stream);
-        case 5: return launch_pipe_nv<5, false>(d_slots, n_slots, lds_bytes, stream);
-        case 6: return launch_pipe_nv<6, false>(d_slots, n_slots, lds_bytes, stream);
-        case 7: return launch_pipe_nv<7, false>(d_slots, n_slots, lds_bytes, stream);
-        case 8: return launch_pipe_nv<8, false>(d_slots, n_slots, lds_bytes, stream);
+        case 1: return launch_pipe_nv<1, false, false>(d_slots, n_slots, lds_bytes, stream);
+        case 2: return launch_pipe_nv<2, false, false>(d_slots, n_slots, lds_bytes, stream);
+        case 3: return launch_pipe_nv<3, false, false>(d_slots, n_slots, lds_bytes, stream);
+        case 4: return launch_pipe_nv<4, false, false>(d_slots, n_slots, lds_bytes, stream);
+        case 5: return launch_pipe_nv<5, false, false>(d_slots, n_slots, lds_bytes, stream);
+        case 6: return launch_pipe_nv<6, false, false>(d_slots, n_slots, lds_bytes, stream);
+        case 7: return launch_pipe_nv<7, false, false>(d_slots, n_slots, lds_bytes, stream);
+        case 8: return launch_pipe_nv<8, false, false>(d_slots, n_slots, lds_bytes, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -146,7 +146,8 @@ int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64);
 /* Which kernels serve this slot: bit 0 = pipelined entropy kernel (else the generic int64 one),
  * bit 1 = fused synthesis kernel (else one launch per layer), bit 2 = the whole float path (upsampling +
  * synthesis + integer samples) in one kernel, ccd_fused.hip, bit 3 = the ARM's layers evaluated on the matrix cores
- * inside the pipelined entropy kernel (exact limb-split int8, ccd_entropy_pipe.hip). */
+ * inside the pipelined entropy kernel (exact limb-split int8, ccd_entropy_pipe.hip), bit 4 = the pipelined kernel's
+ * instantiation that checks the IFCE features on the device (networks whose worst-case feature does not fit 16 bits). */
 int ccd_batch_slot_kernels(const ccd_batch* b, int slot);
 
 /* Batch options, to be set before the slots they concern are added:
