@@ -1,10 +1,12 @@
 """gpurun_out/prof/{fetch,write} (tools/collect_profiles.sh: one rocprofv3 --pmc run per counter) -> profiles/<round>/<tag>_pmc_traffic.json
 
-    python tools/summarise_pmc.py [gpurun_out/prof] [profiles/r02] [kodak24]
+    python tools/summarise_pmc.py [gpurun_out/prof] [profiles/r03] [kodak24]
 
 Bytes per launch = mean of the counter over the launches of a kernel (first launch of every kernel dropped: warm-up
-with cold caches), counter unit KiB.  Kernels launched several times per step (the six pyramid levels) also get a
-per-step figure."""
+with cold caches), counter unit KiB, CORRECTED with the factors measured on this GPU generation by tools/pmc_calibrate.sh
+(profiles/r03/pmc_calibration.json: 1 GiB streamed per kernel with 1 / 2 / 4 / 16 bytes per lane): FETCH_SIZE reports exactly
+half of the bytes read whatever the access width -> x 2; WRITE_SIZE is exact for 1 / 4 / 8 / 16 bytes per lane -> x 1.
+Kernels launched several times per step (the six pyramid levels) also get a per-step figure."""
 import csv
 import glob
 import json
@@ -29,13 +31,13 @@ def read(dir_, counter):
         with open(f) as fh:
             for r in csv.DictReader(fh):
                 if r["Counter_Name"] == counter:
-                    vals[r["Kernel_Name"]].append(float(r["Counter_Value"]) * 1024.0)
+                    vals[r["Kernel_Name"]].append(float(r["Counter_Value"]) * 1024.0 * (2.0 if counter == "FETCH_SIZE" else 1.0))
     return vals
 
 
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-    dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02"
+    dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03"
     tag = sys.argv[3] if len(sys.argv) > 3 else "kodak24"
     fetch, write = read(os.path.join(src, "fetch"), "FETCH_SIZE"), read(os.path.join(src, "write"), "WRITE_SIZE")
     out = {}
@@ -54,13 +56,13 @@ def main():
             e["fetch_bytes"] = sum(f) / len(f)
             e["write_bytes"] = sum(w) / len(w)
         out[short] = e
+    cmd = {"kodak24": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --legs none",
+           "kodak192": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --legs none --scaling strong"}.get(tag, f"python tools/prof_workload.py {tag} 3")
     doc = {
-        "command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --legs none" + (" --scaling strong" if tag != "kodak24" else "")
-                   + " (tools/collect_profiles.sh; one rocprofv3 run per counter)",
-        "unit": "bytes per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB; raw values, no gfx950 correction applied)",
-        "note": "MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide (16 B/lane) coalesced reads by 2x; these kernels "
-                "read 4-byte and 1-byte elements, for which the guide gives no calibration - read FETCH_SIZE as a lower bound "
-                "(x1) .. upper bound (x2).",
+        "command": cmd + " (tools/collect_profiles.sh; one rocprofv3 run per counter)",
+        "unit": "bytes per launch: rocprofv3 FETCH_SIZE x 1024 x 2, WRITE_SIZE x 1024 x 1",
+        "calibration": "profiles/r03/pmc_calibration.json (tools/pmc_calibrate.sh, tools/ubench/pmc_calib.hip): on gfx950 FETCH_SIZE = 0.500 of "
+                       "the bytes streamed with 1, 2, 4 and 16 bytes per lane; WRITE_SIZE = 1.000 with 1, 4, 8 and 16 bytes per lane",
         "kernels": out,
     }
     os.makedirs(dst, exist_ok=True)
