@@ -166,6 +166,12 @@ struct DeviceShared {
     float* d_scale_table = nullptr;
     double* d_rcp_table = nullptr;
     hipStream_t up_stream = nullptr;
+    // side streams for the entropy launches of one batch (one per kernel instantiation in use: MLP width x variant): a
+    // stream is a serial chain on one CU, so launches that queue behind each other on ONE stream add their durations
+    static constexpr int kSide = 8;
+    hipStream_t side[kSide] = {};
+    hipEvent_t side_done[kSide] = {};
+    hipEvent_t fork = nullptr;
 };
 int device_shared(int device, DeviceShared** out);
 
@@ -339,6 +345,11 @@ int device_shared(int device, DeviceShared** out) {
             return CCD_ERR_HIP;
         }
         d.d_scale_table = st; d.d_rcp_table = rt; d.up_stream = us;
+        bool ok = hipEventCreateWithFlags(&d.fork, hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; k < DeviceShared::kSide && ok; ++k)
+            ok = hipStreamCreateWithFlags(&d.side[k], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&d.side_done[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok) return CCD_ERR_HIP;
     }
     *out = &d;
     return CCD_OK;
@@ -776,7 +787,9 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
         D.params = s.d_syn_params + reinterpret_cast<size_t>(D.params);
         for (int i = 0; i < n_levels; ++i) { D.lat[i] = E.latent[lat_grids[i]]; D.lh[i] = h.grid_h[lat_grids[i]]; D.lw[i] = h.grid_w[lat_grids[i]]; }
         D.bitdepth = bitdepth ? bitdepth : 8;
-        D.write_planes = (bitdepth != 0 && frame_data_type != 1 && !need_resize) ? 1 : 0;
+        // integer samples straight from the kernel's epilogue: 1 = three full-size planes (rgb / yuv444), 2 = yuv420 (luma +
+        // the 2 x 2 means of the chroma quads)
+        D.write_planes = (bitdepth != 0 && !need_resize) ? (frame_data_type == 1 ? (h.out_channels >= 3 ? 2 : 0) : 1) : 0;
         // float samples: always when nothing else is produced (or a later stage reads them); otherwise by CCD_OPT_KEEP_FLOAT
         D.out = (!D.write_planes || b->opt_keep_float) ? s.d_syn_out : nullptr;
         for (int p = 0; p < 3; ++p) D.plane[p] = s.d_plane[p];
@@ -1012,8 +1025,33 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
     if (rc < 0) return rc;
     b->last_stream = st; b->last_stream_valid = true;
     if (stage == 0) {
-        for (const auto& g : b->pipe_groups) HIP_TRY(launch_entropy_pipe(b->d_params + g.first, g.n, g.nv, g.mfma, g.dyn, g.lds, st));
-        HIP_TRY(launch_entropy(b->d_params + b->n_pipe, b->n_generic, b->lds_generic, st));
+        // One launch per kernel instantiation in use.  The first goes to the caller's stream; the others fork to side streams
+        // and join again, so that they overlap (each stream of a launch occupies one CU for its whole serial chain: queued on
+        // one stream, a GOP whose I frames need another instantiation than its B frames took the SUM of the two).
+        const int n_launch = static_cast<int>(b->pipe_groups.size()) + (b->n_generic > 0 ? 1 : 0);
+        DeviceShared* sh = nullptr;
+        if (n_launch > 1) {
+            rc = device_shared(b->device, &sh);
+            if (rc < 0) return rc;
+            HIP_TRY(hipEventRecord(sh->fork, st));
+        }
+        int k = 0;
+        std::vector<int> used;
+        auto stream_for = [&](int idx) -> hipStream_t {
+            if (idx == 0 || !sh) return st;
+            const int side = (idx - 1) % DeviceShared::kSide;
+            if (std::find(used.begin(), used.end(), side) == used.end()) {
+                used.push_back(side);
+                (void)hipStreamWaitEvent(sh->side[side], sh->fork, 0);
+            }
+            return sh->side[side];
+        };
+        for (const auto& g : b->pipe_groups) HIP_TRY(launch_entropy_pipe(b->d_params + g.first, g.n, g.nv, g.mfma, g.dyn, g.lds, stream_for(k++)));
+        if (b->n_generic > 0) HIP_TRY(launch_entropy(b->d_params + b->n_pipe, b->n_generic, b->lds_generic, stream_for(k++)));
+        for (int side : used) {
+            HIP_TRY(hipEventRecord(sh->side_done[side], sh->side[side]));
+            HIP_TRY(hipStreamWaitEvent(st, sh->side_done[side], 0));
+        }
         return CCD_OK;
     }
     if (stage == 1)

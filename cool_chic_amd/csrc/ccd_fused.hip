@@ -506,12 +506,36 @@ __global__ __launch_bounds__(kFdThreads, 2) void decode_fused_kernel(const Fused
                         if (two_cols) dst[idx + 1] = res[dy * 2 + 1][j / 4][j % 4];
                     }
             }
-            if (write_planes) {  // rgb / yuv444 integer samples; yuv420 goes through planes_kernel
+            if (write_planes == 2) {
+                // yuv420 (decode.py:191-206, yuv.py:295): every sample onto the bit-depth grid FIRST, then U and V = the mean of
+                // the lane's 2 x 2 quad as F.avg_pool2d forms it (sequential f32 sum in (dy, dx) order, / 4), clamp, grid again.
+                // The quad is the lane's own (tile origins and ey / ex are even): nothing crosses lanes.  Same operations as
+                // planes_kernel (ccd_float.hip), which served these frames through the f32 output before.
+                const int ch = H >> 1, cw = W >> 1;
+                if constexpr (C >= 3) {
+                    if ((gy >> 1) < ch && (gx >> 1) < cw) {
+#pragma unroll
+                        for (int j = 1; j < 3; ++j) {
+                            float sum = 0.0f;
+#pragma unroll
+                            for (int sq = 0; sq < 4; ++sq) sum += rintf(maxv * res[sq][j / 4][j % 4]) / maxv;
+                            float a = sum / 4.0f;
+                            a = a < 0.0f ? 0.0f : (a > 1.0f ? 1.0f : a);
+                            a = rintf(a * maxv) / maxv;
+                            const unsigned q = static_cast<unsigned>(rintf(a * maxv));
+                            const size_t cidx = static_cast<size_t>(gy >> 1) * cw + (gx >> 1);
+                            if (bitdepth == 8) ((uint8_t __attribute__((address_space(1)))*)plane_ptr[j])[cidx] = static_cast<uint8_t>(q);
+                            else ((uint16_t __attribute__((address_space(1)))*)plane_ptr[j])[cidx] = static_cast<uint16_t>(q);
+                        }
+                    }
+                }
+            }
+            if (write_planes) {  // integer samples: rgb / yuv444 all three planes, yuv420 the luma plane
 #pragma unroll
                 for (int j = 0; j < (C < 3 ? C : 3); ++j)
 #pragma unroll
                     for (int dy = 0; dy < 2; ++dy) {
-                        if (dy == 1 && !two_rows) continue;
+                        if ((dy == 1 && !two_rows) || (write_planes == 2 && j > 0)) continue;
                         const size_t idx = static_cast<size_t>(gy + dy) * W + gx;
                         const unsigned q0 = fd_quantise(res[dy * 2][j / 4][j % 4], maxv), q1 = fd_quantise(res[dy * 2 + 1][j / 4][j % 4], maxv);
                         if (bitdepth == 8) {
