@@ -138,6 +138,47 @@ def verify_frames(name, frames, stream_of=lambda i: i, video=False, streams=None
     return out
 
 
+def measure_traffic_live(timeout_s: float = 150.0):
+    """HBM traffic per launch of the workload's kernels from the PMC counters, collected the way MI355X_MICROARCH.md prescribes
+    (one rocprofv3 --pmc pass per counter, never combined with other traces) on `tools/prof_workload.py kodak24 2`, with the
+    gfx950 corrections measured by tools/pmc_calibrate.sh.  {} when rocprofv3 is missing or fails (the caller falls back to the
+    tracked profile)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return {}
+    out = {}
+    names = {"entropy_pipe_kernel": "entropy_pipe_kernel", "decode_fused_kernel": "decode_fused_kernel"}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        for counter, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            d = os.path.join(tmp, counter)
+            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.join(ROOT, "tools", "prof_workload.py"), "kodak24", "2"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            except (subprocess.TimeoutExpired, OSError):
+                return {}
+            if r.returncode != 0:
+                return {}
+            vals = defaultdict(list)
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] == counter:
+                            vals[row["Kernel_Name"]].append(float(row["Counter_Value"]) * 1024.0 * factor)
+            for short, sub in names.items():
+                for k, v in vals.items():
+                    if sub in k and len(v) > 1:
+                        out.setdefault(short, {})["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = sum(v[1:]) / len(v[1:])
+    return out if all("fetch_bytes" in v and "write_bytes" in v for v in out.values()) and out else {}
+
+
 def n_symbols(batch, n):
     return int(sum(batch.header(s).n_symbols for s in range(n)))
 
@@ -253,6 +294,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--legs", default="all", help="comma list of clic41,gop1080p33,uhd4k,wide,png,e2e,float,envelope or all / none (rank 0, beside the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes (roofline.traffic then "
+                    "comes from the tracked profile)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="N > 1: nccl = RCCL over xGMI (one GPU per rank); gloo = host-staged exchange, ranks may share a GPU "
                          "(smoke run of the multi-rank path on a single-GPU box)")
@@ -374,7 +417,11 @@ def main():
         n_lat_px = latent_px(batch, n_frames)
 
         pmc, pmc_from = {}, None
-        for d in PROFILE_DIRS:
+        if args.scaling == "weak" and world == 1 and not args.no_live_traffic:
+            pmc = measure_traffic_live()  # two short rocprofv3 --pmc passes of the same workload, outside every timed region
+            if pmc:
+                pmc_from = "measured in this run"
+        for d in ([] if pmc else PROFILE_DIRS):
             try:
                 with open(os.path.join(ROOT, d, "kodak24_pmc_traffic.json")) as f:
                     pmc, pmc_from = json.load(f)["kernels"], d + "/kodak24_pmc_traffic.json"
@@ -418,19 +465,21 @@ def main():
             "slots_on_unfused_float_path": sum(1 for k in kernels if not k & 4),
             "entropy_msym_per_s": nsym / (stage_ms["entropy"] / 1e3) / 1e6,
             # what actually bounds the dominant kernel: every stream is ONE serial range-decoder recurrence; its bare symbol
-            # loop runs at 164 ticks of the 2.4 GHz shader clock (tools/ubench/dloop.hip), so n streams cannot
-            # exceed n * 2.4e9 / 164 symbols/s however many CUs idle
-            "serial_chain_bound": {"achieved": nsym / (stage_ms["entropy"] / 1e3) / 1e6, "peak": n_frames * 2.4e9 / 164.0 / 1e6,
-                                   "unit": "Msymbol/s", "frac": (nsym / (stage_ms["entropy"] / 1e3)) / (n_frames * 2.4e9 / 164.0),
-                                   "streams": n_frames, "ticks_per_symbol_floor": 164},
+            # loop, fully unrolled, runs at 143.5 ticks of the 2.4 GHz shader clock (tools/ubench/dloop_spec.hip "search",
+            # DESIGN.md 4.1), so n streams cannot exceed n * 2.4e9 / 143.5 symbols/s however many CUs idle
+            "serial_chain_bound": {"achieved": nsym / (stage_ms["entropy"] / 1e3) / 1e6, "peak": n_frames * 2.4e9 / 143.5 / 1e6,
+                                   "unit": "Msymbol/s", "frac": (nsym / (stage_ms["entropy"] / 1e3)) / (n_frames * 2.4e9 / 143.5),
+                                   "streams": n_frames, "ticks_per_symbol_floor": 143.5},
             "roofline": {"bound": "hbm", "kernel": f"entropy_pipe_kernel<5, false> ({n_frames} streams, one workgroup each)", "achieved": ent_ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ent_ach / HBM_PEAK_GBS, "traffic": traffic("entropy_pipe_kernel"),
                          "algorithmic_bytes": ent_bytes, "ms_per_launch": stage_ms["entropy"],
                          "note": "latency-bound serial chain (one range decoder per stream): see entropy_msym_per_s, serial_chain_bound "
                                  "and DESIGN.md 4.1"},
             "roofline_float_stages": float_lines,
-            "traffic_from": (f"tracked profile {pmc_from}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, raw KiB counters "
-                             "(not measured inside this run: rocprof cannot run inside bench.py)") if pmc_from else None,
+            "traffic_from": (("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python tools/prof_workload.py kodak24 2`, "
+                              "launched by this run after the timed region; mean over launches, first launch dropped; FETCH_SIZE x 2, "
+                              "WRITE_SIZE x 1 (profiles/r03/pmc_calibration.json)") if pmc_from == "measured in this run" else
+                             f"tracked profile {pmc_from} (rocprofv3 not usable in this run)") if pmc_from else None,
         }
         # ---- per-orientation entropy time: the 6 portrait streams (more, shorter wavefront steps + a network trained on a
         # landscape picture) set the step time

@@ -14,7 +14,7 @@ for TAG in kodak24 kodak192 clic41 uhd4k; do
   OUT=$REPO/gpurun_out/prof/$TAG
   rm -rf "$OUT"; mkdir -p "$OUT"
   EXTRA=""; [ "$TAG" = kodak192 ] && EXTRA="--scaling strong"
-  CMD="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --legs none $EXTRA"
+  CMD="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --legs none $EXTRA"
   case "$TAG" in clic41|uhd4k) CMD="python $REPO/tools/prof_workload.py $TAG 3";; esac
   cd /tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/bench_stats.log" 2>&1

@@ -56,8 +56,8 @@ def main():
             e["fetch_bytes"] = sum(f) / len(f)
             e["write_bytes"] = sum(w) / len(w)
         out[short] = e
-    cmd = {"kodak24": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --legs none",
-           "kodak192": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --legs none --scaling strong"}.get(tag, f"python tools/prof_workload.py {tag} 3")
+    cmd = {"kodak24": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --legs none",
+           "kodak192": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --legs none --scaling strong"}.get(tag, f"python tools/prof_workload.py {tag} 3")
     doc = {
         "command": cmd + " (tools/collect_profiles.sh; one rocprofv3 run per counter)",
         "unit": "bytes per launch: rocprofv3 FETCH_SIZE x 1024 x 2, WRITE_SIZE x 1024 x 1",
