@@ -159,7 +159,7 @@ def measure_traffic_live(timeout_s: float = 150.0):
         for counter, factor in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
             d = os.path.join(tmp, counter)
             cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-                   sys.executable, os.path.join(ROOT, "tools", "prof_workload.py"), "kodak24", "2"]
+                   sys.executable, os.path.join(ROOT, "tools", "prof_workload.py"), "kodak24", "2", "keep_float"]
             try:
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
             except (subprocess.TimeoutExpired, OSError):
@@ -476,7 +476,7 @@ def main():
                          "note": "latency-bound serial chain (one range decoder per stream): see entropy_msym_per_s, serial_chain_bound "
                                  "and DESIGN.md 4.1"},
             "roofline_float_stages": float_lines,
-            "traffic_from": (("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python tools/prof_workload.py kodak24 2`, "
+            "traffic_from": (("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of `python tools/prof_workload.py kodak24 2 keep_float` (the metric's batch), "
                               "launched by this run after the timed region; mean over launches, first launch dropped; FETCH_SIZE x 2, "
                               "WRITE_SIZE x 1 (profiles/r03/pmc_calibration.json)") if pmc_from == "measured in this run" else
                              f"tracked profile {pmc_from} (rocprofv3 not usable in this run)") if pmc_from else None,

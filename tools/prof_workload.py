@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One image workload of cool_chic_amd/synth.py decoded a few times in one batch - the command tools/collect_profiles.sh puts
 under rocprofv3 for the BASELINE configurations that are legs of bench.py (clic41, uhd4k), so that their kernels do not mix
-with kodak24's in the statistics.     python tools/prof_workload.py clic41 [steps]"""
+with kodak24's in the statistics.     python tools/prof_workload.py clic41 [steps] [keep_float]"""
 import json
 import os
 import sys
@@ -18,8 +18,9 @@ from cool_chic_amd import DecodeBatch, synth  # noqa: E402
 def main():
     name = sys.argv[1]
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    keep_float = len(sys.argv) > 3 and sys.argv[3] == "keep_float"  # like bench.py's metric batch (the library default)
     wl = synth.workload(name)
-    b = DecodeBatch(0, keep_float=False)
+    b = DecodeBatch(0, keep_float=keep_float)
     for s in wl["streams"]:
         b.add(*synth.split_image_stream(s), 8, 0)
     b.run(); b.wait()
