@@ -23,7 +23,7 @@ for TAG in kodak24 kodak192 clic41 uhd4k; do
   cd "$REPO"
   python tools/summarise_pmc.py "$OUT" "$REPO/gpurun_out/prof/summary" $TAG > /dev/null
   cp $(find "$OUT/stats" -name "*kernel_stats.csv" | head -1) "$REPO/gpurun_out/prof/summary/${TAG}_kernel_stats.csv"
-  tail -1 "$OUT/bench_stats.log" | cut -c1-400 > "$REPO/gpurun_out/prof/summary/${TAG}_bench_under_rocprof.json"
+  grep '^{' "$OUT/bench_stats.log" | tail -1 | cut -c1-400 > "$REPO/gpurun_out/prof/summary/${TAG}_bench_under_rocprof.json"
   # the counter CSVs are large: keep the summaries only
   rm -rf "$OUT/fetch" "$OUT/write"
 done
