@@ -859,3 +859,66 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert res["verified"]["ok"] is True and res["verified"]["frames_checked"] == 96  # rank 0's half of the 192 frames
     g = res["verified"]["gathered"]
     assert g["ok"] is True and g["frames_checked"] == 192, g
+
+
+def test_pooled_blocks_are_recycled_and_results_stay_exact(gpu, oracle):
+    """A batch per image set is the normal use: arenas and pinned staging blocks of destroyed batches serve the next one
+    (BlockPool, ccd_api.cpp).  Thirty create / add / run / all_planes / destroy cycles over streams of different sizes and
+    kinds, a failed decode (its blocks must come back too) and ccd_pool_trim in between: planes always equal the oracle's,
+    device memory does not grow, and a batch may be grown and re-run after a first run."""
+    import torch
+
+    from cool_chic_amd._lib import CcdError, lib
+
+    names = ["rgb192", "kodim14", "yuv420_8b", "bicubic190", "yuv444_10b", "cr192"]
+    cases = []
+    for name in names:
+        bs, z, j = load_golden(name)
+        fh, ccs = oracle.split_stream(bs)[1][0]
+        cases.append((ccs[0], fh.bitdepth, fh.frame_data_type, oracle.decode_video(bs)[0]["planes"]))
+
+    def cycle(sel):
+        b = gpu(0, keep_float=False)
+        try:
+            for i in sel:
+                b.add(*cases[i][0], cases[i][1], cases[i][2])
+            b.run()
+            for planes, i in zip(b.all_planes(), sel):
+                for p, w in zip(planes, cases[i][3]):
+                    assert np.array_equal(p.astype(np.uint16), w)
+        finally:
+            b.close()
+
+    cycle([0, 1, 2])
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(30):
+        cycle([(k + d) % len(cases) for d in range(1 + k % 4)])
+        if k == 10:  # a truncated payload: the slot fails, wait raises, everything still goes back to the pool
+            b = gpu(0)
+            hdr, nn, lat = cases[1][0]
+            b.add(hdr, nn, lat[: len(lat) // 2 // 4 * 4], 8, 0)
+            b.run()
+            with pytest.raises(CcdError):
+                b.wait()
+            with pytest.raises(CcdError):
+                b.planes(0)  # a failed slot's planes are never handed out
+            b.close()
+        if k == 20:
+            lib().ccd_pool_trim(0)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 256 << 20, f"device memory grew by {(free0 - free1) >> 20} MiB over 30 batches"
+    # a batch that grows after its first run: tables are rebuilt, earlier slots decode as before
+    b = gpu(0)
+    try:
+        b.add(*cases[0][0], cases[0][1], cases[0][2])
+        b.run(); b.wait()
+        b.add(*cases[2][0], cases[2][1], cases[2][2])
+        b.run(); b.wait()
+        for slot, i in ((0, 0), (1, 2)):
+            for p, w in zip(b.planes(slot), cases[i][3]):
+                assert np.array_equal(p.astype(np.uint16), w)
+    finally:
+        b.close()
+    lib().ccd_pool_trim(0)
