@@ -75,10 +75,16 @@ constexpr int kNarrowMaxScale = kScaleOffset;
 constexpr int kIfceFastIn = 12;             // most IFCE input channels (coarser grids) of the register-resident feature pass
 constexpr unsigned kSpinLimit = 1u << 27;   // bounded spins: a lost hand-over becomes an error, not a hang
 
-// exp(x) for x <= 0 in f64: range reduction by ln 2 (two-part constant) + degree-13 Taylor/Horner.
-// Error ~1 ulp; what matters is floor(16777088 * cdf), which tests/test_gpu_parity.py compares
-// against libm over millions of reachable arguments.
-__device__ __forceinline__ double exp_nonpos(double x) {
+// exp(x) / 2 for x <= 0 in f64, the way glibc does it: x = (128 k' + j) ln2 / 128 + r with |r| <= ln2 / 256, e^x = 2^k' * T[j] *
+// (1 + r + r^2/2 + .. + r^5/120) with T[j] = 2^(j/128) from a 1 KB table (LDS in the kernel), two-part ln2 / 128.  13 f64
+// operations and a Horner chain of depth 4 instead of 21 and depth 7 for the table-free degree-13 version it replaced
+// (-DCCD_EXP_POLY13 keeps that one for A/B).  Error ~1 ulp; what matters is floor(16777088 * cdf), and THAT is proven on the
+// whole reachable domain: tools/cdf_sweep.py compares all 1.0658e10 boundaries with libm (profiles/r03/cdf_sweep.log).
+__device__ const double kExpTab[128] = {
+#include "ccd_exp_table.inc"
+};
+#ifdef CCD_EXP_POLY13
+__device__ __forceinline__ double exp_nonpos(double x, const double*) {
     // branch-free on purpose: four of these chains are interleaved by the table builder
     const bool tiny = x < -60.0;  // below 2^-86: contributes nothing to a 24-bit cumulative, and 1 - e/2 == 1
     x = tiny ? -60.0 : x;
@@ -102,19 +108,42 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     pe = fma(pe, r2, 0.5);                        // 1/2!
     po = fma(po, r2, 1.0);                        // 1/1!
     pe = fma(pe, r2, 1.0);                        // 1/0!
-    const double e = ldexp(fma(po, r, pe), static_cast<int>(k));
+    const double e = ldexp(fma(po, r, pe), static_cast<int>(k) - 1);
     return tiny ? 0.0 : e;
 }
+#else
+__device__ __forceinline__ double exp_nonpos(double x, const double* tab /* 2^(j/128): LDS in the kernel */) {
+    // branch-free on purpose: several of these chains are interleaved by the table builder
+    const bool tiny = x < -60.0;  // below 2^-86: contributes nothing to a 24-bit cumulative, and 1 - e/2 == 1
+    x = tiny ? -60.0 : x;
+    const double kd = rint(x * 0x1.71547652b82fep+7);            // 128 / ln 2
+    double r = fma(kd, -0x1.62e42fef00000p-8, x);                // ln 2 / 128, leading 33 bits: kd * hi is exact
+    r = fma(kd, -0x1.473de6af278edp-41, r);
+    const int ki = static_cast<int>(kd);
+    const double t = tab[ki & 127];
+    const double r2 = r * r;
+    double p = fma(r, 8.333333333333333e-03, 4.1666666666666664e-02);  // 1/5!, 1/4!
+    p = fma(p, r, 1.6666666666666666e-01);
+    p = fma(p, r, 0.5);
+    p = fma(p, r2, r);                                            // e^r - 1
+    const double e = ldexp(fma(t, p, t), (ki >> 7) - 1);           // e^x / 2 (the caller's 0.5 *, folded into the exponent)
+    return tiny ? 0.0 : e;
+}
+#endif
 
 // Left cumulative of symbol s; b and rcp = RN(1 / b): the quotient (x - mu) / b is formed with one
 // Newton correction, which is the correctly rounded quotient (Markstein) for these operands.
-__device__ __forceinline__ uint32_t window_left(double mu, double b, double rcp, int s) {
+__device__ __forceinline__ uint32_t window_left(double mu, double b, double rcp, int s, const double* exp_tab) {
     const double x = static_cast<double>(s) - 0.5;
     const bool below = x <= mu;
     const double a = below ? (x - mu) : (mu - x);  // <= 0
     const double q0 = a * rcp;
+#ifdef CCD_X_NOMARK
+    const double q = q0;
+#else
     const double q = fma(fma(-q0, b, a), rcp, q0);
-    const double e = 0.5 * exp_nonpos(q);
+#endif
+    const double e = exp_nonpos(q, exp_tab);  // e^q / 2
     const double cdf = below ? e : 1.0 - e;
     const uint32_t v = static_cast<uint32_t>(16777088.0 * cdf) + static_cast<uint32_t>(s - kAcLo);
     return s <= kAcLo ? 0u : (s > kAcLo + kAlphabet - 1 ? (1u << kRcPrecision) : v);
@@ -147,6 +176,7 @@ struct PipeCtx {
     LdsRef<RowMeta> s_meta;
     LdsRef<const double> s_rcp;   // [kNumScale] RN(1 / b): LDS copies of the two Laplace-scale tables (a global load per
     LdsRef<const float> s_scale;  // [kNumScale] b        pixel would put an L2 round trip on every task's critical path)
+    LdsRef<const double> s_exp;   // [128] 2^(j/128), the table of exp_nonpos
     LdsRef<int32_t> s_w;          // transposed int32 weights Wt[out][in_pad]
     LdsRef<int64_t> s_b;          // biases: hidden layers, output (2), stabiliser (2)
     LdsRef<int32_t> s_act;        // [kProducers][8][in_pad] (a task holds at most 8 pixels); [kProducers][16][in_pad] with MF
@@ -586,7 +616,13 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 // ---- a full 16-symbol batch, unrolled: the three copies of the loop above in rotation without the index arithmetic, the
                 // bound test and the branch (a lone wave issues in order: every instruction between two symbols lengthens the chain);
                 // rows are addressed with immediate offsets from the batch's first row.  Anything unusual (renormalisation, sentinel)
-                // leaves through a trampoline that restores the loop's conventions (i, v50) and continues in the loop.
+                // leaves through a trampoline that restores the loop's conventions (i, v50, range registers) and continues in the loop.
+                // r03 (tools/ubench/dloop_spec_alt.hip: 132.3 against 143.8 ticks per symbol): the lane search writes EXEC
+                // (v_cmpx; the e32 form also writes VCC) and four v_readfirstlane take the hit lane's products - no s_ff1 ->
+                // SGPR-indexed v_readlane on the chain; the VALU write of EXEC needs 4 wait states before v_readfirstlane, filled
+                // with the scale * P products, the s_ff1 (lane index for the bookkeeping only) and the v_writelane (which ignores
+                // EXEC; a symbol that then leaves through a trampoline is written again by its handler).  The range alternates
+                // between s[52:53] (even symbols) and s[48:49] (odd): no copy of the new range; odd trampolines swap them back.
                 ".p2align 6\n\t"
                 "80:\n\t"
                 "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
@@ -594,316 +630,322 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
                 "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
                 "v_mad_u32_u24 v49, v41, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
+                "v_writelane_b32 %[raw], s44, 0\n\t"
+                "v_readfirstlane_b32 s48, v48\n\t"
+                "v_readfirstlane_b32 s49, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
                 "s_cbranch_scc1 81f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 0\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
                 "ds_read_b64 v[40:41], v50 offset:1536\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
                 "v_mad_u32_u24 v45, v42, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
                 "v_mad_u32_u24 v49, v43, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
+                "v_writelane_b32 %[raw], s44, 1\n\t"
+                "v_readfirstlane_b32 s52, v48\n\t"
+                "v_readfirstlane_b32 s53, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "s_cmp_eq_u32 s53, 0\n\t"
                 "s_cbranch_scc1 82f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 1\n\t"
                 "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
                 "ds_read_b64 v[42:43], v50 offset:2048\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
                 "v_mad_u32_u24 v45, v46, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
                 "v_mad_u32_u24 v49, v47, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
+                "v_writelane_b32 %[raw], s44, 2\n\t"
+                "v_readfirstlane_b32 s48, v48\n\t"
+                "v_readfirstlane_b32 s49, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
                 "s_cbranch_scc1 83f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 2\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
                 "ds_read_b64 v[46:47], v50 offset:2560\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
                 "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
                 "v_mad_u32_u24 v49, v41, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
+                "v_writelane_b32 %[raw], s44, 3\n\t"
+                "v_readfirstlane_b32 s52, v48\n\t"
+                "v_readfirstlane_b32 s53, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "s_cmp_eq_u32 s53, 0\n\t"
                 "s_cbranch_scc1 84f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 3\n\t"
                 "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
                 "ds_read_b64 v[40:41], v50 offset:3072\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
                 "v_mad_u32_u24 v45, v42, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
                 "v_mad_u32_u24 v49, v43, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
+                "v_writelane_b32 %[raw], s44, 4\n\t"
+                "v_readfirstlane_b32 s48, v48\n\t"
+                "v_readfirstlane_b32 s49, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
                 "s_cbranch_scc1 85f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 4\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
                 "ds_read_b64 v[42:43], v50 offset:3584\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
                 "v_mad_u32_u24 v45, v46, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
                 "v_mad_u32_u24 v49, v47, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
+                "v_writelane_b32 %[raw], s44, 5\n\t"
+                "v_readfirstlane_b32 s52, v48\n\t"
+                "v_readfirstlane_b32 s53, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "s_cmp_eq_u32 s53, 0\n\t"
                 "s_cbranch_scc1 86f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 5\n\t"
                 "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
                 "ds_read_b64 v[46:47], v50 offset:4096\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
                 "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
                 "v_mad_u32_u24 v49, v41, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
+                "v_writelane_b32 %[raw], s44, 6\n\t"
+                "v_readfirstlane_b32 s48, v48\n\t"
+                "v_readfirstlane_b32 s49, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
                 "s_cbranch_scc1 87f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 6\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
                 "ds_read_b64 v[40:41], v50 offset:4608\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
                 "v_mad_u32_u24 v45, v42, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
                 "v_mad_u32_u24 v49, v43, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
+                "v_writelane_b32 %[raw], s44, 7\n\t"
+                "v_readfirstlane_b32 s52, v48\n\t"
+                "v_readfirstlane_b32 s53, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "s_cmp_eq_u32 s53, 0\n\t"
                 "s_cbranch_scc1 88f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 7\n\t"
                 "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
                 "ds_read_b64 v[42:43], v50 offset:5120\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
                 "v_mad_u32_u24 v45, v46, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
                 "v_mad_u32_u24 v49, v47, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
+                "v_writelane_b32 %[raw], s44, 8\n\t"
+                "v_readfirstlane_b32 s48, v48\n\t"
+                "v_readfirstlane_b32 s49, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
                 "s_cbranch_scc1 89f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 8\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
                 "ds_read_b64 v[46:47], v50 offset:5632\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
                 "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
                 "v_mad_u32_u24 v49, v41, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
+                "v_writelane_b32 %[raw], s44, 9\n\t"
+                "v_readfirstlane_b32 s52, v48\n\t"
+                "v_readfirstlane_b32 s53, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "s_cmp_eq_u32 s53, 0\n\t"
                 "s_cbranch_scc1 90f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 9\n\t"
                 "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
                 "ds_read_b64 v[40:41], v50 offset:6144\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
                 "v_mad_u32_u24 v45, v42, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
                 "v_mad_u32_u24 v49, v43, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
+                "v_writelane_b32 %[raw], s44, 10\n\t"
+                "v_readfirstlane_b32 s48, v48\n\t"
+                "v_readfirstlane_b32 s49, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
                 "s_cbranch_scc1 91f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 10\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
                 "ds_read_b64 v[42:43], v50 offset:6656\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
                 "v_mad_u32_u24 v45, v46, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
                 "v_mad_u32_u24 v49, v47, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
+                "v_writelane_b32 %[raw], s44, 11\n\t"
+                "v_readfirstlane_b32 s52, v48\n\t"
+                "v_readfirstlane_b32 s53, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "s_cmp_eq_u32 s53, 0\n\t"
                 "s_cbranch_scc1 92f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 11\n\t"
                 "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
                 "ds_read_b64 v[46:47], v50 offset:7168\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
                 "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
                 "v_mad_u32_u24 v49, v41, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
+                "v_writelane_b32 %[raw], s44, 12\n\t"
+                "v_readfirstlane_b32 s48, v48\n\t"
+                "v_readfirstlane_b32 s49, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
                 "s_cbranch_scc1 93f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 12\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
                 "ds_read_b64 v[40:41], v50 offset:7680\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
                 "v_mad_u32_u24 v45, v42, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
                 "v_mad_u32_u24 v49, v43, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
+                "v_writelane_b32 %[raw], s44, 13\n\t"
+                "v_readfirstlane_b32 s52, v48\n\t"
+                "v_readfirstlane_b32 s53, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "s_cmp_eq_u32 s53, 0\n\t"
                 "s_cbranch_scc1 94f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 13\n\t"
                 "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
                 "ds_read_b64 v[42:43], v50 offset:8192\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
                 "v_mad_u32_u24 v45, v46, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
                 "v_mad_u32_u24 v49, v47, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
+                "v_writelane_b32 %[raw], s44, 14\n\t"
+                "v_readfirstlane_b32 s48, v48\n\t"
+                "v_readfirstlane_b32 s49, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
                 "s_cbranch_scc1 95f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 14\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
+                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
                 "ds_read_b64 v[46:47], v50 offset:8704\n\t"
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
                 "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
                 "v_mad_u32_u24 v49, v41, s41, v49\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
+                "v_writelane_b32 %[raw], s44, 15\n\t"
+                "v_readfirstlane_b32 s52, v48\n\t"
+                "v_readfirstlane_b32 s53, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "s_cmp_eq_u32 s53, 0\n\t"
                 "s_cbranch_scc1 96f\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
-                "v_writelane_b32 %[raw], s44, 15\n\t"
                 "s_add_u32 %[i], %[i], 16\n\t"
                 "s_branch 2b\n\t"
                 "81:\n\t"
                 "s_branch 40b\n\t"
                 "82:\n\t"
+                "s_mov_b64 s[42:43], s[52:53]\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_mov_b64 s[48:49], s[42:43]\n\t"
                 "s_add_u32 %[i], %[i], 1\n\t"
                 "s_branch 41b\n\t"
                 "83:\n\t"
                 "s_add_u32 %[i], %[i], 2\n\t"
                 "s_branch 42b\n\t"
                 "84:\n\t"
+                "s_mov_b64 s[42:43], s[52:53]\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_mov_b64 s[48:49], s[42:43]\n\t"
                 "s_add_u32 %[i], %[i], 3\n\t"
                 "v_add_u32 v50, 0x600, v50\n\t"
                 "s_branch 40b\n\t"
@@ -912,6 +954,9 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_add_u32 v50, 0x600, v50\n\t"
                 "s_branch 41b\n\t"
                 "86:\n\t"
+                "s_mov_b64 s[42:43], s[52:53]\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_mov_b64 s[48:49], s[42:43]\n\t"
                 "s_add_u32 %[i], %[i], 5\n\t"
                 "v_add_u32 v50, 0x600, v50\n\t"
                 "s_branch 42b\n\t"
@@ -920,6 +965,9 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_add_u32 v50, 0xc00, v50\n\t"
                 "s_branch 40b\n\t"
                 "88:\n\t"
+                "s_mov_b64 s[42:43], s[52:53]\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_mov_b64 s[48:49], s[42:43]\n\t"
                 "s_add_u32 %[i], %[i], 7\n\t"
                 "v_add_u32 v50, 0xc00, v50\n\t"
                 "s_branch 41b\n\t"
@@ -928,6 +976,9 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_add_u32 v50, 0xc00, v50\n\t"
                 "s_branch 42b\n\t"
                 "90:\n\t"
+                "s_mov_b64 s[42:43], s[52:53]\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_mov_b64 s[48:49], s[42:43]\n\t"
                 "s_add_u32 %[i], %[i], 9\n\t"
                 "v_add_u32 v50, 0x1200, v50\n\t"
                 "s_branch 40b\n\t"
@@ -936,6 +987,9 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_add_u32 v50, 0x1200, v50\n\t"
                 "s_branch 41b\n\t"
                 "92:\n\t"
+                "s_mov_b64 s[42:43], s[52:53]\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_mov_b64 s[48:49], s[42:43]\n\t"
                 "s_add_u32 %[i], %[i], 11\n\t"
                 "v_add_u32 v50, 0x1200, v50\n\t"
                 "s_branch 42b\n\t"
@@ -944,6 +998,9 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_add_u32 v50, 0x1800, v50\n\t"
                 "s_branch 40b\n\t"
                 "94:\n\t"
+                "s_mov_b64 s[42:43], s[52:53]\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_mov_b64 s[48:49], s[42:43]\n\t"
                 "s_add_u32 %[i], %[i], 13\n\t"
                 "v_add_u32 v50, 0x1800, v50\n\t"
                 "s_branch 41b\n\t"
@@ -952,6 +1009,9 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_add_u32 v50, 0x1800, v50\n\t"
                 "s_branch 42b\n\t"
                 "96:\n\t"
+                "s_mov_b64 s[42:43], s[52:53]\n\t"
+                "s_mov_b64 s[52:53], s[48:49]\n\t"
+                "s_mov_b64 s[48:49], s[42:43]\n\t"
                 "s_add_u32 %[i], %[i], 15\n\t"
                 "v_add_u32 v50, 0x1e00, v50\n\t"
                 "s_branch 40b\n\t"
@@ -1032,8 +1092,8 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 }
                 const double mu = -64.0 + static_cast<double>(meta.mu_idx[row0 + pi]) * (1.0 / 256.0);
                 const double b = meta.b[row0 + pi], rcp = meta.rcp[row0 + pi];
-                const uint32_t f0 = window_left(mu, b, rcp, kAcLo + lane);
-                const uint32_t f1 = window_left(mu, b, rcp, kAcLo + 64 + lane);
+                const uint32_t f0 = window_left(mu, b, rcp, kAcLo + lane, C.s_exp);
+                const uint32_t f1 = window_left(mu, b, rcp, kAcLo + 64 + lane, C.s_exp);
                 const unsigned long long m0 = __ballot(scale * f0 <= rc_dist), m1 = __ballot(scale * f1 <= rc_dist);
                 const int sidx = __popcll(m0) + __popcll(m1) - 1;
                 const uint32_t left = uni(static_cast<uint32_t>(__shfl(sidx < 64 ? f0 : f1, sidx & 63)));
@@ -1826,7 +1886,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     top = max(kAcLo + 13, min(kAcLo + kAlphabet - 1, top));
                     const double mu = -64.0 + static_cast<double>(mu_idx) * (1.0 / 256.0);
                     const int ssym = top - (e - 1);  // e = 0 -> top + 1: its left bound is the window's upper edge
-                    uint32_t left = min(window_left(mu, meta.b[mi], meta.rcp[mi], ssym), (1u << kRcPrecision) - 1u);
+                    uint32_t left = min(window_left(mu, meta.b[mi], meta.rcp[mi], ssym, C.s_exp), (1u << kRcPrecision) - 1u);
                     left = e == 15 ? 0u : left;
                     // entry e - 1 of the same 16-lane row (DPP row_shr:1; entry 0 does not use it)
                     const uint32_t right = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(left), 0x111, 0xf, 0xf, false));
@@ -1863,7 +1923,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     const int ssym = top - (lane - 1);
                     // every stored bound must fit 24 bits (v_mad_u32_u24 in the decoder): the upper sentinel of a window that
                     // reaches symbol 63 is clamped to 2^24 - 1; a hit on it only costs a detour through the slow path
-                    uint32_t left = min(window_left(mu, meta.b[mi], meta.rcp[mi], ssym), (1u << kRcPrecision) - 1u);
+                    uint32_t left = min(window_left(mu, meta.b[mi], meta.rcp[mi], ssym, C.s_exp), (1u << kRcPrecision) - 1u);
                     left = lane == 63 ? 0u : left;
                     const uint32_t right = __shfl_up(left, 1);  // lane k-1 holds symbol s+1: its left bound is our right bound
                     uint2 ent;
@@ -1934,8 +1994,11 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     double* s_rcp = reinterpret_cast<double*>(C.s_ring + ring_rows * 64);
     float* s_scale = reinterpret_cast<float*>(s_rcp + kNumScale + 1);
     C.s_rcp = s_rcp; C.s_scale = s_scale;
-    uint32_t* s_sync = reinterpret_cast<uint32_t*>(s_scale + ((kNumScale + 3) & ~3));
+    double* s_exp = reinterpret_cast<double*>(s_scale + ((kNumScale + 3) & ~3));
+    C.s_exp = s_exp;
+    uint32_t* s_sync = reinterpret_cast<uint32_t*>(s_exp + 128);
     for (int i = tid; i < kNumScale; i += kPipeThreads) { s_rcp[i] = P.rcp_table[i]; s_scale[i] = P.scale_table[i]; }
+    if (tid < 128) s_exp[tid] = kExpTab[tid];
     C.s_ready = s_sync;
     C.s_consumed = s_sync + kSlots;
     C.s_abort = C.s_consumed + 1;
@@ -2212,7 +2275,7 @@ size_t entropy_pipe_lds_bytes(int dim, int n_layers, int ring_rows, int mfma) {
     n += static_cast<size_t>(kProducers) * (mfma ? 16 : 8) * in_pad * 4;
     if (mfma) n += static_cast<size_t>(mf_tables(n_layers)) * 1024;
     n += static_cast<size_t>(ring_rows) * 64;
-    n += static_cast<size_t>(kNumScale + 1) * 8 + static_cast<size_t>((kNumScale + 3) & ~3) * 4;
+    n += static_cast<size_t>(kNumScale + 1) * 8 + static_cast<size_t>((kNumScale + 3) & ~3) * 4 + 128 * 8;
     n += (kSlots + 8) * 4;
     return (n + 15) & ~size_t{15};
 }
@@ -2251,7 +2314,7 @@ __global__ void laplace_sweep_pipe_kernel(const float* scale_table, const double
         const int64_t r = i / 127;
         const int mu_idx = static_cast<int>(r % kNumMu), c = scale_first + static_cast<int>(r / kNumMu);
         const double mu = -64.0 + static_cast<double>(mu_idx) * (1.0 / 256.0);
-        out[i] = window_left(mu, static_cast<double>(scale_table[c]), rcp_table[c], s);
+        out[i] = window_left(mu, static_cast<double>(scale_table[c]), rcp_table[c], s, kExpTab);
     }
 }
 hipError_t launch_laplace_sweep_pipe(const float* scale_table, const double* rcp_table, int scale_first, int n_scales, uint32_t* out, hipStream_t stream) {
