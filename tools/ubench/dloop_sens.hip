@@ -45,6 +45,89 @@
 
 #endif
 // production body of symbol J (row in CL / CP, prefetch of row J + 2 into NXT at OFF): entry VAL##J is behind the prefetch
+#ifdef ALT
+// RIN = pair holding the current range, ROUT = pair that receives the new one (roles swap every symbol)
+#ifdef LANEID
+#define BOOK(J) "s_nop 1\n\t"
+#define BOOK2(J) "v_readfirstlane_b32 s44, %[lid]\n\t"
+#define BOOK3(J) "v_writelane_b32 %[raw], s44, " #J "\n\t"
+#elif defined(NOBOOK)
+#define BOOK2(J)
+#define BOOK3(J)
+#define BOOK(J) "s_nop 1\n\t"
+#else
+#define BOOK2(J)
+#define BOOK3(J)
+#define BOOK(J) "s_ff1_i32_b64 s44, vcc\n\tv_writelane_b32 %[raw], s44, " #J "\n\t"
+#endif
+#ifdef NOBR
+#define RARE(H)
+#else
+#define RARE(H) "s_cmp_eq_u32 " H ", 0\n\ts_cbranch_scc1 rare_%=\n\t"
+#endif
+#ifdef NOHI
+#define NOPFILL "s_nop 0\n\t"
+#define HI_L(CL)
+#define HI_P(CP)
+#else
+#define NOPFILL
+#define HI_L(CL) "v_mad_u32_u24 v45, " CL ", s41, v45\n\t"
+#define HI_P(CP) "v_mad_u32_u24 v49, " CP ", s41, v49\n\t"
+#endif
+#ifdef PRELOAD
+#define FETCH(NXT, OFF)
+#define ROWL(J, CL) "v" STR2(64 + 2 * J)
+#define ROWP(J, CP) "v" STR2(65 + 2 * J)
+#else
+#ifdef NOFETCH
+#define FETCH(NXT, OFF)
+#else
+#define FETCH(NXT, OFF) "ds_read_b64 " NXT ", v50 offset:" OFF "\n\ts_waitcnt lgkmcnt(2)\n\t"
+#endif
+#define ROWL(J, CL) CL
+#define ROWP(J, CP) CP
+#endif
+#define VBODY2(J, CL, CP, NXT, OFF, RIN, RINHI, ROUT_LO, ROUT_HI)     \
+    "s_lshr_b64 s[40:41], " RIN ", 24\n\t"                            \
+    FETCH(NXT, OFF)                                                   \
+    "val" #J "_%=:\n\t"                                               \
+    "v_mad_u64_u32 v[44:45], s[42:43], s40, " CL ", 0\n\t"            \
+    HI_L(CL)                                                          \
+    "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"                       \
+    "v_mad_u64_u32 v[48:49], s[42:43], s40, " CP ", 0\n\t"            \
+    HI_P(CP)                                                          \
+    BOOK(J)                                                           \
+    NOPFILL                                                           \
+    "v_readfirstlane_b32 " ROUT_LO ", v48\n\t"                        \
+    "v_readfirstlane_b32 " ROUT_HI ", v49\n\t"                        \
+    "v_readfirstlane_b32 s46, v44\n\t"                                \
+    "v_readfirstlane_b32 s47, v45\n\t"                                \
+    BOOK2(J)                                                          \
+    "s_mov_b64 exec, -1\n\t"                                          \
+    RARE(ROUT_HI)                                                     \
+    "s_sub_u32 s50, s50, s46\n\t"                                     \
+    "s_subb_u32 s51, s51, s47\n\t"                                    \
+    BOOK3(J)
+#define VBODY(J, CL, CP, NXT, OFF) VBODY_##J(CL, CP, NXT, OFF)
+#define VB_E(J, CL, CP, NXT, OFF) VBODY2(J, CL, CP, NXT, OFF, "s[52:53]", "s53", "s54", "s55")
+#define VB_O(J, CL, CP, NXT, OFF) VBODY2(J, CL, CP, NXT, OFF, "s[54:55]", "s55", "s52", "s53")
+#define VBODY_0(a,b,c,d) VB_E(0,a,b,c,d)
+#define VBODY_1(a,b,c,d) VB_O(1,a,b,c,d)
+#define VBODY_2(a,b,c,d) VB_E(2,a,b,c,d)
+#define VBODY_3(a,b,c,d) VB_O(3,a,b,c,d)
+#define VBODY_4(a,b,c,d) VB_E(4,a,b,c,d)
+#define VBODY_5(a,b,c,d) VB_O(5,a,b,c,d)
+#define VBODY_6(a,b,c,d) VB_E(6,a,b,c,d)
+#define VBODY_7(a,b,c,d) VB_O(7,a,b,c,d)
+#define VBODY_8(a,b,c,d) VB_E(8,a,b,c,d)
+#define VBODY_9(a,b,c,d) VB_O(9,a,b,c,d)
+#define VBODY_10(a,b,c,d) VB_E(10,a,b,c,d)
+#define VBODY_11(a,b,c,d) VB_O(11,a,b,c,d)
+#define VBODY_12(a,b,c,d) VB_E(12,a,b,c,d)
+#define VBODY_13(a,b,c,d) VB_O(13,a,b,c,d)
+#define VBODY_14(a,b,c,d) VB_E(14,a,b,c,d)
+#define VBODY_15(a,b,c,d) VB_O(15,a,b,c,d)
+#else
 #define VBODY(J, CL, CP, NXT, OFF)                                    \
     "s_lshr_b64 s[40:41], s[52:53], 24\n\t"                           \
     "ds_read_b64 " NXT ", v50 offset:" OFF "\n\t"                     \
@@ -60,6 +143,7 @@
     "s_subb_u32 s51, s51, s47\n\t"                                    \
     "v_writelane_b32 %[raw], s44, " #J "\n\t"
 
+#endif
 // speculative body of symbol J: (L, P) of its row's lane 7 in (SL, SP); reads the next row's into (NL, NP)
 #define SBODY(J, NROWL, NROWP, NXT, OFF, SL, SP, NL, NP)              \
     "s_lshr_b64 s[40:41], s[52:53], 24\n\t"                           \
@@ -160,7 +244,7 @@ __global__ __launch_bounds__(512) void dloop(uint64_t* out, int n_sym, int busy,
                     "s_mov_b64 %[rng], s[52:53]\n\t"
                     "s_waitcnt lgkmcnt(0)\n\t"
                     : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [raw] "+v"(raw), [st] "=s"(status)
-                    : [ta] "v"(taddr)
+                    : [ta] "v"(taddr), [lid] "v"(lane)
                     : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s72", "s73",
                       "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48",
                       "v49", "v50");
@@ -198,8 +282,8 @@ __global__ __launch_bounds__(512) void dloop(uint64_t* out, int n_sym, int busy,
                     "s_mov_b64 %[rng], s[52:53]\n\t"
                     "s_waitcnt lgkmcnt(0)\n\t"
                     : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [raw] "+v"(raw), [st] "=s"(status)
-                    : [ta] "v"(taddr)
-                    : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "v40", "v41", "v42",
+                    : [ta] "v"(taddr), [lid] "v"(lane)
+                    : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "v40", "v41", "v42",
                       "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50");
             }
             if (status) break;
