@@ -446,17 +446,38 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_add_u32 v50, 0x600, v50\n\t"
                 "s_cmp_lt_u32 %[i], s54\n\t"
                 "s_cbranch_scc1 1b\n\t"
-                // ---- batch end: symbols of the batch -> ring + latent grid, hand the slot back, publish progress
+                // ---- batch end.  FIRST what the producers wait for: the symbols into the LDS ring (and the latent grid), the slot's
+                // counter back to zero (before anybody may count a part of its next batch in), progress published - a producer
+                // task's late part hangs on `consumed`, and where the producers are the limit (every short-step grid, grid 0 of a
+                // portrait picture) each tick between the last symbol and this store is a tick of the critical path.  (r02 had the
+                // next batch's request in front: ~130 ticks.)
                 "2:\n\t"
+                "s_sub_u32 s58, s54, 1\n\t"
+                "s_and_b32 s58, s58, s62\n\t"
+                "s_add_u32 s58, s58, 1\n\t"
+                "v_cmp_gt_u32 vcc, s58, %[lane]\n\t"
+                "s_and_saveexec_b64 s[60:61], vcc\n\t"
+                "v_sub_u32 v52, %[top], %[raw]\n\t"
+                "v_add_u32 v52, 1, v52\n\t"
+                "v_add_u32 v51, %[ringb], %[ring]\n\t"
+                "ds_write_b8 v51, v52\n\t"
+                "global_store_byte %[goff], v52, %[lat]\n\t"
+                "s_mov_b64 exec, s[60:61]\n\t"
+                "v_mov_b32 v51, s59\n\t"
+                "v_mov_b32 v52, 0\n\t"
+                "ds_write_b32 v51, v52\n\t"
+                "s_add_u32 %[seq], %[seq], 1\n\t"
+                "v_mov_b32 v51, %[cons]\n\t"
+                "v_mov_b32 v52, %[seq]\n\t"
+                "ds_write_b32 v51, v52\n\t"
                 // next batch of this step (if any): its ready counter, top symbols and first two rows are requested now; LDS
                 // answers a wave in order and producers store rows before they count a part in, so a counter that reads
-                // complete vouches for the rows read after it.  The round trips hide behind the epilogue.
+                // complete vouches for the rows read after it.  The round trips hide behind the rest of the epilogue.
                 "s_cmp_lt_u32 %[i], %[n]\n\t"
                 "s_cbranch_scc0 9f\n\t"
                 "s_add_u32 s67, %[i], s69\n\t"
                 "s_min_u32 s67, s67, %[n]\n\t"
-                "s_add_u32 s63, %[seq], 1\n\t"
-                "s_and_b32 s63, s63, %[smask]\n\t"
+                "s_and_b32 s63, %[seq], %[smask]\n\t"
                 "s_lshl_b32 s66, s63, 2\n\t"
                 "s_add_u32 s66, s66, %[rdy]\n\t"
                 "v_mov_b32 v51, s66\n\t"
@@ -474,27 +495,9 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_add_u32 s65, s65, s70\n\t"
                 "s_lshr_b32 s65, s65, %[tshift]\n\t"
                 "9:\n\t"
-                "s_sub_u32 s58, s54, 1\n\t"
-                "s_and_b32 s58, s58, s62\n\t"
-                "s_add_u32 s58, s58, 1\n\t"
-                "v_cmp_gt_u32 vcc, s58, %[lane]\n\t"
-                "s_and_saveexec_b64 s[60:61], vcc\n\t"
-                "v_sub_u32 v52, %[top], %[raw]\n\t"
-                "v_add_u32 v52, 1, v52\n\t"
-                "v_add_u32 v51, %[ringb], %[ring]\n\t"
-                "ds_write_b8 v51, v52\n\t"
-                "global_store_byte %[goff], v52, %[lat]\n\t"
-                "s_mov_b64 exec, s[60:61]\n\t"
                 "v_add_u32 %[ring], s71, %[ring]\n\t"
                 "v_and_b32 %[ring], %[rmask], %[ring]\n\t"
                 "v_add_u32 %[goff], %[gstride], %[goff]\n\t"
-                "v_mov_b32 v51, s59\n\t"
-                "v_mov_b32 v52, 0\n\t"
-                "ds_write_b32 v51, v52\n\t"
-                "s_add_u32 %[seq], %[seq], 1\n\t"
-                "v_mov_b32 v51, %[cons]\n\t"
-                "v_mov_b32 v52, %[seq]\n\t"
-                "ds_write_b32 v51, v52\n\t"
                 "s_cmp_lt_u32 %[i], %[n]\n\t"
                 "s_cbranch_scc0 10f\n\t"
                 // ---- fast entry into the next batch: everything it needs was requested above
