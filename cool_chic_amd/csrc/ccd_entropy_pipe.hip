@@ -5,8 +5,9 @@
 // hand-over adds ~13 (tools/ubench/lat.hip), so
 //
 //   * wave 0 (the DECODER) runs nothing but the range-decoder recurrence: per symbol one LDS read of
-//     a 64-entry window of cumulatives (L, P = R - L), two multiply-adds, one compare, s_ff1 on the
-//     ballot, three readlanes and ~8 scalar ops.  Symbols outside the window hit a sentinel lane whose
+//     a 64-entry window of cumulatives (L, P = R - L), two multiply-adds, one compare that writes EXEC
+//     (the hit lane becomes the first active one: four v_readfirstlane, no lane search on the chain)
+//     and ~6 scalar ops.  Symbols outside the window hit a sentinel lane whose
 //     P = 0, which makes the new range 0 and so rides the (rare) renormalisation branch into the slow
 //     path - no extra test on the common path;
 //   * waves 1..N-1 (PRODUCERS) run ahead: for each batch of <= 16 pixels of a wavefront diagonal they
