@@ -476,25 +476,27 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 // complete vouches for the rows read after it.  The round trips hide behind the rest of the epilogue.
                 "s_cmp_lt_u32 %[i], %[n]\n\t"
                 "s_cbranch_scc0 9f\n\t"
-                "s_add_u32 s67, %[i], s69\n\t"
-                "s_min_u32 s67, s67, %[n]\n\t"
-                "s_and_b32 s63, %[seq], %[smask]\n\t"
-                "s_lshl_b32 s66, s63, 2\n\t"
-                "s_add_u32 s66, s66, %[rdy]\n\t"
-                "v_mov_b32 v51, s66\n\t"
+                // (straight into the registers the loop uses: the finished batch's are dead by now - its end index, slot, counter
+                // address, rows, top symbols, row base - and a batch that turns out incomplete reloads top and rows after its poll)
+                "s_add_u32 s54, %[i], s69\n\t"
+                "s_min_u32 s54, s54, %[n]\n\t"
+                "s_and_b32 s55, %[seq], %[smask]\n\t"
+                "s_lshl_b32 s59, s55, 2\n\t"
+                "s_add_u32 s59, s59, %[rdy]\n\t"
+                "v_mov_b32 v51, s59\n\t"
                 "ds_read_b32 v54, v51\n\t"
-                "s_lshl_b32 s64, s63, %[bshift]\n\t"
-                "s_lshl_b32 s58, s64, 2\n\t"
+                "s_lshl_b32 s56, s55, %[bshift]\n\t"
+                "s_lshl_b32 s58, s56, 2\n\t"
                 "s_add_u32 s58, s58, %[topb]\n\t"
-                "v_add_u32 v60, s58, %[l4]\n\t"
-                "ds_read_b32 v55, v60\n\t"
-                "s_lshl_b32 s58, s64, 9\n\t"
-                "v_add_u32 v53, s58, %[tabl]\n\t"
-                "ds_read_b64 v[56:57], v53\n\t"
-                "ds_read_b64 v[58:59], v53 offset:512\n\t"
-                "s_sub_u32 s65, s67, %[i]\n\t"
-                "s_add_u32 s65, s65, s70\n\t"
-                "s_lshr_b32 s65, s65, %[tshift]\n\t"
+                "v_add_u32 v53, s58, %[l4]\n\t"
+                "ds_read_b32 %[top], v53\n\t"
+                "s_lshl_b32 s58, s56, 9\n\t"
+                "v_add_u32 v50, s58, %[tabl]\n\t"
+                "ds_read_b64 v[40:41], v50\n\t"
+                "ds_read_b64 v[42:43], v50 offset:512\n\t"
+                "s_sub_u32 s57, s54, %[i]\n\t"
+                "s_add_u32 s57, s57, s70\n\t"
+                "s_lshr_b32 s57, s57, %[tshift]\n\t"
                 "9:\n\t"
                 "v_add_u32 %[ring], s71, %[ring]\n\t"
                 "v_and_b32 %[ring], %[rmask], %[ring]\n\t"
@@ -503,28 +505,12 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_cbranch_scc0 10f\n\t"
                 // ---- fast entry into the next batch: everything it needs was requested above
                 "s_waitcnt lgkmcnt(0)\n\t"
-                "s_mov_b32 s54, s67\n\t"
-                "s_mov_b32 s55, s63\n\t"
-                "s_mov_b32 s56, s64\n\t"
-                "s_mov_b32 s59, s66\n\t"
-                "s_mov_b32 s57, s65\n\t"
-                "v_mov_b32 v50, v53\n\t"
                 "v_readfirstlane_b32 s58, v54\n\t"
-                "s_cmp_eq_u32 s58, s65\n\t"
-                "s_cbranch_scc1 13f\n\t"
-                // not complete when asked: poll it like a batch entered from the top (the early copies of top / rows are stale)
-                "v_mov_b32 v51, s59\n\t"
-                "v_mov_b32 v53, v60\n\t"
+                "s_cmp_eq_u32 s58, s57\n\t"
+                "s_cbranch_scc1 19b\n\t"
+                // not complete when asked: poll it like a batch entered from the top (v51 = its counter, v53 = its top symbols)
                 "s_mov_b32 s68, 0\n\t"
                 "s_branch 11b\n\t"
-                "13:\n\t"
-                "v_mov_b32 %[top], v55\n\t"
-                "v_mov_b32 %[raw], 0\n\t"
-                "v_mov_b32 v40, v56\n\t"
-                "v_mov_b32 v41, v57\n\t"
-                "v_mov_b32 v42, v58\n\t"
-                "v_mov_b32 v43, v59\n\t"
-                "s_branch 19b\n\t"
                 "10:\n\t"
                 "s_mov_b32 %[st], 0\n\t"
                 "s_branch 4f\n\t"
