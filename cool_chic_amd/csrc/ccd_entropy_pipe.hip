@@ -378,15 +378,16 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
                 "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
                 "v_mad_u32_u24 v49, v41, s41, v49\n\t"
                 "s_and_b32 m0, %[i], s62\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
+                "v_readfirstlane_b32 s48, v48\n\t"
+                "v_readfirstlane_b32 s49, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
                 "s_cbranch_scc1 40f\n\t"
                 "s_mov_b64 s[52:53], s[48:49]\n\t"
@@ -403,15 +404,16 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
                 "v_mad_u32_u24 v45, v42, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
                 "v_mad_u32_u24 v49, v43, s41, v49\n\t"
                 "s_and_b32 m0, %[i], s62\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
+                "v_readfirstlane_b32 s48, v48\n\t"
+                "v_readfirstlane_b32 s49, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
                 "s_cbranch_scc1 41f\n\t"
                 "s_mov_b64 s[52:53], s[48:49]\n\t"
@@ -428,15 +430,16 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_waitcnt lgkmcnt(2)\n\t"
                 "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
                 "v_mad_u32_u24 v45, v46, s41, v45\n\t"
-                "v_cmp_ge_u64 vcc, s[50:51], v[44:45]\n\t"
+                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
                 "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
                 "v_mad_u32_u24 v49, v47, s41, v49\n\t"
                 "s_and_b32 m0, %[i], s62\n\t"
                 "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_readlane_b32 s48, v48, s44\n\t"
-                "v_readlane_b32 s49, v49, s44\n\t"
-                "v_readlane_b32 s46, v44, s44\n\t"
-                "v_readlane_b32 s47, v45, s44\n\t"
+                "v_readfirstlane_b32 s48, v48\n\t"
+                "v_readfirstlane_b32 s49, v49\n\t"
+                "v_readfirstlane_b32 s46, v44\n\t"
+                "v_readfirstlane_b32 s47, v45\n\t"
+                "s_mov_b64 exec, -1\n\t"
                 "s_cmp_eq_u32 s49, 0\n\t"
                 "s_cbranch_scc1 42f\n\t"
                 "s_mov_b64 s[52:53], s[48:49]\n\t"
