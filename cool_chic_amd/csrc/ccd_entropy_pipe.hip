@@ -1455,7 +1455,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // the first layer on them BEFORE the left neighbour is decoded, and only adds that one term afterwards: the
                 // critical path from "symbol decoded" to "table ready" loses the gather and a third of the MLP.
                 const bool split = k_left >= 0 && !it.raster && n_layers >= 2;
-                uint32_t need = seq >= static_cast<uint32_t>(kNSlots) ? seq - kNSlots + 1 : 0;  // slot free again (table / meta rows)
+                const uint32_t need_slot = seq >= static_cast<uint32_t>(kNSlots) ? seq - kNSlots + 1 : 0;  // slot free again (table / meta rows)
+                uint32_t need = need_slot;
                 if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev_y0), prev_n - 1) / kBpx) + 1);
                 need = max(need, seq_base);
                 uint32_t need_early = seq_base;
@@ -1643,11 +1644,25 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 #endif
                 {
                     const unsigned long long t0 = PROF_T();
-                    if (!wait_ge(C.s_consumed, split ? need_early : need, C.s_abort)) { ok = false; break; }
+                    // (the early wait includes "slot free again": true long ago whenever it is looked at - the slot was last used
+                    // kNSlots batches back - and it lets the table rows' tails be cleared before the late wait, see below)
+                    if (!wait_ge(C.s_consumed, split ? max(need_early, need_slot) : need, C.s_abort)) { ok = false; break; }
                     PROF_ADD(prof[0], t0);
                 }
                 lt_b = LPROF_T(pw == 0);
                 const unsigned long long t_g = PROF_T();
+                // ---- entries 16..63 of the task's table rows: lower sentinels of a narrow window (P = 0).  Written now, off the
+                // late path: a row that turns out wide overwrites all 64 entries later.  cnt rows x 24 16-byte stores.
+                {
+                    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 z4 = {0u, 0u, 0u, 0u};
+                    uint2* const tab0 = C.s_tab + static_cast<size_t>(slot * kBpx + half * kTaskPix) * 64;
+#pragma unroll
+                    for (int j = 0; j < (kTaskPix * 24 + 63) / 64; ++j) {
+                        const int t = lane + 64 * j, row = t / 24, e2 = t - 24 * row;
+                        if (row < cnt) *reinterpret_cast<u32x4*>(&tab0[row * 64 + 16 + 2 * e2]) = z4;
+                    }
+                }
                 // ---- gather: lane q of the pixel's group fetches inputs k = q, q + 8, ... --------------------------
                 if (px < cnt) {
 #pragma unroll
@@ -1890,8 +1905,9 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         tab[mine * 64 + e] = ent;
                         if (e == 0) meta.top[mi] = top;
                     }
-                    // entries 16..63 of the (up to) four rows: lower sentinels (4 rows x 24 16-byte stores)
-                    {
+                    // entries 16..63 of the (up to) four rows: lower sentinels (4 rows x 24 16-byte stores); the vector-ALU path
+                    // cleared them before its late wait
+                    if constexpr (MF) {
                         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                         const u32x4 z4 = {0u, 0u, 0u, 0u};
 #pragma unroll
