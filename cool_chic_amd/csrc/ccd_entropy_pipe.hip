@@ -1874,7 +1874,33 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // Wide pixels: 62 real symbols, one pixel per pass.
                 const int base = slot * kBpx + half * kTaskPix;  // first table row of the task
                 uint2* tab = C.s_tab + static_cast<size_t>(base) * 64;
-                unsigned rest = narrow_mask;
+                if constexpr (!MF) {
+                    // Static layout: pass k builds the 14-symbol windows of pixels 4 k .. 4 k + 3, narrow or not (99.3 % are;
+                    // the row of a wide pixel is rewritten in full below) - no bit-scanning of the mask on the late path.
+                    for (int p4 = 0; p4 < cnt; p4 += 4) {
+                        const int u = lane >> 4, e = lane & 15;
+                        const int mine = p4 + u;
+                        const bool valid = mine < cnt;
+                        const int mi = base + (valid ? mine : p4);
+                        const int mu_idx = meta.mu_idx[mi];
+                        int top = ((mu_idx + 128) >> 8) - 64 + 6;  // round(mu) + 6: window = [round(mu) - 7, round(mu) + 6]
+                        top = max(kAcLo + 13, min(kAcLo + kAlphabet - 1, top));
+                        const double mu = -64.0 + static_cast<double>(mu_idx) * (1.0 / 256.0);
+                        const int ssym = top - (e - 1);  // e = 0 -> top + 1: its left bound is the window's upper edge
+                        uint32_t left = min(window_left(mu, meta.b[mi], meta.rcp[mi], ssym, C.s_exp), (1u << kRcPrecision) - 1u);
+                        left = e == 15 ? 0u : left;
+                        // entry e - 1 of the same 16-lane row (DPP row_shr:1; entry 0 does not use it)
+                        const uint32_t right = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(left), 0x111, 0xf, 0xf, false));
+                        uint2 ent;
+                        ent.x = left;
+                        ent.y = (e == 0 || e == 15) ? 0u : ((e == 1 && ssym == kAcLo + kAlphabet - 1) ? (1u << kRcPrecision) - left : right - left);
+                        if (valid) {
+                            tab[mine * 64 + e] = ent;
+                            if (e == 0) meta.top[mi] = top;
+                        }
+                    }
+                }
+                unsigned rest = MF ? narrow_mask : 0u;
                 while (rest) {
                     // up to four narrow pixels: sub-wave u = lane >> 4 handles pixel pix[u], entry e = lane & 15.  (Both passes of an
                     // 8-pixel task as two interleaved chains per lane were tried: slower - a pass is bound by the issue rate of its
@@ -1942,7 +1968,11 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     tab[i * 64 + lane] = ent;
                     if (lane == 0) meta.top[mi] = top;
                 }
-                if (lane == 0) __hip_atomic_fetch_add(&C.s_ready[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // LDS requests of one wave are performed in order: a relaxed add issued behind the table stores is enough for the
+                // decoder (a release would first wait for every outstanding LDS and global access of the wave)
+                asm volatile("" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&C.s_ready[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                asm volatile("" ::: "memory");
                 PROF_ADD(prof[3], t_t);
 #if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
                 if (pw == 0) {
