@@ -1463,7 +1463,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 if (prev2_nb > 0) need_early = max(need_early, prev2_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev2_y0), prev2_n - 1) / kBpx) + 1);
                 unsigned long long lt_a = 0, lt_b = 0, lt_c = 0, lt_d = 0;  // level-2 profile stamps
                 (void)lt_a; (void)lt_b; (void)lt_c; (void)lt_d;
-                unsigned narrow_mask = 0;  // bit i: pixel i of the task is narrow (wave-uniform)
+                unsigned narrow_mask = 0;  // matrix-core path: bit i: pixel i of the task is narrow (wave-uniform)
+                unsigned long long wide_lanes = 0ull;  // vector-ALU path: ballot of the log-scale lanes of the pixels that are not
                 RowMeta& meta = *C.s_meta;
                 if constexpr (MF) {
                     const int n = px, g = q;  // lane = 16 g + n: pixel n of the task, K-slot group g of the matrix operands
@@ -1859,9 +1860,9 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     if (lane == 0) atomicAdd(reinterpret_cast<int*>(P.status) + 39, n_redo);  // status[39]: pixels redone (tests)
                 }
                 // bit (px * kLpp + 1) of the ballot: pixel px of the task takes a narrow window (wave-uniform, no LDS trip)
-                const unsigned long long narrow_lanes = __ballot(q == 1 && px < cnt && idx <= kNarrowMaxScale);
-#pragma unroll
-                for (int i = 0; i < kTaskPix; ++i) narrow_mask |= static_cast<unsigned>((narrow_lanes >> (i * kLpp + 1)) & 1ull) << i;
+                // lanes (px * kLpp + 1) of pixels that need the wide window (scale index above kNarrowMaxScale: 0.7 % of the symbols);
+                // the common path only tests the ballot for zero
+                wide_lanes = __ballot(q == 1 && px < cnt && idx > kNarrowMaxScale);
                 PROF_ADD(prof[2], t_m);
                 PROF_ADD(prof[7], t_o);
 #if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE >= 3
@@ -1946,10 +1947,11 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     }
                     (void)n_here;
                 }
-                unsigned wide = ((1u << cnt) - 1u) & ~narrow_mask;
+                unsigned long long wide = MF ? static_cast<unsigned long long>(((1u << cnt) - 1u) & ~narrow_mask) : wide_lanes;
                 while (wide) {
-                    const int i = __builtin_ctz(wide);
+                    const int bit = __builtin_ctzll(wide);
                     wide &= wide - 1;
+                    const int i = MF ? bit : bit / kLpp;  // pixel of the task
                     const int mi = base + i;
                     const int mu_idx = meta.mu_idx[mi];
                     int top = ((mu_idx + 128) >> 8) - 64 + 30;  // round(mu) + 30: window = [round(mu) - 31, round(mu) + 30]
