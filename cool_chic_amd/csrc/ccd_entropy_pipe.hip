@@ -114,11 +114,10 @@ __device__ __forceinline__ double exp_nonpos(double x, const double*) {
 }
 #else
 __device__ __forceinline__ double exp_nonpos(double x, const double* tab /* 2^(j/128): LDS in the kernel */) {
-    // branch-free on purpose: several of these chains are interleaved by the table builder
-    const bool tiny = x < -60.0;  // below 2^-86: contributes nothing to a 24-bit cumulative, and 1 - e/2 == 1
-    x = tiny ? -60.0 : x;
+    // No clamp for very negative x: kd stays finite, 2^(ki >> 7) underflows to an exact 0 in v_ldexp_f64 (and 1 - 0 == 1), which
+    // is what the 24-bit cumulative needs; |x| <= 128 / min scale = 1.9e4 here, far from where ki could overflow.
     const double kd = rint(x * 0x1.71547652b82fep+7);            // 128 / ln 2
-    double r = fma(kd, -0x1.62e42fef00000p-8, x);                // ln 2 / 128, leading 33 bits: kd * hi is exact
+    double r = fma(kd, -0x1.62e42fef00000p-8, x);                // ln 2 / 128, leading 33 bits: kd * hi is exact below 2^20
     r = fma(kd, -0x1.473de6af278edp-41, r);
     const int ki = static_cast<int>(kd);
     const double t = tab[ki & 127];
@@ -127,31 +126,24 @@ __device__ __forceinline__ double exp_nonpos(double x, const double* tab /* 2^(j
     p = fma(p, r, 1.6666666666666666e-01);
     p = fma(p, r, 0.5);
     p = fma(p, r2, r);                                            // e^r - 1
-    const double e = ldexp(fma(t, p, t), (ki >> 7) - 1);           // e^x / 2 (the caller's 0.5 *, folded into the exponent)
-    return tiny ? 0.0 : e;
+    return ldexp(fma(t, p, t), (ki >> 7) - 1);                    // e^x / 2 (the caller's 0.5 *, folded into the exponent)
 }
 #endif
 
-// Left cumulative of symbol s; b and rcp = RN(1 / b): the quotient (x - mu) / b is formed with one
-// Newton correction, which is the correctly rounded quotient (Markstein) for these operands.
-__device__ __forceinline__ uint32_t window_left(double mu, double b, double rcp, int s, const double* exp_tab) {
+// Left cumulative of symbol s under (mu, b) with rcp = RN(1 / b) from the host.  The quotient (x - mu) / b is formed as
+// (x - mu) * rcp WITHOUT the Newton step that would make it the correctly rounded quotient: with or without it, with or
+// without a clamp of very negative arguments, all 1.0658e10 reachable boundaries equal libm's (tools/cdf_sweep.py) - the
+// proof is the enumeration, not the error analysis.
+__device__ __forceinline__ uint32_t window_left(double mu, double rcp, int s, const double* exp_tab) {
     const double x = static_cast<double>(s) - 0.5;
-    const bool below = x <= mu;
-    const double a = below ? (x - mu) : (mu - x);  // <= 0
-    const double q0 = a * rcp;
-#ifdef CCD_X_NOMARK
-    const double q = q0;
-#else
-    const double q = fma(fma(-q0, b, a), rcp, q0);
-#endif
-    const double e = exp_nonpos(q, exp_tab);  // e^q / 2
-    const double cdf = below ? e : 1.0 - e;
+    const double d = x - mu;
+    const double e = exp_nonpos(-fabs(d) * rcp, exp_tab);  // e^(-|x - mu| / b) / 2
+    const double cdf = d <= 0.0 ? e : 1.0 - e;
     const uint32_t v = static_cast<uint32_t>(16777088.0 * cdf) + static_cast<uint32_t>(s - kAcLo);
     return s <= kAcLo ? 0u : (s > kAcLo + kAlphabet - 1 ? (1u << kRcPrecision) : v);
 }
 
 struct alignas(16) RowMeta {  // per table row (= pixel of a batch in flight)
-    double b[kRows];        // Laplace scale (float32 table value widened)
     double rcp[kRows];      // RN(1 / b)
     int32_t mu_idx[kRows];
     int32_t top[kRows];     // symbol of window lane 1
@@ -175,8 +167,8 @@ struct PipeCtx {
     const EntropyParams* P;
     LdsRef<uint2> s_tab;          // [kRows][64] (L, P)
     LdsRef<RowMeta> s_meta;
-    LdsRef<const double> s_rcp;   // [kNumScale] RN(1 / b): LDS copies of the two Laplace-scale tables (a global load per
-    LdsRef<const float> s_scale;  // [kNumScale] b        pixel would put an L2 round trip on every task's critical path)
+    LdsRef<const double> s_rcp;   // [kNumScale] RN(1 / b), b = the float32 Laplace scale of the index, widened: LDS copy of the table
+                                  // (a global load per pixel would put an L2 round trip on every task's critical path)
     LdsRef<const double> s_exp;   // [128] 2^(j/128), the table of exp_nonpos
     LdsRef<int32_t> s_w;          // transposed int32 weights Wt[out][in_pad]
     LdsRef<int64_t> s_b;          // biases: hidden layers, output (2), stabiliser (2)
@@ -1084,9 +1076,9 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                     break;
                 }
                 const double mu = -64.0 + static_cast<double>(meta.mu_idx[row0 + pi]) * (1.0 / 256.0);
-                const double b = meta.b[row0 + pi], rcp = meta.rcp[row0 + pi];
-                const uint32_t f0 = window_left(mu, b, rcp, kAcLo + lane, C.s_exp);
-                const uint32_t f1 = window_left(mu, b, rcp, kAcLo + 64 + lane, C.s_exp);
+                const double rcp = meta.rcp[row0 + pi];
+                const uint32_t f0 = window_left(mu, rcp, kAcLo + lane, C.s_exp);
+                const uint32_t f1 = window_left(mu, rcp, kAcLo + 64 + lane, C.s_exp);
                 const unsigned long long m0 = __ballot(scale * f0 <= rc_dist), m1 = __ballot(scale * f1 <= rc_dist);
                 const int sidx = __popcll(m0) + __popcll(m1) - 1;
                 const uint32_t left = uni(static_cast<uint32_t>(__shfl(sidx < 64 ? f0 : f1, sidx & 63)));
@@ -1629,7 +1621,6 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     const int mpx = slot * kBpx + half * kTaskPix + n;  // table row of the pixel
                     if (g == 0 && live) {
                         meta.mu_idx[mpx] = idx_mu;
-                        meta.b[mpx] = static_cast<double>(C.s_scale[idx_sc]);
                         meta.rcp[mpx] = C.s_rcp[idx_sc];
                     }
                     narrow_mask = static_cast<unsigned>(__ballot(g == 0 && live && idx_sc <= kNarrowMaxScale)) & 0xffffu;
@@ -1825,7 +1816,6 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         if (q == 0) {
                             meta.mu_idx[mpx] = idx;
                         } else {
-                            meta.b[mpx] = static_cast<double>(C.s_scale[idx]);
                             meta.rcp[mpx] = C.s_rcp[idx];
                         }
                     }
@@ -1851,8 +1841,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                             if (q == 0) {
                                 meta.mu_idx[mpx] = idx;
                             } else {
-                                meta.b[mpx] = static_cast<double>(C.s_scale[idx]);
-                                meta.rcp[mpx] = C.s_rcp[idx];
+                                    meta.rcp[mpx] = C.s_rcp[idx];
                             }
                         }
                         ++n_redo;
@@ -1888,7 +1877,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         top = max(kAcLo + 13, min(kAcLo + kAlphabet - 1, top));
                         const double mu = -64.0 + static_cast<double>(mu_idx) * (1.0 / 256.0);
                         const int ssym = top - (e - 1);  // e = 0 -> top + 1: its left bound is the window's upper edge
-                        uint32_t left = min(window_left(mu, meta.b[mi], meta.rcp[mi], ssym, C.s_exp), (1u << kRcPrecision) - 1u);
+                        uint32_t left = min(window_left(mu, meta.rcp[mi], ssym, C.s_exp), (1u << kRcPrecision) - 1u);
                         left = e == 15 ? 0u : left;
                         // entry e - 1 of the same 16-lane row (DPP row_shr:1; entry 0 does not use it)
                         const uint32_t right = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(left), 0x111, 0xf, 0xf, false));
@@ -1921,7 +1910,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     top = max(kAcLo + 13, min(kAcLo + kAlphabet - 1, top));
                     const double mu = -64.0 + static_cast<double>(mu_idx) * (1.0 / 256.0);
                     const int ssym = top - (e - 1);  // e = 0 -> top + 1: its left bound is the window's upper edge
-                    uint32_t left = min(window_left(mu, meta.b[mi], meta.rcp[mi], ssym, C.s_exp), (1u << kRcPrecision) - 1u);
+                    uint32_t left = min(window_left(mu, meta.rcp[mi], ssym, C.s_exp), (1u << kRcPrecision) - 1u);
                     left = e == 15 ? 0u : left;
                     // entry e - 1 of the same 16-lane row (DPP row_shr:1; entry 0 does not use it)
                     const uint32_t right = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(left), 0x111, 0xf, 0xf, false));
@@ -1960,7 +1949,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     const int ssym = top - (lane - 1);
                     // every stored bound must fit 24 bits (v_mad_u32_u24 in the decoder): the upper sentinel of a window that
                     // reaches symbol 63 is clamped to 2^24 - 1; a hit on it only costs a detour through the slow path
-                    uint32_t left = min(window_left(mu, meta.b[mi], meta.rcp[mi], ssym, C.s_exp), (1u << kRcPrecision) - 1u);
+                    uint32_t left = min(window_left(mu, meta.rcp[mi], ssym, C.s_exp), (1u << kRcPrecision) - 1u);
                     left = lane == 63 ? 0u : left;
                     const uint32_t right = __shfl_up(left, 1);  // lane k-1 holds symbol s+1: its left bound is our right bound
                     uint2 ent;
@@ -2033,12 +2022,11 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     const int ring_rows = MF ? P.ring_rows : kRingRows;
     C.ring_mask = ring_rows - 1;
     double* s_rcp = reinterpret_cast<double*>(C.s_ring + ring_rows * 64);
-    float* s_scale = reinterpret_cast<float*>(s_rcp + kNumScale + 1);
-    C.s_rcp = s_rcp; C.s_scale = s_scale;
-    double* s_exp = reinterpret_cast<double*>(s_scale + ((kNumScale + 3) & ~3));
+    C.s_rcp = s_rcp;
+    double* s_exp = s_rcp + kNumScale + 1;
     C.s_exp = s_exp;
     uint32_t* s_sync = reinterpret_cast<uint32_t*>(s_exp + 128);
-    for (int i = tid; i < kNumScale; i += kPipeThreads) { s_rcp[i] = P.rcp_table[i]; s_scale[i] = P.scale_table[i]; }
+    for (int i = tid; i < kNumScale; i += kPipeThreads) s_rcp[i] = P.rcp_table[i];
     if (tid < 128) s_exp[tid] = kExpTab[tid];
     C.s_ready = s_sync;
     C.s_consumed = s_sync + kSlots;
@@ -2316,7 +2304,7 @@ size_t entropy_pipe_lds_bytes(int dim, int n_layers, int ring_rows, int mfma) {
     n += static_cast<size_t>(kProducers) * (mfma ? 16 : 8) * in_pad * 4;
     if (mfma) n += static_cast<size_t>(mf_tables(n_layers)) * 1024;
     n += static_cast<size_t>(ring_rows) * 64;
-    n += static_cast<size_t>(kNumScale + 1) * 8 + static_cast<size_t>((kNumScale + 3) & ~3) * 4 + 128 * 8;
+    n += static_cast<size_t>(kNumScale + 1) * 8 + 128 * 8;
     n += (kSlots + 8) * 4;
     return (n + 15) & ~size_t{15};
 }
@@ -2355,7 +2343,7 @@ __global__ void laplace_sweep_pipe_kernel(const float* scale_table, const double
         const int64_t r = i / 127;
         const int mu_idx = static_cast<int>(r % kNumMu), c = scale_first + static_cast<int>(r / kNumMu);
         const double mu = -64.0 + static_cast<double>(mu_idx) * (1.0 / 256.0);
-        out[i] = window_left(mu, static_cast<double>(scale_table[c]), rcp_table[c], s, kExpTab);
+        out[i] = window_left(mu, rcp_table[c], s, kExpTab);
     }
 }
 hipError_t launch_laplace_sweep_pipe(const float* scale_table, const double* rcp_table, int scale_first, int n_scales, uint32_t* out, hipStream_t stream) {
