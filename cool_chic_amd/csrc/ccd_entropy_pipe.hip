@@ -81,8 +81,17 @@ constexpr unsigned kSpinLimit = 1u << 27;   // bounded spins: a lost hand-over b
 // operations and a Horner chain of depth 4 instead of 21 and depth 7 for the table-free degree-13 version it replaced
 // (-DCCD_EXP_POLY13 keeps that one for A/B).  Error ~1 ulp; what matters is floor(16777088 * cdf), and THAT is proven on the
 // whole reachable domain: tools/cdf_sweep.py compares all 1.0658e10 boundaries with libm (profiles/r03/cdf_sweep.log).
-__device__ const double kExpTab[128] = {
-#include "ccd_exp_table.inc"
+#ifndef CCD_EXP_LOG
+#define CCD_EXP_LOG 7
+#endif
+#ifndef CCD_EXP_DEG
+#define CCD_EXP_DEG 5
+#endif
+#ifndef CCD_EXP_INC
+#define CCD_EXP_INC "ccd_exp_table.inc"
+#endif
+__device__ const double kExpTab[1 << CCD_EXP_LOG] = {
+#include CCD_EXP_INC
 };
 #ifdef CCD_EXP_POLY13
 __device__ __forceinline__ double exp_nonpos(double x, const double*) {
@@ -113,20 +122,30 @@ __device__ __forceinline__ double exp_nonpos(double x, const double*) {
     return tiny ? 0.0 : e;
 }
 #else
-__device__ __forceinline__ double exp_nonpos(double x, const double* tab /* 2^(j/128): LDS in the kernel */) {
-    // No clamp for very negative x: kd stays finite, 2^(ki >> 7) underflows to an exact 0 in v_ldexp_f64 (and 1 - 0 == 1), which
+constexpr int kExpLog = CCD_EXP_LOG, kExpN = 1 << kExpLog;
+__device__ __forceinline__ double exp_nonpos(double x, const double* tab /* 2^(j/N): LDS in the kernel */) {
+    // No clamp for very negative x: kd stays finite, 2^(ki >> log N) underflows to an exact 0 in v_ldexp_f64 (and 1 - 0 == 1), which
     // is what the 24-bit cumulative needs; |x| <= 128 / min scale = 1.9e4 here, far from where ki could overflow.
-    const double kd = rint(x * 0x1.71547652b82fep+7);            // 128 / ln 2
-    double r = fma(kd, -0x1.62e42fef00000p-8, x);                // ln 2 / 128, leading 33 bits: kd * hi is exact below 2^20
-    r = fma(kd, -0x1.473de6af278edp-41, r);
+    const double kd = rint(x * ldexp(0x1.71547652b82fep+0, kExpLog));            // N / ln 2
+    double r = fma(kd, -ldexp(0x1.62e42fef00000p-1, -kExpLog), x);               // ln 2 / N, leading 33 bits: kd * hi is exact below 2^20
+    r = fma(kd, -ldexp(0x1.473de6af278edp-34, -kExpLog), r);
     const int ki = static_cast<int>(kd);
-    const double t = tab[ki & 127];
+    const double t = tab[ki & (kExpN - 1)];
     const double r2 = r * r;
+#if CCD_EXP_DEG == 5
     double p = fma(r, 8.333333333333333e-03, 4.1666666666666664e-02);  // 1/5!, 1/4!
     p = fma(p, r, 1.6666666666666666e-01);
     p = fma(p, r, 0.5);
+#elif CCD_EXP_DEG == 4
+    double p = fma(r, 4.1666666666666664e-02, 1.6666666666666666e-01);
+    p = fma(p, r, 0.5);
+#elif CCD_EXP_DEG == 3
+    double p = fma(r, 1.6666666666666666e-01, 0.5);
+#else
+    double p = 0.5;
+#endif
     p = fma(p, r2, r);                                            // e^r - 1
-    return ldexp(fma(t, p, t), (ki >> 7) - 1);                    // e^x / 2 (the caller's 0.5 *, folded into the exponent)
+    return ldexp(fma(t, p, t), (ki >> kExpLog) - 1);              // e^x / 2 (the caller's 0.5 *, folded into the exponent)
 }
 #endif
 
@@ -282,14 +301,14 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     const int slot_mask = kRows / bpx - 1;       // 8 / 16 slots share the 128 table rows
     const int task_shift = task_pix == 8 ? 3 : (task_pix == 4 ? 2 : 1);
     // LDS byte addresses (the dynamic LDS starts at 0) and per-lane constants of the step loop below
-    const uint32_t ready_base = C.s_ready.off, consumed_addr = C.s_consumed.off, ring_base = C.s_ring.off;
+    const uint32_t ready_base = C.s_ready.off;  // s_consumed sits kSlots words behind it, the ring at LDS address 0 (kernel set-up)
     // the ring has kRingRows rows unless the matrix-core variant needs the LDS (then EntropyParams::ring_rows): a constant
     // here keeps one more SGPR out of the step loop
     const int ring_mask = MF ? uni(C.ring_mask) : kRingRows - 1;
     const uint32_t ring_cells_mask = static_cast<uint32_t>(ring_mask) * 64u + 63u;
     const uint32_t top_base = C.s_meta.off + static_cast<uint32_t>(offsetof(RowMeta, top));
     const uint32_t tab_lane = C.s_tab.off + static_cast<uint32_t>(lane) * 8u;
-    const uint32_t lane_top_off = static_cast<uint32_t>(lane & (bpx - 1)) * 4u;
+    const uint32_t lane_top_off = top_base + static_cast<uint32_t>(lane & (bpx - 1)) * 4u;
     const uint64_t lat_addr = uni(reinterpret_cast<uint64_t>(C.lat));
     const uint32_t glo_stride = static_cast<uint32_t>(bpx * (grid_w - 10));
     const RowMeta& meta = *C.s_meta;
@@ -324,19 +343,14 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_add_u32 s54, %[i], s69\n\t"
                 "s_min_u32 s54, s54, %[n]\n\t"
                 "s_and_b32 s55, %[seq], %[smask]\n\t"
-                "s_lshl_b32 s59, s55, 2\n\t"
-                "s_add_u32 s59, s59, %[rdy]\n\t"
-                "v_mov_b32 v51, s59\n\t"
+                "v_lshl_add_u32 v51, s55, 2, %[rdy]\n\t"
                 "ds_read_b32 v52, v51\n\t"
                 "s_lshl_b32 s56, s55, %[bshift]\n\t"
                 "s_sub_u32 s57, s54, %[i]\n\t"
                 "s_add_u32 s57, s57, s70\n\t"
                 "s_lshr_b32 s57, s57, %[tshift]\n\t"
-                "s_lshl_b32 s58, s56, 9\n\t"
-                "v_add_u32 v50, s58, %[tabl]\n\t"
-                "s_lshl_b32 s58, s56, 2\n\t"
-                "s_add_u32 s58, s58, %[topb]\n\t"
-                "v_add_u32 v53, s58, %[l4]\n\t"
+                "v_lshl_add_u32 v50, s56, 9, %[tabl]\n\t"
+                "v_lshl_add_u32 v53, s56, 2, %[l4]\n\t"
                 "s_mov_b32 s68, 0\n\t"
                 "s_branch 12f\n\t"
                 // bounded spin on the slot's counter (short waits are the rule on short steps); a long wait goes back to the
@@ -442,73 +456,27 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_add_u32 v50, 0x600, v50\n\t"
                 "s_cmp_lt_u32 %[i], s54\n\t"
                 "s_cbranch_scc1 1b\n\t"
-                // ---- batch end.  FIRST what the producers wait for: the symbols into the LDS ring (and the latent grid), the slot's
-                // counter back to zero (before anybody may count a part of its next batch in), progress published - a producer
-                // task's late part hangs on `consumed`, and where the producers are the limit (every short-step grid, grid 0 of a
-                // portrait picture) each tick between the last symbol and this store is a tick of the critical path.  (r02 had the
-                // next batch's request in front: ~130 ticks.)
+                // ---- batch end of the loop above (a partial batch, or one that left the unrolled block).  FIRST what the producers
+                // wait for: the symbols into the LDS ring (and the latent grid), the slot's counter back to zero (before anybody may
+                // count a part of its next batch in), progress published - a producer task's late part hangs on `consumed`, and
+                // where the producers are the limit (every short-step grid, grid 0 of a portrait picture) each tick between the
+                // last symbol and this store is a tick of the critical path.  The ring sits at LDS address 0 (ring cell = address),
+                // v51 still holds the batch's counter address, `consumed` lives kSlots words behind the counters.
                 "2:\n\t"
                 "s_sub_u32 s58, s54, 1\n\t"
                 "s_and_b32 s58, s58, s62\n\t"
                 "s_add_u32 s58, s58, 1\n\t"
-                "v_cmp_gt_u32 vcc, s58, %[lane]\n\t"
-                "s_and_saveexec_b64 s[60:61], vcc\n\t"
+                "s_bfm_b64 exec, s58, 0\n\t"          // lanes below the batch's pixel count
                 "v_sub_u32 v52, %[top], %[raw]\n\t"
                 "v_add_u32 v52, 1, v52\n\t"
-                "v_add_u32 v51, %[ringb], %[ring]\n\t"
-                "ds_write_b8 v51, v52\n\t"
+                "ds_write_b8 %[ring], v52\n\t"
                 "global_store_byte %[goff], v52, %[lat]\n\t"
-                "s_mov_b64 exec, s[60:61]\n\t"
-                "v_mov_b32 v51, s59\n\t"
-                "v_mov_b32 v52, 0\n\t"
-                "ds_write_b32 v51, v52\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "ds_write_b32 v51, %[zero]\n\t"
                 "s_add_u32 %[seq], %[seq], 1\n\t"
-                "v_mov_b32 v51, %[cons]\n\t"
                 "v_mov_b32 v52, %[seq]\n\t"
-                "ds_write_b32 v51, v52\n\t"
-                // next batch of this step (if any): its ready counter, top symbols and first two rows are requested now; LDS
-                // answers a wave in order and producers store rows before they count a part in, so a counter that reads
-                // complete vouches for the rows read after it.  The round trips hide behind the rest of the epilogue.
-                "s_cmp_lt_u32 %[i], %[n]\n\t"
-                "s_cbranch_scc0 9f\n\t"
-                // (straight into the registers the loop uses: the finished batch's are dead by now - its end index, slot, counter
-                // address, rows, top symbols, row base - and a batch that turns out incomplete reloads top and rows after its poll)
-                "s_add_u32 s54, %[i], s69\n\t"
-                "s_min_u32 s54, s54, %[n]\n\t"
-                "s_and_b32 s55, %[seq], %[smask]\n\t"
-                "s_lshl_b32 s59, s55, 2\n\t"
-                "s_add_u32 s59, s59, %[rdy]\n\t"
-                "v_mov_b32 v51, s59\n\t"
-                "ds_read_b32 v54, v51\n\t"
-                "s_lshl_b32 s56, s55, %[bshift]\n\t"
-                "s_lshl_b32 s58, s56, 2\n\t"
-                "s_add_u32 s58, s58, %[topb]\n\t"
-                "v_add_u32 v53, s58, %[l4]\n\t"
-                "ds_read_b32 %[top], v53\n\t"
-                "s_lshl_b32 s58, s56, 9\n\t"
-                "v_add_u32 v50, s58, %[tabl]\n\t"
-                "ds_read_b64 v[40:41], v50\n\t"
-                "ds_read_b64 v[42:43], v50 offset:512\n\t"
-                "s_sub_u32 s57, s54, %[i]\n\t"
-                "s_add_u32 s57, s57, s70\n\t"
-                "s_lshr_b32 s57, s57, %[tshift]\n\t"
-                "9:\n\t"
-                "v_add_u32 %[ring], s71, %[ring]\n\t"
-                "v_and_b32 %[ring], %[rmask], %[ring]\n\t"
-                "v_add_u32 %[goff], %[gstride], %[goff]\n\t"
-                "s_cmp_lt_u32 %[i], %[n]\n\t"
-                "s_cbranch_scc0 10f\n\t"
-                // ---- fast entry into the next batch: everything it needs was requested above
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_readfirstlane_b32 s58, v54\n\t"
-                "s_cmp_eq_u32 s58, s57\n\t"
-                "s_cbranch_scc1 19b\n\t"
-                // not complete when asked: poll it like a batch entered from the top (v51 = its counter, v53 = its top symbols)
-                "s_mov_b32 s68, 0\n\t"
-                "s_branch 11b\n\t"
-                "10:\n\t"
-                "s_mov_b32 %[st], 0\n\t"
-                "s_branch 4f\n\t"
+                "ds_write_b32 %[rdy], v52 offset:64\n\t"
+                "s_branch 22f\n\t"
                 // ---- re-entry after a symbol decoded by the C++ path: i already points behind it
                 "6:\n\t"
                 "s_sub_u32 s58, %[i], 1\n\t"
@@ -517,8 +485,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_add_u32 s54, s58, s69\n\t"
                 "s_min_u32 s54, s54, %[n]\n\t"
                 "s_and_b32 s55, %[seq], %[smask]\n\t"
-                "s_lshl_b32 s59, s55, 2\n\t"
-                "s_add_u32 s59, s59, %[rdy]\n\t"
+                "v_lshl_add_u32 v51, s55, 2, %[rdy]\n\t"
                 "s_lshl_b32 s56, s55, %[bshift]\n\t"
                 "s_sub_u32 s57, %[i], s58\n\t"
                 "s_add_u32 s57, s57, s56\n\t"
@@ -915,7 +882,56 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_sub_u32 s50, s50, s46\n\t"
                 "s_subb_u32 s51, s51, s47\n\t"
                 "s_add_u32 %[i], %[i], 16\n\t"
-                "s_branch 2b\n\t"
+                // ---- end of a full batch: the same hand-over as at 2: with a constant lane mask ...
+                "s_mov_b64 exec, 0xffff\n\t"
+                "v_sub_u32 v52, %[top], %[raw]\n\t"
+                "v_add_u32 v52, 1, v52\n\t"
+                "ds_write_b8 %[ring], v52\n\t"
+                "global_store_byte %[goff], v52, %[lat]\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "ds_write_b32 v51, %[zero]\n\t"
+                "s_add_u32 %[seq], %[seq], 1\n\t"
+                "v_mov_b32 v52, %[seq]\n\t"
+                "ds_write_b32 %[rdy], v52 offset:64\n\t"
+                // ---- ... then the next batch of this step (if any): its ready counter, top symbols and first two rows are requested
+                // straight into the registers the loop uses (the finished batch's are dead by now); LDS answers a wave in order
+                // and producers store rows before they count a part in, so a counter that reads complete vouches for the rows
+                // read after it.  The ring / latent-grid positions advance while the answers travel (a finished step leaves
+                // them: the compiled code sets them per step).
+                "22:\n\t"
+                "s_cmp_lt_u32 %[i], %[n]\n\t"
+                "s_cbranch_scc0 10f\n\t"
+                "s_add_u32 s54, %[i], s69\n\t"
+                "s_min_u32 s54, s54, %[n]\n\t"
+                "s_and_b32 s55, %[seq], %[smask]\n\t"
+                "v_lshl_add_u32 v51, s55, 2, %[rdy]\n\t"
+                "ds_read_b32 v54, v51\n\t"
+                "s_lshl_b32 s56, s55, %[bshift]\n\t"
+                "v_lshl_add_u32 v53, s56, 2, %[l4]\n\t"
+                "ds_read_b32 %[top], v53\n\t"
+                "v_lshl_add_u32 v50, s56, 9, %[tabl]\n\t"
+                "ds_read_b64 v[40:41], v50\n\t"
+                "ds_read_b64 v[42:43], v50 offset:512\n\t"
+                "s_sub_u32 s58, s54, %[i]\n\t"
+                "s_add_u32 s57, s58, s70\n\t"
+                "s_lshr_b32 s57, s57, %[tshift]\n\t"
+                "v_add_u32 %[ring], s71, %[ring]\n\t"
+                "v_and_b32 %[ring], %[rmask], %[ring]\n\t"
+                "v_add_u32 %[goff], %[gstride], %[goff]\n\t"
+                "s_waitcnt lgkmcnt(3)\n\t"          // the counter (the first of the four answers)
+                "v_readfirstlane_b32 s59, v54\n\t"
+                "s_cmp_eq_u32 s59, s57\n\t"
+                "s_cbranch_scc0 23f\n\t"
+                "s_cmp_eq_u32 s58, 16\n\t"
+                "s_cbranch_scc1 80b\n\t"
+                "s_branch 1b\n\t"
+                // not complete when asked: poll it like a batch entered from the top (v51 = its counter, v53 = its top symbols)
+                "23:\n\t"
+                "s_mov_b32 s68, 0\n\t"
+                "s_branch 11b\n\t"
+                "10:\n\t"
+                "s_mov_b32 %[st], 0\n\t"
+                "s_branch 4f\n\t"
                 "81:\n\t"
                 "s_branch 40b\n\t"
                 "82:\n\t"
@@ -1014,7 +1030,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                   [ring] "+v"(v_ring), [goff] "+v"(v_goff), [spins] "+s"(n_spins), [wpos] "+s"(word_pos), [st] "=s"(status), [kr] "=s"(k_rare)
                 : [mode] "s"(mode), [n] "s"(n_step), [smask] "s"(static_cast<uint32_t>(slot_mask)),
                   [bshift] "s"(bpx_shift), [tshift] "s"(static_cast<uint32_t>(task_shift)),
-                  [rdy] "s"(ready_base), [cons] "s"(consumed_addr), [topb] "s"(top_base), [ringb] "s"(ring_base), [rmask] "s"(ring_cells_mask),
+                  [rdy] "v"(ready_base), [zero] "v"(0u), [rmask] "s"(ring_cells_mask),
                   [gstride] "s"(glo_stride), [wbuf] "v"(wbuf), [wbase] "s"(wbase), [tabl] "v"(tab_lane), [lane] "v"(static_cast<uint32_t>(lane)),
                   [l4] "v"(lane_top_off), [lat] "s"(lat_addr)
                 : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
@@ -2008,7 +2024,10 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     PipeCtx C;
     C.P = &P;
     // network first: its addresses stay below 64 KB, so the per-vector offsets fold into the ds_read immediates
-    C.s_w = reinterpret_cast<int32_t*>(smem);
+    const int ring_rows = MF ? P.ring_rows : kRingRows;
+    C.s_ring = reinterpret_cast<int8_t*>(smem);  // LDS address 0: the decoder uses ring cells as addresses
+    C.ring_mask = ring_rows - 1;
+    C.s_w = reinterpret_cast<int32_t*>(smem + ring_rows * 64);
     C.n_w_hidden = (n_layers - 1) * dim * in_pad;
     const int n_w_total = C.n_w_hidden + 4 * in_pad;  // + output layer (2 rows) + stabiliser (2 rows)
     C.s_b = reinterpret_cast<int64_t*>(C.s_w + ((n_w_total + 3) & ~3));
@@ -2018,16 +2037,13 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     C.s_a = reinterpret_cast<uint32_t*>(C.s_act + kProducers * kActRows * in_pad);
     C.s_tab = reinterpret_cast<uint2*>(static_cast<uint32_t*>(C.s_a) + (MF ? mf_tables(n_layers) * 256 : 0));
     C.s_meta = reinterpret_cast<RowMeta*>(C.s_tab + kRows * 64);
-    C.s_ring = reinterpret_cast<int8_t*>(C.s_meta + 1);
-    const int ring_rows = MF ? P.ring_rows : kRingRows;
-    C.ring_mask = ring_rows - 1;
-    double* s_rcp = reinterpret_cast<double*>(C.s_ring + ring_rows * 64);
+    double* s_rcp = reinterpret_cast<double*>(C.s_meta + 1);
     C.s_rcp = s_rcp;
     double* s_exp = s_rcp + kNumScale + 1;
     C.s_exp = s_exp;
-    uint32_t* s_sync = reinterpret_cast<uint32_t*>(s_exp + 128);
+    uint32_t* s_sync = reinterpret_cast<uint32_t*>(s_exp + kExpN);
     for (int i = tid; i < kNumScale; i += kPipeThreads) s_rcp[i] = P.rcp_table[i];
-    if (tid < 128) s_exp[tid] = kExpTab[tid];
+    for (int i = tid; i < kExpN; i += kPipeThreads) s_exp[i] = kExpTab[i];
     C.s_ready = s_sync;
     C.s_consumed = s_sync + kSlots;
     C.s_abort = C.s_consumed + 1;
@@ -2304,7 +2320,7 @@ size_t entropy_pipe_lds_bytes(int dim, int n_layers, int ring_rows, int mfma) {
     n += static_cast<size_t>(kProducers) * (mfma ? 16 : 8) * in_pad * 4;
     if (mfma) n += static_cast<size_t>(mf_tables(n_layers)) * 1024;
     n += static_cast<size_t>(ring_rows) * 64;
-    n += static_cast<size_t>(kNumScale + 1) * 8 + 128 * 8;
+    n += static_cast<size_t>(kNumScale + 1) * 8 + static_cast<size_t>(kExpN) * 8;
     n += (kSlots + 8) * 4;
     return (n + 15) & ~size_t{15};
 }
