@@ -320,14 +320,19 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
         // the file header) and the epilogue (symbols -> LDS ring + latent grid, slot handed back, progress published) without
         // returning to compiled code.  It leaves early for a symbol whose new range has a zero high word (renormalisation,
         // window miss, invalid data: status 1, handled below, then re-entered) and for a batch that is not ready (status 2).
-        const uint32_t n_step = static_cast<uint32_t>(it.n);
+        // The region walks the remaining steps of a wavefront-ordered grid itself (label 30); `it` only sets it up.  A grid
+        // narrower than 10 (raster order, one pixel per step) comes back after every step.
+        uint32_t n_step = static_cast<uint32_t>(it.n), step_x0 = static_cast<uint32_t>(it.x0), step_hy = static_cast<uint32_t>(it.H - it.y0);
+        uint32_t steps_left = it.raster ? 1u : static_cast<uint32_t>(it.n_steps - it.c);
         uint32_t i = 0, mode = 0;
-        // lane p <-> pixel p of the step's first batch; both advance by one batch in the epilogue
-        uint32_t v_ring = static_cast<uint32_t>((((it.y0 + lane) & ring_mask) << 6) | ((it.x0 + 10 * it.y0) & 63));
-        uint32_t v_goff = static_cast<uint32_t>((it.y0 + lane) * grid_w + (it.x0 - 10 * lane));
+        // lane p <-> pixel p of the step's first batch (v_rbase, v_gbase); the working copies advance by one batch in the epilogue
+        uint32_t v_rbase = static_cast<uint32_t>((((it.y0 + lane) & ring_mask) << 6) | ((it.x0 + 10 * it.y0) & 63));
+        uint32_t v_gbase = static_cast<uint32_t>((it.y0 + lane) * grid_w + (it.x0 - 10 * lane));
+        uint32_t v_ring = v_rbase, v_goff = v_gbase;
         while (true) {
             uint32_t status, k_rare;
             i = uni(i); seq = uni(seq); mode = uni(mode); n_spins = uni(n_spins);  // scalar operands of the region below
+            n_step = uni(n_step); step_x0 = uni(step_x0); step_hy = uni(step_hy); steps_left = uni(steps_left);
             asm volatile(
                 "s_mov_b64 s[50:51], %[dst]\n\t"
                 "s_mov_b64 s[52:53], %[rng]\n\t"
@@ -336,6 +341,8 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_lshl_b32 s70, 1, %[tshift]\n\t"
                 "s_sub_u32 s70, s70, 1\n\t"           // pixels per task - 1
                 "s_lshl_b32 s71, s69, 6\n\t"          // ring cells per batch
+                "s_sub_u32 s63, %[gw], 9\n\t"
+                "s_sub_u32 s64, %[gw], 10\n\t"
                 "s_cmp_eq_u32 %[mode], 0\n\t"
                 "s_cbranch_scc0 6f\n\t"
                 // ---- batch start: symbol index i is the first of a batch
@@ -899,10 +906,6 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 // read after it.  The ring / latent-grid positions advance while the answers travel (a finished step leaves
                 // them: the compiled code sets them per step).
                 "22:\n\t"
-                "s_cmp_lt_u32 %[i], %[n]\n\t"
-                "s_cbranch_scc0 10f\n\t"
-                "s_add_u32 s54, %[i], s69\n\t"
-                "s_min_u32 s54, s54, %[n]\n\t"
                 "s_and_b32 s55, %[seq], %[smask]\n\t"
                 "v_lshl_add_u32 v51, s55, 2, %[rdy]\n\t"
                 "ds_read_b32 v54, v51\n\t"
@@ -912,12 +915,17 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_lshl_add_u32 v50, s56, 9, %[tabl]\n\t"
                 "ds_read_b64 v[40:41], v50\n\t"
                 "ds_read_b64 v[42:43], v50 offset:512\n\t"
-                "s_sub_u32 s58, s54, %[i]\n\t"
-                "s_add_u32 s57, s58, s70\n\t"
-                "s_lshr_b32 s57, s57, %[tshift]\n\t"
+                "s_cmp_lt_u32 %[i], %[n]\n\t"
+                "s_cbranch_scc0 30f\n\t"
+                "s_add_u32 s54, %[i], s69\n\t"
+                "s_min_u32 s54, s54, %[n]\n\t"
                 "v_add_u32 %[ring], s71, %[ring]\n\t"
                 "v_and_b32 %[ring], %[rmask], %[ring]\n\t"
                 "v_add_u32 %[goff], %[gstride], %[goff]\n\t"
+                "24:\n\t"
+                "s_sub_u32 s58, s54, %[i]\n\t"
+                "s_add_u32 s57, s58, s70\n\t"
+                "s_lshr_b32 s57, s57, %[tshift]\n\t"
                 "s_waitcnt lgkmcnt(3)\n\t"          // the counter (the first of the four answers)
                 "v_readfirstlane_b32 s59, v54\n\t"
                 "s_cmp_eq_u32 s59, s57\n\t"
@@ -929,6 +937,35 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "23:\n\t"
                 "s_mov_b32 s68, 0\n\t"
                 "s_branch 11b\n\t"
+                // ---- the step is finished.  The next one (x + 10 y = c + 1) starts one pixel to the right in the same row, or - past
+                // the right edge - at x = W - 10 one row down; its first batch sits in the slot just requested.  Everything the
+                // compiled code derives per step (StepIter, lane positions) is advanced here: ~25 instructions instead of ~90
+                // and two region crossings per step (there are W + 10 (H - 1) steps per grid).
+                "30:\n\t"
+                "s_sub_u32 %[cleft], %[cleft], 1\n\t"
+                "s_cmp_eq_u32 %[cleft], 0\n\t"
+                "s_cbranch_scc1 10f\n\t"
+                "s_add_u32 %[x0], %[x0], 1\n\t"
+                "s_cmp_eq_u32 %[x0], %[gw]\n\t"
+                "s_cselect_b32 s58, 64, 0\n\t"        // ring: one row down
+                "s_cselect_b32 s59, s63, 1\n\t"       // latent grid: + 1, past the edge + 1 + (W - 10)
+                "s_cselect_b32 %[x0], s64, %[x0]\n\t"
+                "s_cselect_b32 s60, 1, 0\n\t"
+                "s_sub_u32 %[hy], %[hy], s60\n\t"     // rows left below the step's first
+                "s_mul_i32 s60, %[x0], 0xcccd\n\t"    // x0 / 10 (exact below 43699)
+                "s_lshr_b32 s60, s60, 19\n\t"
+                "s_add_u32 s60, s60, 1\n\t"
+                "s_min_u32 %[n], s60, %[hy]\n\t"
+                "s_mov_b32 %[i], 0\n\t"
+                "s_min_u32 s54, s69, %[n]\n\t"
+                "v_add_u32 v52, 1, %[rbase]\n\t"
+                "v_bfi_b32 %[rbase], 63, v52, %[rbase]\n\t"   // column (c & 63) + 1
+                "v_add_u32 %[rbase], s58, %[rbase]\n\t"
+                "v_and_b32 %[rbase], %[rmask], %[rbase]\n\t"
+                "v_mov_b32 %[ring], %[rbase]\n\t"
+                "v_add_u32 %[gbase], s59, %[gbase]\n\t"
+                "v_mov_b32 %[goff], %[gbase]\n\t"
+                "s_branch 24b\n\t"
                 "10:\n\t"
                 "s_mov_b32 %[st], 0\n\t"
                 "s_branch 4f\n\t"
@@ -1027,15 +1064,19 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_mov_b64 %[rng], s[52:53]\n\t"
                 "s_waitcnt lgkmcnt(0)\n\t"
                 : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [i] "+s"(i), [seq] "+s"(seq), [raw] "+v"(raw), [top] "+v"(top_l),
-                  [ring] "+v"(v_ring), [goff] "+v"(v_goff), [spins] "+s"(n_spins), [wpos] "+s"(word_pos), [st] "=s"(status), [kr] "=s"(k_rare)
-                : [mode] "s"(mode), [n] "s"(n_step), [smask] "s"(static_cast<uint32_t>(slot_mask)),
+                  [ring] "+v"(v_ring), [goff] "+v"(v_goff), [spins] "+s"(n_spins), [wpos] "+s"(word_pos), [st] "=s"(status), [kr] "=s"(k_rare),
+                  [n] "+s"(n_step), [x0] "+s"(step_x0), [hy] "+s"(step_hy), [cleft] "+s"(steps_left), [rbase] "+v"(v_rbase), [gbase] "+v"(v_gbase)
+                : [mode] "s"(mode), [gw] "s"(static_cast<uint32_t>(grid_w)), [smask] "s"(static_cast<uint32_t>(slot_mask)),
                   [bshift] "s"(bpx_shift), [tshift] "s"(static_cast<uint32_t>(task_shift)),
                   [rdy] "v"(ready_base), [zero] "v"(0u), [rmask] "s"(ring_cells_mask),
                   [gstride] "s"(glo_stride), [wbuf] "v"(wbuf), [wbase] "s"(wbase), [tabl] "v"(tab_lane), [lane] "v"(static_cast<uint32_t>(lane)),
                   [l4] "v"(lane_top_off), [lat] "s"(lat_addr)
                 : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
                   "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60");
-            if (status == 0) break;
+            if (status == 0) {
+                if (!it.raster) it.c = it.n_steps;  // every step of the grid is done
+                break;
+            }
             if (status == 3) {  // the region renormalised with the last buffered payload word: refill, resume inside the batch
                 wbase = word_pos;
                 wbuf = (wbase + lane < n_words) ? words_g[wbase + lane] : 0u;
@@ -1046,7 +1087,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
             const int slot = uni(static_cast<int>(seq) & slot_mask);
             const int row0 = slot * bpx;
             if (status == 2) {  // the batch starting at symbol i is not complete yet: poll, then enter again
-                const int cnt = min(bpx, it.n - i0);
+                const int cnt = min(bpx, static_cast<int>(n_step) - i0);
                 const uint32_t n_parts = static_cast<uint32_t>((cnt + task_pix - 1) >> task_shift);
 #ifdef CCD_PIPE_PROFILE
                 const unsigned long long ts = __builtin_amdgcn_s_memtime();
@@ -1056,7 +1097,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 const unsigned long long dts = __builtin_amdgcn_s_memtime() - ts;
                 S.stall_ticks += dts;
                 S.stall_events += 1;
-                if (it.n >= 48) S.wait_by_j[min(i0 / bpx, 5)] += dts;  // finest grid: stall ticks by batch position
+                if (n_step >= 48) S.wait_by_j[min(i0 / bpx, 5)] += dts;  // finest grid: stall ticks by batch position
 #endif
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 mode = 0;
