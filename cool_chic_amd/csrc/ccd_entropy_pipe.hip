@@ -194,8 +194,9 @@ struct PipeCtx {
     LdsRef<int32_t> s_act;        // [kProducers][8][in_pad] (a task holds at most 8 pixels); [kProducers][16][in_pad] with MF
     LdsRef<uint32_t> s_a;         // MF: A operands [mf_tables][64] x 16 bytes
     LdsRef<int8_t> s_ring;        // [ring_mask + 1][64]
-    LdsRef<uint32_t> s_ready;     // [kSlots] parts of the slot's batch finished by the producers (cleared by the decoder)
-    LdsRef<uint32_t> s_consumed;
+    LdsRef<uint32_t> s_ready;     // [kSlots] one bit per part (producer task) of the slot's batch whose table rows are complete
+                                  // (set by the producers, cleared by the decoder)
+    LdsRef<uint32_t> s_consumed;  // [0] batches, [1] pixels of the stream whose symbols the decoder has published (ring + counters)
     LdsRef<uint32_t> s_abort;
     int dim, n_layers, n_sp, n_if, n_w_hidden;
     int ring_mask;         // ring rows - 1
@@ -204,7 +205,8 @@ struct PipeCtx {
     int task_pix;          // pixels per producer task in this grid (8, 4 or 2)
     int k_left;            // index of the context (y, x - 1) among the spatial contexts, -1 if the mask has none
     int8_t* lat;
-    uint32_t seq_base;
+    uint32_t seq_base;     // batches / pixels of the grids decoded so far
+    uint32_t px_base;
 };
 
 struct DecState {
@@ -315,6 +317,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     bool ok = true;
     int raw = 0, top_l = 0;  // lane p: window lane chosen for / top symbol of pixel p of the current batch
     uint32_t n_spins = 0;    // polls of a ready counter inside the asm region (profile builds report them)
+    uint32_t pix0 = uni(C.px_base);  // pixels of the stream decoded before the current step (the asm region counts on)
     while (ok && it.next()) {
         // ---- one wavefront step = one asm region: per batch the ready check, the symbol loop (hand-scheduled recurrence, see
         // the file header) and the epilogue (symbols -> LDS ring + latent grid, slot handed back, progress published) without
@@ -332,7 +335,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
         while (true) {
             uint32_t status, k_rare;
             i = uni(i); seq = uni(seq); mode = uni(mode); n_spins = uni(n_spins);  // scalar operands of the region below
-            n_step = uni(n_step); step_x0 = uni(step_x0); step_hy = uni(step_hy); steps_left = uni(steps_left);
+            n_step = uni(n_step); step_x0 = uni(step_x0); step_hy = uni(step_hy); steps_left = uni(steps_left); pix0 = uni(pix0);
             asm volatile(
                 "s_mov_b64 s[50:51], %[dst]\n\t"
                 "s_mov_b64 s[52:53], %[rng]\n\t"
@@ -343,6 +346,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_lshl_b32 s71, s69, 6\n\t"          // ring cells per batch
                 "s_sub_u32 s63, %[gw], 9\n\t"
                 "s_sub_u32 s64, %[gw], 10\n\t"
+                "s_mov_b32 s65, 0\n\t"               // 1: the batch is decoded part by part (see 27:)
                 "s_cmp_eq_u32 %[mode], 0\n\t"
                 "s_cbranch_scc0 6f\n\t"
                 // ---- batch start: symbol index i is the first of a batch
@@ -356,6 +360,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_sub_u32 s57, s54, %[i]\n\t"
                 "s_add_u32 s57, s57, s70\n\t"
                 "s_lshr_b32 s57, s57, %[tshift]\n\t"
+                "s_bfm_b32 s57, s57, 0\n\t"          // one bit per part (producer task) of the batch
                 "v_lshl_add_u32 v50, s56, 9, %[tabl]\n\t"
                 "v_lshl_add_u32 v53, s56, 2, %[l4]\n\t"
                 "s_mov_b32 s68, 0\n\t"
@@ -371,10 +376,20 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_waitcnt lgkmcnt(0)\n\t"
                 "v_readfirstlane_b32 s58, v52\n\t"
                 "s_cmp_eq_u32 s58, s57\n\t"
+                "s_cbranch_scc1 13f\n\t"
+                "s_bitcmp1_b32 s58, 0\n\t"
                 "s_cbranch_scc0 11b\n\t"
+                // the first part is there, the rest is not: the producers are the limit here.  Decode the batch part by part - each
+                // part as soon as its producer is done - and publish every part's symbols at once, so that the producers of the
+                // NEXT step start on a part while the later parts of this step are still being decoded (a step then costs
+                // "table latency + one part" instead of "table latency + the whole step")
+                "s_add_u32 %[spins], %[spins], s68\n\t"
+                "s_mov_b32 s65, 1\n\t"
+                "s_mov_b32 s66, s54\n\t"
+                "s_branch 27f\n\t"
+                "13:\n\t"
                 "s_add_u32 %[spins], %[spins], s68\n\t"
                 "ds_read_b32 %[top], v53\n\t"
-                "v_mov_b32 %[raw], 0\n\t"
                 "8:\n\t"
                 "ds_read_b64 v[40:41], v50\n\t"
                 "ds_read_b64 v[42:43], v50 offset:512\n\t"
@@ -470,6 +485,8 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 // last symbol and this store is a tick of the critical path.  The ring sits at LDS address 0 (ring cell = address),
                 // v51 still holds the batch's counter address, `consumed` lives kSlots words behind the counters.
                 "2:\n\t"
+                "s_cmp_eq_u32 s65, 0\n\t"
+                "s_cbranch_scc0 26f\n\t"
                 "s_sub_u32 s58, s54, 1\n\t"
                 "s_and_b32 s58, s58, s62\n\t"
                 "s_add_u32 s58, s58, 1\n\t"
@@ -479,6 +496,59 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "ds_write_b8 %[ring], v52\n\t"
                 "global_store_byte %[goff], v52, %[lat]\n\t"
                 "s_mov_b64 exec, -1\n\t"
+                "ds_write_b32 v51, %[zero]\n\t"
+                "s_add_u32 %[seq], %[seq], 1\n\t"
+                "s_add_u32 s58, %[pix0], %[i]\n\t"
+                "v_mov_b32 v56, %[seq]\n\t"
+                "v_mov_b32 v57, s58\n\t"
+                "ds_write_b64 %[rdy], v[56:57] offset:64\n\t"   // batches done, pixels done (of the whole stream)
+                "s_branch 22f\n\t"
+                // ---- part by part: symbols [s67, i) of the step are decoded and not published yet
+                "26:\n\t"
+                "s_and_b32 s58, s67, s62\n\t"
+                "s_sub_u32 s59, %[i], s67\n\t"
+                "s_bfm_b64 exec, s59, s58\n\t"
+                "v_sub_u32 v52, %[top], %[raw]\n\t"
+                "v_add_u32 v52, 1, v52\n\t"
+                "ds_write_b8 %[ring], v52\n\t"
+                "global_store_byte %[goff], v52, %[lat]\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "s_add_u32 s58, %[pix0], %[i]\n\t"
+                "v_mov_b32 v52, s58\n\t"
+                "ds_write_b32 %[rdy], v52 offset:68\n\t"
+                "s_cmp_lt_u32 %[i], s66\n\t"
+                "s_cbranch_scc0 29f\n\t"
+                // the next part of the batch: wait for its bit
+                "s_and_b32 s59, %[i], s62\n\t"
+                "s_lshr_b32 s59, s59, %[tshift]\n\t"
+                "s_mov_b32 s68, 0\n\t"
+                "28:\n\t"
+                "ds_read_b32 v52, v51\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_readfirstlane_b32 s58, v52\n\t"
+                "s_bitcmp1_b32 s58, s59\n\t"
+                "s_cbranch_scc1 27f\n\t"
+                "s_add_u32 s68, s68, 1\n\t"
+                "s_cmp_lt_u32 s68, 1024\n\t"
+                "s_cbranch_scc1 28b\n\t"
+                "s_branch 7f\n\t"
+                // a part starts at symbol i (its tables are there): it runs through the loop above like a short batch
+                "27:\n\t"
+                "s_add_u32 %[spins], %[spins], s68\n\t"
+                "s_mov_b32 s67, %[i]\n\t"
+                "s_add_u32 s54, %[i], s70\n\t"
+                "s_add_u32 s54, s54, 1\n\t"
+                "s_min_u32 s54, s54, s66\n\t"
+                "s_and_b32 s58, %[i], s62\n\t"
+                "s_add_u32 s58, s58, s56\n\t"
+                "v_lshl_add_u32 v50, s58, 9, %[tabl]\n\t"
+                "ds_read_b32 %[top], v53\n\t"
+                "ds_read_b64 v[40:41], v50\n\t"
+                "ds_read_b64 v[42:43], v50 offset:512\n\t"
+                "s_branch 1b\n\t"
+                // the batch is finished (its last part is published): slot handed back, batch counted
+                "29:\n\t"
+                "s_mov_b32 s65, 0\n\t"
                 "ds_write_b32 v51, %[zero]\n\t"
                 "s_add_u32 %[seq], %[seq], 1\n\t"
                 "v_mov_b32 v52, %[seq]\n\t"
@@ -498,6 +568,17 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_add_u32 s57, s57, s56\n\t"
                 "s_lshl_b32 s57, s57, 9\n\t"
                 "v_add_u32 v50, s57, %[tabl]\n\t"
+                "v_lshl_add_u32 v53, s56, 2, %[l4]\n\t"
+                // whatever the batch was doing before, it goes on part by part: everything decoded so far is (re)published at
+                // the end of the part that holds symbol i - 1
+                "s_mov_b32 s65, 1\n\t"
+                "s_mov_b32 s66, s54\n\t"
+                "s_mov_b32 s67, s58\n\t"
+                "s_sub_u32 s57, %[i], 1\n\t"
+                "s_or_b32 s57, s57, s70\n\t"
+                "s_add_u32 s57, s57, 1\n\t"
+                "s_min_u32 s54, s57, s66\n\t"
+                "s_mov_b32 s68, 0\n\t"
                 "s_cmp_lt_u32 %[i], s54\n\t"
                 "s_cbranch_scc1 8b\n\t"
                 "s_branch 2b\n\t"
@@ -898,8 +979,10 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_mov_b64 exec, -1\n\t"
                 "ds_write_b32 v51, %[zero]\n\t"
                 "s_add_u32 %[seq], %[seq], 1\n\t"
-                "v_mov_b32 v52, %[seq]\n\t"
-                "ds_write_b32 %[rdy], v52 offset:64\n\t"
+                "s_add_u32 s58, %[pix0], %[i]\n\t"
+                "v_mov_b32 v56, %[seq]\n\t"
+                "v_mov_b32 v57, s58\n\t"
+                "ds_write_b64 %[rdy], v[56:57] offset:64\n\t"
                 // ---- ... then the next batch of this step (if any): its ready counter, top symbols and first two rows are requested
                 // straight into the registers the loop uses (the finished batch's are dead by now); LDS answers a wave in order
                 // and producers store rows before they count a part in, so a counter that reads complete vouches for the rows
@@ -926,6 +1009,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_sub_u32 s58, s54, %[i]\n\t"
                 "s_add_u32 s57, s58, s70\n\t"
                 "s_lshr_b32 s57, s57, %[tshift]\n\t"
+                "s_bfm_b32 s57, s57, 0\n\t"
                 "s_waitcnt lgkmcnt(3)\n\t"          // the counter (the first of the four answers)
                 "v_readfirstlane_b32 s59, v54\n\t"
                 "s_cmp_eq_u32 s59, s57\n\t"
@@ -942,6 +1026,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 // compiled code derives per step (StepIter, lane positions) is advanced here: ~25 instructions instead of ~90
                 // and two region crossings per step (there are W + 10 (H - 1) steps per grid).
                 "30:\n\t"
+                "s_add_u32 %[pix0], %[pix0], %[n]\n\t"
                 "s_sub_u32 %[cleft], %[cleft], 1\n\t"
                 "s_cmp_eq_u32 %[cleft], 0\n\t"
                 "s_cbranch_scc1 10f\n\t"
@@ -1065,7 +1150,8 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_waitcnt lgkmcnt(0)\n\t"
                 : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [i] "+s"(i), [seq] "+s"(seq), [raw] "+v"(raw), [top] "+v"(top_l),
                   [ring] "+v"(v_ring), [goff] "+v"(v_goff), [spins] "+s"(n_spins), [wpos] "+s"(word_pos), [st] "=s"(status), [kr] "=s"(k_rare),
-                  [n] "+s"(n_step), [x0] "+s"(step_x0), [hy] "+s"(step_hy), [cleft] "+s"(steps_left), [rbase] "+v"(v_rbase), [gbase] "+v"(v_gbase)
+                  [n] "+s"(n_step), [x0] "+s"(step_x0), [hy] "+s"(step_hy), [cleft] "+s"(steps_left), [rbase] "+v"(v_rbase), [gbase] "+v"(v_gbase),
+                  [pix0] "+s"(pix0)
                 : [mode] "s"(mode), [gw] "s"(static_cast<uint32_t>(grid_w)), [smask] "s"(static_cast<uint32_t>(slot_mask)),
                   [bshift] "s"(bpx_shift), [tshift] "s"(static_cast<uint32_t>(task_shift)),
                   [rdy] "v"(ready_base), [zero] "v"(0u), [rmask] "s"(ring_cells_mask),
@@ -1083,7 +1169,8 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 mode = 1;
                 continue;
             }
-            const int i0 = static_cast<int>(status == 2 ? i : ((i) & ~static_cast<uint32_t>(bpx - 1)));
+            // first symbol of the batch that holds symbol i (status 2 leaves in front of a part of it, status 1 in front of symbol i)
+            const int i0 = static_cast<int>(i & ~static_cast<uint32_t>(bpx - 1));
             const int slot = uni(static_cast<int>(seq) & slot_mask);
             const int row0 = slot * bpx;
             if (status == 2) {  // the batch starting at symbol i is not complete yet: poll, then enter again
@@ -1092,7 +1179,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
 #ifdef CCD_PIPE_PROFILE
                 const unsigned long long ts = __builtin_amdgcn_s_memtime();
 #endif
-                if (!wait_ge(&C.s_ready[slot], n_parts, C.s_abort)) { ok = false; break; }
+                if (!wait_ge(&C.s_ready[slot], (1u << n_parts) - 1u, C.s_abort)) { ok = false; break; }  // one bit per part, all of them
 #ifdef CCD_PIPE_PROFILE
                 const unsigned long long dts = __builtin_amdgcn_s_memtime() - ts;
                 S.stall_ticks += dts;
@@ -1100,7 +1187,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 if (n_step >= 48) S.wait_by_j[min(i0 / bpx, 5)] += dts;  // finest grid: stall ticks by batch position
 #endif
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                mode = 0;
+                mode = (i & static_cast<uint32_t>(bpx - 1)) ? 1u : 0u;  // inside a batch: re-entry behind symbol i - 1
                 continue;
             }
 #ifdef CCD_PIPE_PROFILE
@@ -1465,6 +1552,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     int prev_nb = 0, prev_n = 0, prev_y0 = 0;
     uint32_t prev2_first = seq_base;
     int prev2_nb = 0, prev2_n = 0, prev2_y0 = 0;
+    uint32_t pix0 = uni(C.px_base), prev_pix0 = pix0;  // pixels of the stream before this step / before the previous one
     bool ok = true;
     // Task t of a step (pixels t kTaskPix ..) has the global index seq0 kHalves + t and belongs to producer index % kProducers:
     // a producer visits only its own tasks (first owned one of the step, then every kProducers-th).
@@ -1508,6 +1596,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 uint32_t need = need_slot;
                 if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev_y0), prev_n - 1) / kBpx) + 1);
                 need = max(need, seq_base);
+                // the same in pixels (the late wait of a split task: the decoder publishes a batch part by part when it has to wait)
+                const uint32_t need_px = prev_nb > 0 ? prev_pix0 + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev_y0), prev_n - 1)) + 1u : prev_pix0;
                 uint32_t need_early = seq_base;
                 if (prev2_nb > 0) need_early = max(need_early, prev2_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev2_y0), prev2_n - 1) / kBpx) + 1);
                 unsigned long long lt_a = 0, lt_b = 0, lt_c = 0, lt_d = 0;  // level-2 profile stamps
@@ -1531,7 +1621,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 #endif
                     {
                         const unsigned long long t0 = PROF_T();
-                        if (!wait_ge(C.s_consumed, split ? need_early : need, C.s_abort)) { ok = false; break; }
+                        if (!wait_ge(C.s_consumed, split ? max(need_early, need_slot) : need, C.s_abort)) { ok = false; break; }
                         PROF_ADD(prof[0], t0);
                     }
                     lt_b = LPROF_T(pw == 0);
@@ -1603,7 +1693,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     lt_c = LPROF_T(pw == 0);
                     if (split) {
                         const unsigned long long t0 = PROF_T();
-                        if (!wait_ge(C.s_consumed, need, C.s_abort)) { ok = false; break; }
+                        if (!wait_ge(C.s_consumed + 1, need_px, C.s_abort)) { ok = false; break; }
                         PROF_ADD(prof[0], t0);
                         PROF_SUB(prof[2], t0);  // the MLP's stamps bracket this wait: take it out of them
                         PROF_ADD(prof[5], t0);  // late wait
@@ -1794,7 +1884,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 lt_c = LPROF_T(pw == 0);
                 if (split) {
                     const unsigned long long t0 = PROF_T();
-                    if (!wait_ge(C.s_consumed, need, C.s_abort)) { ok = false; break; }
+                    if (!wait_ge(C.s_consumed + 1, need_px, C.s_abort)) { ok = false; break; }
                     PROF_ADD(prof[0], t0);
                     PROF_SUB(prof[2], t0);  // the MLP's stamps bracket this wait: take it out of them
                     PROF_SUB(prof[6], t0);
@@ -2019,7 +2109,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // LDS requests of one wave are performed in order: a relaxed add issued behind the table stores is enough for the
                 // decoder (a release would first wait for every outstanding LDS and global access of the wave)
                 asm volatile("" ::: "memory");
-                if (lane == 0) __hip_atomic_fetch_add(&C.s_ready[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) __hip_atomic_fetch_or(&C.s_ready[slot], 1u << half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 asm volatile("" ::: "memory");
                 PROF_ADD(prof[3], t_t);
 #if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
@@ -2039,6 +2129,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
         prev_nb = nb;
         prev_n = it.n;
         prev_y0 = it.y0;
+        prev_pix0 = pix0;
+        pix0 += static_cast<uint32_t>(it.n);
     }
     return seq;
 }
@@ -2087,7 +2179,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     for (int i = tid; i < kExpN; i += kPipeThreads) s_exp[i] = kExpTab[i];
     C.s_ready = s_sync;
     C.s_consumed = s_sync + kSlots;
-    C.s_abort = C.s_consumed + 1;
+    C.s_abort = C.s_consumed + 2;
     C.dim = dim; C.n_layers = n_layers; C.n_sp = P.n_spatial; C.n_if = n_if;
     C.k_left = -1;
     for (int k = 0; k < P.n_spatial; ++k) if (P.ctx_dy[k] == 0 && P.ctx_dx[k] == -1) C.k_left = k;
@@ -2119,7 +2211,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         mf_build_tables(C, in_pad, C.s_a, tid);
     }
     if (tid < kSlots) C.s_ready[tid] = 0;
-    if (tid == 0) { *C.s_consumed = 0; *C.s_abort = 0; P.status[39] = 0; }
+    if (tid == 0) { C.s_consumed[0] = 0; C.s_consumed[1] = 0; *C.s_abort = 0; P.status[39] = 0; }
 
     DecState S;
     S.range = ~uint64_t{0}; S.dist = 0; S.word_pos = 2; S.wbase = 2; S.wbuf = 0; S.n_decoded = 0;
@@ -2136,6 +2228,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     unsigned long long prof[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // [4..7]: MLP sub-phases, [8]: tasks
     const unsigned long long prof_total0 = PROF_T();
     C.seq_base = 0;
+    C.px_base = 0;
     __syncthreads();
 
     unsigned long long prof_ifce = 0, prof_bar = 0;
@@ -2317,6 +2410,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         PROF_ADD(prof_bar, t_b);
         if (lds_load_acquire(C.s_abort) != 0) break;
         C.seq_base = seq_end;  // every wave walked the same batches
+        C.px_base += static_cast<uint32_t>(C.H) * static_cast<uint32_t>(C.W);
     }
     if (tid == 0) {
         const uint32_t ab = *C.s_abort;
