@@ -259,6 +259,40 @@ __device__ __forceinline__ bool wait_ge(const uint32_t* p, uint32_t want, uint32
     return true;
 }
 
+// The decoder's progress is a pair (batches, pixels) in one aligned 64-bit LDS word: one read serves both conditions.
+__device__ __forceinline__ bool wait_ge2(const uint32_t* p, uint32_t want_batches, uint32_t want_pixels, uint32_t* s_abort) {
+    unsigned spins = 0;
+    while (true) {
+        const uint64_t v = uni(__hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (static_cast<int32_t>(static_cast<uint32_t>(v) - want_batches) >= 0 && static_cast<int32_t>(static_cast<uint32_t>(v >> 32) - want_pixels) >= 0) break;
+        if ((++spins & 1023u) == 0) {
+            if (lds_load_acquire(s_abort) != 0) return false;
+            if (spins > kSpinLimit) { lds_store_release(s_abort, static_cast<uint32_t>(-CCD_ERR_HIP)); return false; }
+        }
+    }
+    return true;
+}
+
+// The producers' walk over the steps of a grid (same order as StepIter below), kept incremental and unsigned: a producer
+// passes every step on the way to its next task, so this is on the path between two tasks.
+struct StepWalk {
+    uint32_t H, W, raster, left;
+    uint32_t y0, x0, n, moved;  // moved: the step's first row is one below the previous step's
+    __device__ void init(uint32_t h, uint32_t w) {
+        H = h; W = w; raster = w <= 9u; left = raster ? h * w : w + 10u * (h - 1u);
+        y0 = 0; x0 = ~0u; n = 0; moved = 0;
+    }
+    __device__ bool next() {
+        if (left == 0) return false;
+        --left;
+        ++x0;
+        moved = x0 == W;
+        if (moved) { x0 = raster ? 0u : W - 10u; ++y0; }
+        n = raster ? 1u : min(H - y0, ((x0 * 0xcccdu) >> 19) + 1u);  // x0 / 10 + 1 (exact below 43699)
+        return true;
+    }
+};
+
 // Iterates the wavefront steps of one grid (latent.py:66-140).
 struct StepIter {
     int H, W, raster, n_steps;
@@ -1546,31 +1580,34 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
         }
     }
     (void)mf_dxy; (void)mf_wl;
-    StepIter it;
-    it.init(uni(C.H), W);
-    uint32_t seq = seq_base, prev_first = seq_base;
-    int prev_nb = 0, prev_n = 0, prev_y0 = 0;
-    uint32_t prev2_first = seq_base;
-    int prev2_nb = 0, prev2_n = 0, prev2_y0 = 0;
-    uint32_t pix0 = uni(C.px_base), prev_pix0 = pix0;  // pixels of the stream before this step / before the previous one
+    constexpr uint32_t kTaskShift = kTaskPix == 8 ? 3 : (kTaskPix == 4 ? 2 : 1), kBpxShift = kBpx == 16 ? 4 : 3, kHalvesShift = kBpxShift - kTaskShift;
+    StepWalk it;
+    it.init(static_cast<uint32_t>(uni(C.H)), static_cast<uint32_t>(W));
+    uint32_t seq = seq_base;
+    // pixels of the stream in front of this step, the previous one, the one before; rows the step start moved down in between
+    uint32_t pix0 = uni(C.px_base), prev_pix0 = pix0, prev2_pix0 = pix0, prev_moved = 0;
     bool ok = true;
     // Task t of a step (pixels t kTaskPix ..) has the global index seq0 kHalves + t and belongs to producer index % kProducers:
     // a producer visits only its own tasks (first owned one of the step, then every kProducers-th).
-    int phase = static_cast<int>((static_cast<unsigned long long>(seq_base) * kHalves) % kProducers);  // (seq0 kHalves) mod kProducers
+    uint32_t phase = static_cast<uint32_t>((static_cast<unsigned long long>(seq_base) * kHalves) % kProducers);  // (seq0 kHalves) mod kProducers
+    const bool split = k_left >= 0 && W > 9 && n_layers >= 2;  // (not in raster order)
     while (ok && it.next()) {
-        const int nb = (it.n + kBpx - 1) / kBpx;
-        const int n_tasks = (it.n + kTaskPix - 1) / kTaskPix;
+        const uint32_t nb = (it.n + kBpx - 1) >> kBpxShift;
+        const uint32_t n_tasks = (it.n + kTaskPix - 1) >> kTaskShift;
         const uint32_t seq0 = seq;
-        int t_first = pw - phase;
-        t_first += t_first < 0 ? kProducers : 0;
+        const uint32_t dy1 = it.moved, dy2 = it.moved + prev_moved;
+        const uint32_t prev_n = pix0 - prev_pix0, prev2_n = prev_pix0 - prev2_pix0;
+        uint32_t t_first = static_cast<uint32_t>(pw) - phase;
+        t_first += static_cast<int32_t>(t_first) < 0 ? kProducers : 0;
         {
-            for (int task = t_first; task < n_tasks; task += kProducers) {
-                const int j = task / kHalves, half = task % kHalves;
-                seq = seq0 + static_cast<uint32_t>(j);
-                const int slot = seq % kNSlots;
-                const int i0 = task * kTaskPix;                // first pixel of the task within the step
-                const int cnt = min(kTaskPix, it.n - i0);
-                const int y = it.y0 + i0 + px, x = it.x0 - 10 * (i0 + px);
+            for (uint32_t task = t_first; task < n_tasks; task += kProducers) {
+                const uint32_t j = task >> kHalvesShift;
+                const int half = static_cast<int>(task & (kHalves - 1));
+                seq = seq0 + j;
+                const int slot = static_cast<int>(seq & (kNSlots - 1));
+                const int i0 = static_cast<int>(task << kTaskShift);   // first pixel of the task within the step
+                const int cnt = min(kTaskPix, static_cast<int>(it.n) - i0);
+                const int y = static_cast<int>(it.y0) + i0 + px, x = static_cast<int>(it.x0) - 10 * (i0 + px);
                 // ---- IFCE features do not depend on this grid: fetch them before waiting on the decoder -------
                 int32_t fv[NOUT];
 #pragma unroll
@@ -1591,15 +1628,12 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // two steps back, everything else at least five.  So the task gathers every other input, runs the stabiliser and
                 // the first layer on them BEFORE the left neighbour is decoded, and only adds that one term afterwards: the
                 // critical path from "symbol decoded" to "table ready" loses the gather and a third of the MLP.
-                const bool split = k_left >= 0 && !it.raster && n_layers >= 2;
-                const uint32_t need_slot = seq >= static_cast<uint32_t>(kNSlots) ? seq - kNSlots + 1 : 0;  // slot free again (table / meta rows)
-                uint32_t need = need_slot;
-                if (prev_nb > 0) need = max(need, prev_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev_y0), prev_n - 1) / kBpx) + 1);
-                need = max(need, seq_base);
-                // the same in pixels (the late wait of a split task: the decoder publishes a batch part by part when it has to wait)
-                const uint32_t need_px = prev_nb > 0 ? prev_pix0 + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev_y0), prev_n - 1)) + 1u : prev_pix0;
-                uint32_t need_early = seq_base;
-                if (prev2_nb > 0) need_early = max(need_early, prev2_first + static_cast<uint32_t>(min(i0 + cnt - 1 + (it.y0 - prev2_y0), prev2_n - 1) / kBpx) + 1);
+                // Both waits are in pixels of the stream (the decoder publishes in decoding order: a published pixel vouches
+                // for every earlier step); the first one also wants the slot's previous batch gone (table / meta rows free again).
+                const uint32_t need_slot = seq >= static_cast<uint32_t>(kNSlots) ? seq - kNSlots + 1 : 0;
+                const uint32_t last1 = static_cast<uint32_t>(i0 + cnt);  // pixels of the step up to the task's last one
+                const uint32_t need_px = prev_pix0 + min(last1 + dy1, prev_n);         // ... the left neighbours
+                const uint32_t need_early_px = prev2_pix0 + min(last1 + dy2, prev2_n);  // ... the pixels two to the left
                 unsigned long long lt_a = 0, lt_b = 0, lt_c = 0, lt_d = 0;  // level-2 profile stamps
                 (void)lt_a; (void)lt_b; (void)lt_c; (void)lt_d;
                 unsigned narrow_mask = 0;  // matrix-core path: bit i: pixel i of the task is narrow (wave-uniform)
@@ -1621,7 +1655,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 #endif
                     {
                         const unsigned long long t0 = PROF_T();
-                        if (!wait_ge(C.s_consumed, split ? max(need_early, need_slot) : need, C.s_abort)) { ok = false; break; }
+                        if (!wait_ge2(C.s_consumed, need_slot, split ? need_early_px : need_px, C.s_abort)) { ok = false; break; }
                         PROF_ADD(prof[0], t0);
                     }
                     lt_b = LPROF_T(pw == 0);
@@ -1785,7 +1819,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     const unsigned long long t0 = PROF_T();
                     // (the early wait includes "slot free again": true long ago whenever it is looked at - the slot was last used
                     // kNSlots batches back - and it lets the table rows' tails be cleared before the late wait, see below)
-                    if (!wait_ge(C.s_consumed, split ? max(need_early, need_slot) : need, C.s_abort)) { ok = false; break; }
+                    if (!wait_ge2(C.s_consumed, need_slot, split ? need_early_px : need_px, C.s_abort)) { ok = false; break; }
                     PROF_ADD(prof[0], t0);
                 }
                 lt_b = LPROF_T(pw == 0);
@@ -1980,7 +2014,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         A.W = W; A.fin = fin; A.fw = fw; A.feat_plane = feat_plane; A.ring_mask = ring_mask;
                         asm volatile("" : "+s"(A.P), "+s"(A.s_w), "+s"(A.s_b), "+s"(A.s_ring), "+s"(A.n_w_hidden), "+s"(A.dim), "+s"(A.n_layers));
                         asm volatile("" : "+s"(A.n_sp), "+s"(A.W), "+s"(A.fin), "+s"(A.fw), "+s"(A.feat_plane), "+s"(A.ring_mask));
-                        const ExactOut r = exact_pixel(A, it.y0 + i0 + p, it.x0 - 10 * (i0 + p));
+                        const ExactOut r = exact_pixel(A, static_cast<int>(it.y0) + i0 + p, static_cast<int>(it.x0) - 10 * (i0 + p));
                         if (px == p && q < 2) {
                             const int64_t off = ((q == 0 ? r.mu : r.ls) >> 24) + (q == 0 ? kMuOffset : kScaleOffset);
                             const int64_t hi = q == 0 ? kNumMu - 1 : kNumScale - 1;
@@ -2122,15 +2156,12 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
             }
         }
         if (!ok) break;
-        seq = seq0 + static_cast<uint32_t>(nb);
+        seq = seq0 + nb;
         phase = (phase + nb * kHalves) % kProducers;
-        prev2_first = prev_first; prev2_nb = prev_nb; prev2_n = prev_n; prev2_y0 = prev_y0;
-        prev_first = seq - nb;
-        prev_nb = nb;
-        prev_n = it.n;
-        prev_y0 = it.y0;
+        prev2_pix0 = prev_pix0;
         prev_pix0 = pix0;
-        pix0 += static_cast<uint32_t>(it.n);
+        pix0 += it.n;
+        prev_moved = it.moved;
     }
     return seq;
 }
