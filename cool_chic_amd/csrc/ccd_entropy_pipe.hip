@@ -54,10 +54,10 @@ namespace ccd {
 
 // widest step of a grid >= CCD_T8 pixels: 8-pixel tasks; >= CCD_T4: 4-pixel tasks; else 2-pixel tasks (tunable at build time)
 #ifndef CCD_T8
-#define CCD_T8 29
+#define CCD_T8 25
 #endif
 #ifndef CCD_T4
-#define CCD_T4 15
+#define CCD_T4 9
 #endif
 constexpr int kPipeThreads = 512;           // 8 waves: 1 decoder + 7 producers
 constexpr int kPipeWaves = kPipeThreads / 64;
@@ -213,6 +213,7 @@ struct DecState {
     uint64_t dist, range;  // dist = point - lower (all the decoder ever uses)
     uint32_t word_pos, wbase, wbuf;
     uint64_t n_decoded;
+    uint32_t n_part_batches;  // batches decoded part by part (status word 37)
     unsigned long long prof_wait, prof_work, stall_ticks, stall_events, n_rare, n_search, n_spins;
     unsigned long long wait_by_j[6];  // grid 0, steps with n >= 64: decoder wait per batch position
 };
@@ -352,6 +353,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     int raw = 0, top_l = 0;  // lane p: window lane chosen for / top symbol of pixel p of the current batch
     uint32_t n_spins = 0;    // polls of a ready counter inside the asm region (profile builds report them)
     uint32_t pix0 = uni(C.px_base);  // pixels of the stream decoded before the current step (the asm region counts on)
+    uint32_t n_part = 0;             // batches decoded part by part
     while (ok && it.next()) {
         // ---- one wavefront step = one asm region: per batch the ready check, the symbol loop (hand-scheduled recurrence, see
         // the file header) and the epilogue (symbols -> LDS ring + latent grid, slot handed back, progress published) without
@@ -370,6 +372,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
             uint32_t status, k_rare;
             i = uni(i); seq = uni(seq); mode = uni(mode); n_spins = uni(n_spins);  // scalar operands of the region below
             n_step = uni(n_step); step_x0 = uni(step_x0); step_hy = uni(step_hy); steps_left = uni(steps_left); pix0 = uni(pix0);
+            n_part = uni(n_part);
             asm volatile(
                 "s_mov_b64 s[50:51], %[dst]\n\t"
                 "s_mov_b64 s[52:53], %[rng]\n\t"
@@ -418,6 +421,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 // NEXT step start on a part while the later parts of this step are still being decoded (a step then costs
                 // "table latency + one part" instead of "table latency + the whole step")
                 "s_add_u32 %[spins], %[spins], s68\n\t"
+                "s_add_u32 %[npart], %[npart], 1\n\t"
                 "s_mov_b32 s65, 1\n\t"
                 "s_mov_b32 s66, s54\n\t"
                 "s_branch 27f\n\t"
@@ -1185,7 +1189,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [i] "+s"(i), [seq] "+s"(seq), [raw] "+v"(raw), [top] "+v"(top_l),
                   [ring] "+v"(v_ring), [goff] "+v"(v_goff), [spins] "+s"(n_spins), [wpos] "+s"(word_pos), [st] "=s"(status), [kr] "=s"(k_rare),
                   [n] "+s"(n_step), [x0] "+s"(step_x0), [hy] "+s"(step_hy), [cleft] "+s"(steps_left), [rbase] "+v"(v_rbase), [gbase] "+v"(v_gbase),
-                  [pix0] "+s"(pix0)
+                  [pix0] "+s"(pix0), [npart] "+s"(n_part)
                 : [mode] "s"(mode), [gw] "s"(static_cast<uint32_t>(grid_w)), [smask] "s"(static_cast<uint32_t>(slot_mask)),
                   [bshift] "s"(bpx_shift), [tshift] "s"(static_cast<uint32_t>(task_shift)),
                   [rdy] "v"(ready_base), [zero] "v"(0u), [rmask] "s"(ring_cells_mask),
@@ -1280,6 +1284,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     }
     S.dist = rc_dist; S.range = rc_range; S.word_pos = word_pos; S.wbase = wbase; S.wbuf = wbuf;
     S.n_spins += n_spins;
+    S.n_part_batches += n_part;
     return seq;
 }
 
@@ -2246,6 +2251,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
 
     DecState S;
     S.range = ~uint64_t{0}; S.dist = 0; S.word_pos = 2; S.wbase = 2; S.wbuf = 0; S.n_decoded = 0;
+    S.n_part_batches = 0;
     S.prof_wait = 0; S.prof_work = 0; S.stall_ticks = 0; S.stall_events = 0; S.n_rare = 0; S.n_search = 0; S.n_spins = 0;
     for (int i = 0; i < 6; ++i) S.wait_by_j[i] = 0;
     if (wave == 0) {
@@ -2447,6 +2453,9 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         const uint32_t ab = *C.s_abort;
         P.status[0] = ab ? -static_cast<int32_t>(ab) : 0;
         P.status[1] = static_cast<int32_t>(S.word_pos);
+#ifndef CCD_PIPE_PROFILE
+        P.status[37] = static_cast<int32_t>(S.n_part_batches);  // batches the decoder took part by part (tests)
+#endif
         {   // symbols decoded = all grids unless aborted
             uint64_t n_sym = 0;
             for (int g2 = 0; g2 < P.n_grids; ++g2) n_sym += static_cast<uint64_t>(P.grid_h[g2]) * P.grid_w[g2];

@@ -165,7 +165,9 @@ int ccd_batch_slot_kernels(const ccd_batch* b, int slot);
  *   CCD_OPT_RANGE_BITS  0 (default): production limit of the pipelined entropy kernel's dynamic operand check (an IFCE feature
  *                       with |f| >= 2^15 sends its pixel through the int64 redo).  Tests pass 8..14 to lower the limit and
  *                       drive ordinary streams through the redo; results are identical bit for bit.
- *                       ccd_batch_slot_stats word [39] counts the redone pixels. */
+ *                       ccd_batch_slot_stats word [39] counts the redone pixels; word [37] counts the batches the
+ *                       pipelined kernel's decoder took part by part (a producer task at a time, because only the first
+ *                       part's tables were there when it looked: DESIGN.md 4.1). */
 enum { CCD_OPT_FUSED_DEC = 1, CCD_OPT_KEEP_FLOAT = 2, CCD_OPT_MFMA_ARM = 3, CCD_OPT_RANGE_BITS = 4 };
 int ccd_batch_set_option(ccd_batch* b, int option, int value);
 
