@@ -8,7 +8,9 @@ import bench
 from cool_chic_amd import DecodeBatch
 
 n_iter = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+copies = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # kodak24 x copies streams in the batch (8: most CUs busy)
 items, _ = bench.build_kodak24(0)
+items = items * copies
 b = DecodeBatch(0)
 for hdr, nn, lat, _ in items:
     b.add(hdr, nn, lat, 8, 0)
@@ -30,4 +32,4 @@ for it in range(n_iter):
         ref = d
     elif d != ref:
         print("MISMATCH at iteration", it); sys.exit(1)
-print("%d iterations, 24 streams each: identical (%s)" % (n_iter, ref[:16]))
+print("%d iterations, %d streams each: identical (%s)" % (n_iter, len(items), ref[:16]))
