@@ -1308,6 +1308,9 @@ __device__ __forceinline__ void mad64(int64_t& acc, int32_t x, int32_t w) {
     _Pragma("unroll") for (int g_ = 0; g_ < (NCH); ++g_) mad64(ACC[g_], (X).y, Wv[g_].y); \
     _Pragma("unroll") for (int g_ = 0; g_ < (NCH); ++g_) mad64(ACC[g_], (X).z, Wv[g_].z); \
     _Pragma("unroll") for (int g_ = 0; g_ < (NCH); ++g_) mad64(ACC[g_], (X).w, Wv[g_].w);
+// one output per lane (2-pixel tasks): a second partial sum, so that no multiply-add directly follows the one it depends on
+#define CCD_MAD4_PAIR(ACC, ACC2, X, Wv)                                             \
+    mad64(ACC[0], (X).x, Wv[0].x); mad64(ACC2, (X).y, Wv[0].y); mad64(ACC[0], (X).z, Wv[0].z); mad64(ACC2, (X).w, Wv[0].w);
 
 
 // ---- the ARM on the matrix cores (MF = true) ---------------------------------------------------------------------------
@@ -1879,17 +1882,17 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 #pragma unroll
                     for (int v = 0; v < NV; ++v) wv[v] = wr[v];
 #pragma unroll
-                    for (int v = 0; v < NV; ++v) {
+                    for (int v = 0; v < NV; ++v) {  // the two chains alternate: a dependent v_mad_i64_i32 right behind its producer costs a wait state
                         const int4 w = wv[v];
-                        int64_t& a = so[v & 1];
-                        mad64(a, xv[v].x, w.x); mad64(a, xv[v].y, w.y); mad64(a, xv[v].z, w.z); mad64(a, xv[v].w, w.w);
+                        mad64(so[0], xv[v].x, w.x); mad64(so[1], xv[v].y, w.y); mad64(so[0], xv[v].z, w.z); mad64(so[1], xv[v].w, w.w);
                     }
                 }
                 PROF_ADD(prof[5], t_s);
                 const unsigned long long t_h = PROF_T();
                 // first hidden layer on the early inputs (the only layer when the late wait does not apply is handled alike:
                 // the left term is then simply zero and the gather above already took the neighbour)
-                int64_t acc0[NOUT];
+                int64_t acc0[NOUT], acc0_b = 0;
+                (void)acc0_b;
                 int32_t wleft[NOUT], wleft_stab = 0;
                 if (n_layers >= 2) {
                     const int32_t* wl = C.s_w;
@@ -1913,10 +1916,11 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 #pragma unroll
                             for (int t = 0; t < NOUT; ++t) wn[t] = wr[t][v + 1];
                         }
-                        CCD_MAD4(acc0, xv[v], w, NOUT)
+                        if constexpr (NOUT == 1) { CCD_MAD4_PAIR(acc0, acc0_b, xv[v], w) } else { CCD_MAD4(acc0, xv[v], w, NOUT) }
 #pragma unroll
                         for (int t = 0; t < NOUT; ++t) w[t] = wn[t];
                     }
+                    if constexpr (NOUT == 1) acc0[0] += acc0_b;
                 }
                 // ---- the left neighbour: wait for it (and for the slot), add its term to the first layer and the stabiliser
                 int32_t xleft = 0;
@@ -1946,7 +1950,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 for (int l = 1; l < n_layers - 1; ++l) {
                     const int32_t* wl = C.s_w + l * dim * in_pad;
                     const int64_t* bl = C.s_b + l * dim;
-                    int64_t acc[NOUT];
+                    int64_t acc[NOUT], acc_b = 0;
+                    (void)acc_b;
                     const int4* wr[NOUT];
 #pragma unroll
                     for (int t = 0; t < NOUT; ++t) {
@@ -1963,10 +1968,11 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 #pragma unroll
                             for (int t = 0; t < NOUT; ++t) wn[t] = wr[t][v + 1];
                         }
-                        CCD_MAD4(acc, xv[v], w, NOUT)
+                        if constexpr (NOUT == 1) { CCD_MAD4_PAIR(acc, acc_b, xv[v], w) } else { CCD_MAD4(acc, xv[v], w, NOUT) }
 #pragma unroll
                         for (int t = 0; t < NOUT; ++t) w[t] = wn[t];
                     }
+                    if constexpr (NOUT == 1) acc[0] += acc_b;
 #pragma unroll
                     for (int t = 0; t < NOUT; ++t) {
                         const int o = q + kLpp * t;
@@ -1990,8 +1996,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 #pragma unroll
                     for (int v = 0; v < NV; ++v) {
                         const int4 w = wv[v];
-                        int64_t& a = ao[v & 1];
-                        mad64(a, xv[v].x, w.x); mad64(a, xv[v].y, w.y); mad64(a, xv[v].z, w.z); mad64(a, xv[v].w, w.w);
+                        mad64(ao[0], xv[v].x, w.x); mad64(ao[1], xv[v].y, w.y); mad64(ao[0], xv[v].z, w.z); mad64(ao[1], xv[v].w, w.w);
                     }
                     const int64_t acc = ao[0] + ao[1];
                     const int64_t q8 = acc >> 24;
