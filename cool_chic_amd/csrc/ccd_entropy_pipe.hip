@@ -59,7 +59,10 @@ namespace ccd {
 #ifndef CCD_T4
 #define CCD_T4 9
 #endif
-constexpr int kPipeThreads = 512;           // 8 waves: 1 decoder + 7 producers
+#ifndef CCD_PIPE_THREADS
+#define CCD_PIPE_THREADS 512
+#endif
+constexpr int kPipeThreads = CCD_PIPE_THREADS;  // 8 waves: 1 decoder + 7 producers
 constexpr int kPipeWaves = kPipeThreads / 64;
 constexpr int kProducers = kPipeWaves - 1;
 // pixels per decoder batch: 16 (two 8-pixel or four 4-pixel tasks), 8 with 2-pixel tasks (bpx / kBpx below)
