@@ -15,10 +15,13 @@
 //     4 lanes per pixel (32x32->64 multiply-adds, weights read as 16-byte LDS vectors, activations
 //     exchanged through a per-wave LDS tile) and expand (mu, scale) into the window table with one
 //     f64 exp per lane;
-//   * hand-over is by sequence numbers in LDS; a batch of diagonal c+1 only needs its own rows' pixels
-//     of diagonal c, so producers work on c+1 while the decoder is still finishing c;
+//   * hand-over through LDS words: per batch slot one ready bit per producer task ("part"), and the decoder's
+//     progress as a pair (batches, pixels of the stream).  A pixel of diagonal c+1 only needs its own row's
+//     pixel of diagonal c, so producers work on c+1 while the decoder is still finishing c; a batch whose
+//     later parts are not built yet is decoded part by part, each part published at once;
 //   * a lone wave issues in order, so every instruction between two symbols lengthens the chain: a full
-//     16-symbol batch runs an unrolled copy of the symbol loop without index arithmetic, bound test or branch;
+//     16-symbol batch runs an unrolled copy of the symbol loop without index arithmetic, bound test or branch,
+//     and the decoder stays inside ONE asm region for a whole grid (batch hand-over, step advance, renormalisation);
 //   * between grids the whole workgroup computes the IFCE features of the next grid (loads requested a
 //     position ahead through explicit global pointers, straight-line body: see the notes there);
 //   * optionally (EntropyParams::mfma, off by default: measured slower) the ARM's layers of 8-pixel tasks run
