@@ -69,6 +69,13 @@ constexpr int kPipeThreads = CCD_PIPE_THREADS;  // 8 waves: 1 decoder + 7 produc
 constexpr int kPipeWaves = kPipeThreads / 64;
 constexpr int kProducers = kPipeWaves - 1;
 // pixels per decoder batch: 16 (two 8-pixel or four 4-pixel tasks), 8 with 2-pixel tasks (bpx / kBpx below)
+#ifndef CCD_BPX_WIDE
+#define CCD_BPX_WIDE 16
+#endif
+// pixels per decoder batch on grids with 8-pixel tasks: 16; 32 (-DCCD_BPX_WIDE=32: half the hand-overs per symbol, the first 16
+// symbols published half-way) is built and bit-exact but SLOWER (50.3 against 46.2 ms on kodak24, as in r01 without the half-way
+// publication): a batch must be complete to be taken whole, and table rows are handed back to the producers in coarser units
+constexpr int kBpxWide = CCD_BPX_WIDE;
 constexpr int kRows = 128;                  // table rows in LDS = slots x pixels per batch (4 x 32, 8 x 16 or 16 x 8)
 // Producer task = a part of a batch: 8 pixels x 8 lanes on wide wavefronts, 4 pixels x 16 lanes on short ones
 // (small grids are bound by the producers' latency, not their throughput).
@@ -336,11 +343,10 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     const glb_ptr<const uint32_t> words_g = (glb_ptr<const uint32_t>)P.words;
     const int task_pix = uni(C.task_pix);
     const int grid_w = uni(C.W);
-    // pixels per batch: 16 (two 8-pixel or four 4-pixel tasks) or 8 (four 2-pixel tasks).  32-pixel batches were tried:
-    // the decoder saves ~20 ticks / symbol of per-batch overhead, but progress is published (and the producers of the next
-    // step released) only half as often, which costs more in stalls than it saves.
-    const int bpx = task_pix == 2 ? 8 : 16;
-    const uint32_t bpx_shift = task_pix == 2 ? 3u : 4u;
+    // pixels per batch: 16 (two 8-pixel or four 4-pixel tasks) or 8 (four 2-pixel tasks).  32-pixel batches were tried twice
+    // (r01; r03 with the first half published half-way, kBpxWide above): fewer hand-overs for the decoder, but slower overall.
+    const int bpx = task_pix == 2 ? 8 : (task_pix == 8 ? kBpxWide : 16);
+    const uint32_t bpx_shift = task_pix == 2 ? 3u : (task_pix == 8 && kBpxWide == 32 ? 5u : 4u);
     const int slot_mask = kRows / bpx - 1;       // 8 / 16 slots share the 128 table rows
     const int task_shift = task_pix == 8 ? 3 : (task_pix == 4 ? 2 : 1);
     // LDS byte addresses (the dynamic LDS starts at 0) and per-lane constants of the step loop below
@@ -440,8 +446,17 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 // a full batch of 16 symbols takes the unrolled copy of the loop (80:): no loop control on the chain
                 "19:\n\t"
                 "s_sub_u32 s58, s54, %[i]\n\t"
+#if CCD_BPX_WIDE == 32
+                "s_cmp_eq_u32 s58, s69\n\t"
+                "s_cbranch_scc0 1f\n\t"
+                "s_cmp_eq_u32 s69, 32\n\t"
+                "s_cbranch_scc1 70f\n\t"
+                "s_cmp_eq_u32 s69, 16\n\t"
+                "s_cbranch_scc1 80f\n\t"
+#else
                 "s_cmp_eq_u32 s58, 16\n\t"
                 "s_cbranch_scc1 80f\n\t"
+#endif
                 ".p2align 6\n\t"
                 "1:\n\t"
                 // ---- copy 0: (L, P) of the current symbol in v[40:41], two rows ahead in flight (order: dloop_variants.hip)
@@ -709,311 +724,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 // between s[52:53] (even symbols) and s[48:49] (odd): no copy of the new range; odd trampolines swap them back.
                 ".p2align 6\n\t"
                 "80:\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
-                "ds_read_b64 v[46:47], v50 offset:1024\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
-                "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
-                "v_mad_u32_u24 v49, v41, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 0\n\t"
-                "v_readfirstlane_b32 s48, v48\n\t"
-                "v_readfirstlane_b32 s49, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
-                "s_cbranch_scc1 81f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
-                "ds_read_b64 v[40:41], v50 offset:1536\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
-                "v_mad_u32_u24 v45, v42, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
-                "v_mad_u32_u24 v49, v43, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 1\n\t"
-                "v_readfirstlane_b32 s52, v48\n\t"
-                "v_readfirstlane_b32 s53, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s53, 0\n\t"
-                "s_cbranch_scc1 82f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
-                "ds_read_b64 v[42:43], v50 offset:2048\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
-                "v_mad_u32_u24 v45, v46, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
-                "v_mad_u32_u24 v49, v47, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 2\n\t"
-                "v_readfirstlane_b32 s48, v48\n\t"
-                "v_readfirstlane_b32 s49, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
-                "s_cbranch_scc1 83f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
-                "ds_read_b64 v[46:47], v50 offset:2560\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
-                "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
-                "v_mad_u32_u24 v49, v41, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 3\n\t"
-                "v_readfirstlane_b32 s52, v48\n\t"
-                "v_readfirstlane_b32 s53, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s53, 0\n\t"
-                "s_cbranch_scc1 84f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
-                "ds_read_b64 v[40:41], v50 offset:3072\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
-                "v_mad_u32_u24 v45, v42, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
-                "v_mad_u32_u24 v49, v43, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 4\n\t"
-                "v_readfirstlane_b32 s48, v48\n\t"
-                "v_readfirstlane_b32 s49, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
-                "s_cbranch_scc1 85f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
-                "ds_read_b64 v[42:43], v50 offset:3584\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
-                "v_mad_u32_u24 v45, v46, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
-                "v_mad_u32_u24 v49, v47, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 5\n\t"
-                "v_readfirstlane_b32 s52, v48\n\t"
-                "v_readfirstlane_b32 s53, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s53, 0\n\t"
-                "s_cbranch_scc1 86f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
-                "ds_read_b64 v[46:47], v50 offset:4096\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
-                "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
-                "v_mad_u32_u24 v49, v41, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 6\n\t"
-                "v_readfirstlane_b32 s48, v48\n\t"
-                "v_readfirstlane_b32 s49, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
-                "s_cbranch_scc1 87f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
-                "ds_read_b64 v[40:41], v50 offset:4608\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
-                "v_mad_u32_u24 v45, v42, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
-                "v_mad_u32_u24 v49, v43, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 7\n\t"
-                "v_readfirstlane_b32 s52, v48\n\t"
-                "v_readfirstlane_b32 s53, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s53, 0\n\t"
-                "s_cbranch_scc1 88f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
-                "ds_read_b64 v[42:43], v50 offset:5120\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
-                "v_mad_u32_u24 v45, v46, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
-                "v_mad_u32_u24 v49, v47, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 8\n\t"
-                "v_readfirstlane_b32 s48, v48\n\t"
-                "v_readfirstlane_b32 s49, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
-                "s_cbranch_scc1 89f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
-                "ds_read_b64 v[46:47], v50 offset:5632\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
-                "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
-                "v_mad_u32_u24 v49, v41, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 9\n\t"
-                "v_readfirstlane_b32 s52, v48\n\t"
-                "v_readfirstlane_b32 s53, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s53, 0\n\t"
-                "s_cbranch_scc1 90f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
-                "ds_read_b64 v[40:41], v50 offset:6144\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
-                "v_mad_u32_u24 v45, v42, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
-                "v_mad_u32_u24 v49, v43, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 10\n\t"
-                "v_readfirstlane_b32 s48, v48\n\t"
-                "v_readfirstlane_b32 s49, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
-                "s_cbranch_scc1 91f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
-                "ds_read_b64 v[42:43], v50 offset:6656\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
-                "v_mad_u32_u24 v45, v46, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
-                "v_mad_u32_u24 v49, v47, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 11\n\t"
-                "v_readfirstlane_b32 s52, v48\n\t"
-                "v_readfirstlane_b32 s53, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s53, 0\n\t"
-                "s_cbranch_scc1 92f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
-                "ds_read_b64 v[46:47], v50 offset:7168\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
-                "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
-                "v_mad_u32_u24 v49, v41, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 12\n\t"
-                "v_readfirstlane_b32 s48, v48\n\t"
-                "v_readfirstlane_b32 s49, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
-                "s_cbranch_scc1 93f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
-                "ds_read_b64 v[40:41], v50 offset:7680\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v42, 0\n\t"
-                "v_mad_u32_u24 v45, v42, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v43, 0\n\t"
-                "v_mad_u32_u24 v49, v43, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 13\n\t"
-                "v_readfirstlane_b32 s52, v48\n\t"
-                "v_readfirstlane_b32 s53, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s53, 0\n\t"
-                "s_cbranch_scc1 94f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[52:53], 24\n\t"
-                "ds_read_b64 v[42:43], v50 offset:8192\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v46, 0\n\t"
-                "v_mad_u32_u24 v45, v46, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v47, 0\n\t"
-                "v_mad_u32_u24 v49, v47, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 14\n\t"
-                "v_readfirstlane_b32 s48, v48\n\t"
-                "v_readfirstlane_b32 s49, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s49, 0\n\t"
-                "s_cbranch_scc1 95f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_lshr_b64 s[40:41], s[48:49], 24\n\t"
-                "ds_read_b64 v[46:47], v50 offset:8704\n\t"
-                "s_waitcnt lgkmcnt(2)\n\t"
-                "v_mad_u64_u32 v[44:45], s[42:43], s40, v40, 0\n\t"
-                "v_mad_u32_u24 v45, v40, s41, v45\n\t"
-                "v_cmpx_ge_u64 vcc, s[50:51], v[44:45]\n\t"
-                "v_mad_u64_u32 v[48:49], s[42:43], s40, v41, 0\n\t"
-                "v_mad_u32_u24 v49, v41, s41, v49\n\t"
-                "s_ff1_i32_b64 s44, vcc\n\t"
-                "v_writelane_b32 %[raw], s44, 15\n\t"
-                "v_readfirstlane_b32 s52, v48\n\t"
-                "v_readfirstlane_b32 s53, v49\n\t"
-                "v_readfirstlane_b32 s46, v44\n\t"
-                "v_readfirstlane_b32 s47, v45\n\t"
-                "s_mov_b64 exec, -1\n\t"
-                "s_cmp_eq_u32 s53, 0\n\t"
-                "s_cbranch_scc1 96f\n\t"
-                "s_sub_u32 s50, s50, s46\n\t"
-                "s_subb_u32 s51, s51, s47\n\t"
-                "s_add_u32 %[i], %[i], 16\n\t"
+#include "ccd_dec_block16.inc"
                 // ---- end of a full batch: the same hand-over as at 2: with a constant lane mask ...
                 "s_mov_b64 exec, 0xffff\n\t"
                 "v_sub_u32 v52, %[top], %[raw]\n\t"
@@ -1027,6 +738,27 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_mov_b32 v56, %[seq]\n\t"
                 "v_mov_b32 v57, s58\n\t"
                 "ds_write_b64 %[rdy], v[56:57] offset:64\n\t"
+#if CCD_BPX_WIDE == 32
+                "s_branch 22f\n\t"
+                // ---- the same for a full 32-symbol batch (8-pixel tasks): half the hand-overs per symbol; its first 16 symbols are
+                // published half-way, so progress reaches the producers as often as with 16-symbol batches
+                ".p2align 6\n\t"
+                "70:\n\t"
+#include "ccd_dec_block32.inc"
+                // ---- end of a full batch: the same hand-over as at 2: with a constant lane mask ...
+                "s_bfm_b64 exec, 32, 0\n\t"
+                "v_sub_u32 v52, %[top], %[raw]\n\t"
+                "v_add_u32 v52, 1, v52\n\t"
+                "ds_write_b8 %[ring], v52\n\t"
+                "global_store_byte %[goff], v52, %[lat]\n\t"
+                "s_mov_b64 exec, -1\n\t"
+                "ds_write_b32 v51, %[zero]\n\t"
+                "s_add_u32 %[seq], %[seq], 1\n\t"
+                "s_add_u32 s58, %[pix0], %[i]\n\t"
+                "v_mov_b32 v56, %[seq]\n\t"
+                "v_mov_b32 v57, s58\n\t"
+                "ds_write_b64 %[rdy], v[56:57] offset:64\n\t"
+#endif
                 // ---- ... then the next batch of this step (if any): its ready counter, top symbols and first two rows are requested
                 // straight into the registers the loop uses (the finished batch's are dead by now); LDS answers a wave in order
                 // and producers store rows before they count a part in, so a counter that reads complete vouches for the rows
@@ -1058,9 +790,19 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_readfirstlane_b32 s59, v54\n\t"
                 "s_cmp_eq_u32 s59, s57\n\t"
                 "s_cbranch_scc0 23f\n\t"
+#if CCD_BPX_WIDE == 32
+                "s_cmp_eq_u32 s58, s69\n\t"
+                "s_cbranch_scc0 1b\n\t"
+                "s_cmp_eq_u32 s69, 32\n\t"
+                "s_cbranch_scc1 70b\n\t"
+                "s_cmp_eq_u32 s69, 16\n\t"
+                "s_cbranch_scc1 80b\n\t"
+                "s_branch 1b\n\t"
+#else
                 "s_cmp_eq_u32 s58, 16\n\t"
                 "s_cbranch_scc1 80b\n\t"
                 "s_branch 1b\n\t"
+#endif
                 // not complete when asked: poll it like a batch entered from the top (v51 = its counter, v53 = its top symbols)
                 "23:\n\t"
                 "s_mov_b32 s68, 0\n\t"
@@ -1098,90 +840,10 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "10:\n\t"
                 "s_mov_b32 %[st], 0\n\t"
                 "s_branch 4f\n\t"
-                "81:\n\t"
-                "s_branch 40b\n\t"
-                "82:\n\t"
-                "s_mov_b64 s[42:43], s[52:53]\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
-                "s_mov_b64 s[48:49], s[42:43]\n\t"
-                "s_add_u32 %[i], %[i], 1\n\t"
-                "s_branch 41b\n\t"
-                "83:\n\t"
-                "s_add_u32 %[i], %[i], 2\n\t"
-                "s_branch 42b\n\t"
-                "84:\n\t"
-                "s_mov_b64 s[42:43], s[52:53]\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
-                "s_mov_b64 s[48:49], s[42:43]\n\t"
-                "s_add_u32 %[i], %[i], 3\n\t"
-                "v_add_u32 v50, 0x600, v50\n\t"
-                "s_branch 40b\n\t"
-                "85:\n\t"
-                "s_add_u32 %[i], %[i], 4\n\t"
-                "v_add_u32 v50, 0x600, v50\n\t"
-                "s_branch 41b\n\t"
-                "86:\n\t"
-                "s_mov_b64 s[42:43], s[52:53]\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
-                "s_mov_b64 s[48:49], s[42:43]\n\t"
-                "s_add_u32 %[i], %[i], 5\n\t"
-                "v_add_u32 v50, 0x600, v50\n\t"
-                "s_branch 42b\n\t"
-                "87:\n\t"
-                "s_add_u32 %[i], %[i], 6\n\t"
-                "v_add_u32 v50, 0xc00, v50\n\t"
-                "s_branch 40b\n\t"
-                "88:\n\t"
-                "s_mov_b64 s[42:43], s[52:53]\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
-                "s_mov_b64 s[48:49], s[42:43]\n\t"
-                "s_add_u32 %[i], %[i], 7\n\t"
-                "v_add_u32 v50, 0xc00, v50\n\t"
-                "s_branch 41b\n\t"
-                "89:\n\t"
-                "s_add_u32 %[i], %[i], 8\n\t"
-                "v_add_u32 v50, 0xc00, v50\n\t"
-                "s_branch 42b\n\t"
-                "90:\n\t"
-                "s_mov_b64 s[42:43], s[52:53]\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
-                "s_mov_b64 s[48:49], s[42:43]\n\t"
-                "s_add_u32 %[i], %[i], 9\n\t"
-                "v_add_u32 v50, 0x1200, v50\n\t"
-                "s_branch 40b\n\t"
-                "91:\n\t"
-                "s_add_u32 %[i], %[i], 10\n\t"
-                "v_add_u32 v50, 0x1200, v50\n\t"
-                "s_branch 41b\n\t"
-                "92:\n\t"
-                "s_mov_b64 s[42:43], s[52:53]\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
-                "s_mov_b64 s[48:49], s[42:43]\n\t"
-                "s_add_u32 %[i], %[i], 11\n\t"
-                "v_add_u32 v50, 0x1200, v50\n\t"
-                "s_branch 42b\n\t"
-                "93:\n\t"
-                "s_add_u32 %[i], %[i], 12\n\t"
-                "v_add_u32 v50, 0x1800, v50\n\t"
-                "s_branch 40b\n\t"
-                "94:\n\t"
-                "s_mov_b64 s[42:43], s[52:53]\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
-                "s_mov_b64 s[48:49], s[42:43]\n\t"
-                "s_add_u32 %[i], %[i], 13\n\t"
-                "v_add_u32 v50, 0x1800, v50\n\t"
-                "s_branch 41b\n\t"
-                "95:\n\t"
-                "s_add_u32 %[i], %[i], 14\n\t"
-                "v_add_u32 v50, 0x1800, v50\n\t"
-                "s_branch 42b\n\t"
-                "96:\n\t"
-                "s_mov_b64 s[42:43], s[52:53]\n\t"
-                "s_mov_b64 s[52:53], s[48:49]\n\t"
-                "s_mov_b64 s[48:49], s[42:43]\n\t"
-                "s_add_u32 %[i], %[i], 15\n\t"
-                "v_add_u32 v50, 0x1e00, v50\n\t"
-                "s_branch 40b\n\t"
+#include "ccd_dec_tramp16.inc"
+#if CCD_BPX_WIDE == 32
+#include "ccd_dec_tramp32.inc"
+#endif
                 "15:\n\t"
                 "s_mov_b32 %[st], 3\n\t"
                 "s_branch 4f\n\t"
@@ -1541,7 +1203,7 @@ template <int NV, int kLpp, bool MF, bool DYN_RING, bool DYN>
 __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned long long* prof) {
     constexpr int in_pad = 4 * NV;
     constexpr int kTaskPix = 64 / kLpp;
-    constexpr int kBpx = kTaskPix == 2 ? 8 : 16;   // pixels per decoder batch (see decoder_grid)
+    constexpr int kBpx = kTaskPix == 2 ? 8 : (kTaskPix == 8 ? kBpxWide : 16);   // pixels per decoder batch (see decoder_grid)
     constexpr int kHalves = kBpx / kTaskPix;
     constexpr int kNSlots = kRows / kBpx;
     constexpr int NOUT = (in_pad + kLpp - 1) / kLpp;  // outputs per lane in a hidden layer
@@ -1594,7 +1256,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
         }
     }
     (void)mf_dxy; (void)mf_wl;
-    constexpr uint32_t kTaskShift = kTaskPix == 8 ? 3 : (kTaskPix == 4 ? 2 : 1), kBpxShift = kBpx == 16 ? 4 : 3, kHalvesShift = kBpxShift - kTaskShift;
+    constexpr uint32_t kTaskShift = kTaskPix == 8 ? 3 : (kTaskPix == 4 ? 2 : 1), kBpxShift = kBpx == 32 ? 5 : (kBpx == 16 ? 4 : 3), kHalvesShift = kBpxShift - kTaskShift;
     StepWalk it;
     it.init(static_cast<uint32_t>(uni(C.H)), static_cast<uint32_t>(W));
     uint32_t seq = seq_base;
