@@ -396,6 +396,11 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_sub_u32 s63, %[gw], 9\n\t"
                 "s_sub_u32 s64, %[gw], 10\n\t"
                 "s_mov_b32 s65, 0\n\t"               // 1: the batch is decoded part by part (see 27:)
+                "s_cmp_eq_u32 s69, 16\n\t"
+                "s_cselect_b32 s61, 1, 0\n\t"
+                "s_mul_i32 s72, %[n], s61\n\t"       // steps shorter than i + 16 have no full batch ahead; 0: no unrolled block on this grid
+                "s_lshr_b32 s73, 16, %[tshift]\n\t"
+                "s_bfm_b32 s73, s73, 0\n\t"          // ready word of a full 16-symbol batch
                 "s_cmp_eq_u32 %[mode], 0\n\t"
                 "s_cbranch_scc0 6f\n\t"
                 // ---- batch start: symbol index i is the first of a batch
@@ -774,6 +779,24 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_lshl_add_u32 v50, s56, 9, %[tabl]\n\t"
                 "ds_read_b64 v[40:41], v50\n\t"
                 "ds_read_b64 v[42:43], v50 offset:512\n\t"
+#if CCD_BPX_WIDE == 16
+                // a FULL batch of this step ahead (the common case on the wide grids): its end index needs no clamp, its ready word
+                // is compared with the constant "all parts", and nothing else is tested (s72 = n on grids with 16-symbol batches,
+                // 0 on the others: never full)
+                "s_add_u32 s54, %[i], s69\n\t"
+                "s_cmp_le_u32 s54, s72\n\t"
+                "s_cbranch_scc0 25f\n\t"
+                "v_add_u32 %[ring], s71, %[ring]\n\t"
+                "v_and_b32 %[ring], %[rmask], %[ring]\n\t"
+                "v_add_u32 %[goff], %[gstride], %[goff]\n\t"
+                "s_waitcnt lgkmcnt(3)\n\t"          // the counter (the first of the four answers)
+                "v_readfirstlane_b32 s59, v54\n\t"
+                "s_cmp_eq_u32 s59, s73\n\t"
+                "s_cbranch_scc1 80b\n\t"
+                "s_mov_b32 s57, s73\n\t"
+                "s_branch 23f\n\t"
+                "25:\n\t"
+#endif
                 "s_cmp_lt_u32 %[i], %[n]\n\t"
                 "s_cbranch_scc0 30f\n\t"
                 "s_add_u32 s54, %[i], s69\n\t"
@@ -827,6 +850,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_lshr_b32 s60, s60, 19\n\t"
                 "s_add_u32 s60, s60, 1\n\t"
                 "s_min_u32 %[n], s60, %[hy]\n\t"
+                "s_mul_i32 s72, %[n], s61\n\t"
                 "s_mov_b32 %[i], 0\n\t"
                 "s_min_u32 s54, s69, %[n]\n\t"
                 "v_add_u32 v52, 1, %[rbase]\n\t"
@@ -864,7 +888,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                   [gstride] "s"(glo_stride), [wbuf] "v"(wbuf), [wbase] "s"(wbase), [tabl] "v"(tab_lane), [lane] "v"(static_cast<uint32_t>(lane)),
                   [l4] "v"(lane_top_off), [lat] "s"(lat_addr)
                 : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
-                  "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60");
+                  "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60");
             if (status == 0) {
                 if (!it.raster) it.c = it.n_steps;  // every step of the grid is done
                 break;
