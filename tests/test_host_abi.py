@@ -317,3 +317,29 @@ def test_ppm_writer_matches_reference(tmp_path, bitdepth):
     with open(os.path.join(ROOT, "tests", "golden", f"ppm{bitdepth}.ppm"), "rb") as f:
         want = f.read()
     assert out.read_bytes() == want
+
+
+def test_generated_kernel_tables_are_current(tmp_path, monkeypatch):
+    """The generated pieces of the entropy kernel (the decoder's unrolled symbol blocks, the table of the device exp) are what
+    their generators write: nobody edited one side only."""
+    import importlib.util
+    import shutil
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "cool_chic_amd", "csrc")
+    names = ["ccd_dec_block16.inc", "ccd_dec_block32.inc", "ccd_dec_tramp16.inc", "ccd_dec_tramp32.inc", "ccd_exp_table.inc"]
+    # run the generators on a copy of the tree layout (they write next to the sources)
+    fake = tmp_path / "repo"
+    (fake / "tools").mkdir(parents=True)
+    (fake / "cool_chic_amd" / "csrc").mkdir(parents=True)
+    for tool, argv in (("gen_decoder_block.py", []), ("gen_exp_table.py", ["7"])):
+        dst = fake / "tools" / tool
+        shutil.copy(os.path.join(root, "tools", tool), dst)
+        monkeypatch.setattr(sys, "argv", [str(dst)] + argv)
+        spec = importlib.util.spec_from_file_location("gen_" + tool[:-3], dst)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        if hasattr(mod, "main"):
+            mod.main()
+    for n in names:
+        assert (fake / "cool_chic_amd" / "csrc" / n).read_text() == open(os.path.join(csrc, n)).read(), n
