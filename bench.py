@@ -42,6 +42,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
+SYMBOL_FLOOR_TICKS = 117.5  # bare symbol loop of the entropy kernel's decoder, ticks per symbol (tools/ubench/dcycle.hip)
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
 PROFILE_DIRS = ["profiles/r03", "profiles/r02", "profiles/r01"]
 
@@ -465,11 +466,12 @@ def main():
             "slots_on_unfused_float_path": sum(1 for k in kernels if not k & 4),
             "entropy_msym_per_s": nsym / (stage_ms["entropy"] / 1e3) / 1e6,
             # what actually bounds the dominant kernel: every stream is ONE serial range-decoder recurrence; its bare symbol
-            # loop, fully unrolled, runs at 123.8 ticks of the 2.4 GHz shader clock (tools/ubench/dloop_spec_alt.hip: the body of
-            # decoder_grid's label 80), so n streams cannot exceed n * 2.4e9 / 123.8 symbols/s however many CUs idle
-            "serial_chain_bound": {"achieved": nsym / (stage_ms["entropy"] / 1e3) / 1e6, "peak": n_frames * 2.4e9 / 123.8 / 1e6,
-                                   "unit": "Msymbol/s", "frac": (nsym / (stage_ms["entropy"] / 1e3)) / (n_frames * 2.4e9 / 123.8),
-                                   "streams": n_frames, "ticks_per_symbol_floor": 123.8},
+            # loop, fully unrolled, runs at 117.5 ticks of the 2.4 GHz shader clock (tools/ubench/dcycle.hip variant 0: the generated
+            # 16-symbol block of decoder_grid + the least a loop around it needs; the production cycle with its hand-over runs at
+            # 127.5 there), so n streams cannot exceed n * 2.4e9 / 117.5 symbols/s however many CUs idle
+            "serial_chain_bound": {"achieved": nsym / (stage_ms["entropy"] / 1e3) / 1e6, "peak": n_frames * 2.4e9 / SYMBOL_FLOOR_TICKS / 1e6,
+                                   "unit": "Msymbol/s", "frac": (nsym / (stage_ms["entropy"] / 1e3)) / (n_frames * 2.4e9 / SYMBOL_FLOOR_TICKS),
+                                   "streams": n_frames, "ticks_per_symbol_floor": SYMBOL_FLOOR_TICKS},
             "roofline": {"bound": "hbm", "kernel": f"entropy_pipe_kernel<5, false> ({n_frames} streams, one workgroup each)", "achieved": ent_ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ent_ach / HBM_PEAK_GBS, "traffic": traffic("entropy_pipe_kernel"),
                          "algorithmic_bytes": ent_bytes, "ms_per_launch": stage_ms["entropy"],
