@@ -729,7 +729,11 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 // between s[52:53] (even symbols) and s[48:49] (odd): no copy of the new range; odd trampolines swap them back.
                 ".p2align 6\n\t"
                 "80:\n\t"
+#ifdef CCD_BLOCK_TEST_EVERY_SYMBOL
 #include "ccd_dec_block16.inc"
+#else
+#include "ccd_dec_block16p.inc"   // one renormalisation / sentinel test per two symbols (tools/gen_decoder_block.py: block_paired)
+#endif
                 // ---- end of a full batch: the same hand-over as at 2: with a constant lane mask ...
                 "s_mov_b64 exec, 0xffff\n\t"
                 "v_sub_u32 v52, %[top], %[raw]\n\t"
@@ -864,7 +868,11 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "10:\n\t"
                 "s_mov_b32 %[st], 0\n\t"
                 "s_branch 4f\n\t"
+#ifdef CCD_BLOCK_TEST_EVERY_SYMBOL
 #include "ccd_dec_tramp16.inc"
+#else
+#include "ccd_dec_tramp16p.inc"
+#endif
 #if CCD_BPX_WIDE == 32
 #include "ccd_dec_tramp32.inc"
 #endif
@@ -888,7 +896,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                   [gstride] "s"(glo_stride), [wbuf] "v"(wbuf), [wbase] "s"(wbase), [tabl] "v"(tab_lane), [lane] "v"(static_cast<uint32_t>(lane)),
                   [l4] "v"(lane_top_off), [lat] "s"(lat_addr)
                 : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
-                  "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60");
+                  "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60");
             if (status == 0) {
                 if (!it.raster) it.c = it.n_steps;  // every step of the grid is done
                 break;

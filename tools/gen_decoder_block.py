@@ -67,12 +67,100 @@ def trampolines(n, tramp0):
     return out
 
 
+# ---- the 16-symbol block with ONE renormalisation / sentinel test per TWO symbols --------------------------------------------
+# A not-taken s_cbranch costs ~17 ticks on this chain.  An even symbol is not tested at all: if its new range has a zero high
+# word, the odd symbol behind it computes garbage from a tiny scale, and the test after that one (min of the two high words)
+# sends both back: nothing of the even symbol's inputs has been overwritten by then - the range rotates through THREE register
+# pairs, the distance through two, the hit lane's products and index through two sets - so the trampoline hands the even
+# symbol to the loop's handler exactly as the per-symbol test would have.
+RP = [("s52", "s53"), ("s48", "s49"), ("s74", "s75")]   # range pairs: symbol j reads RP[j % 3], writes RP[(j + 1) % 3]
+DP = [("s50", "s51"), ("s76", "s77")]                    # distance pairs: symbol j compares DP[j % 2], writes DP[(j + 1) % 2]
+HS = [("s46", "s47", "s44"), ("s78", "s79", "s80")]      # (scale * L low, high, hit lane) of even / odd symbols
+
+
+def pair(p):
+    return "s[%s:%s]" % (p[0][1:], p[1][1:])
+
+
+def block_paired(n, tramp0):
+    assert n % 2 == 0
+    out = []
+    for j in range(n):
+        cur_l, cur_p, nxt = PAIRS[j % 3]
+        rcur, rnew = RP[j % 3], RP[(j + 1) % 3]
+        dcur, dnew = DP[j % 2], DP[(j + 1) % 2]
+        lp_lo, lp_hi, lane = HS[j % 2]
+        out += [q("s_lshr_b64 s[40:41], %s, 24" % pair(rcur)),
+                q("ds_read_b64 %s, v50 offset:%d" % (nxt, 512 * (j + 2))),
+                q("s_waitcnt lgkmcnt(2)"),
+                q("v_mad_u64_u32 v[44:45], s[42:43], s40, %s, 0" % cur_l),
+                q("v_mad_u32_u24 v45, %s, s41, v45" % cur_l),
+                q("v_cmpx_ge_u64 vcc, %s, v[44:45]" % pair(dcur)),
+                q("v_mad_u64_u32 v[48:49], s[42:43], s40, %s, 0" % cur_p),
+                q("v_mad_u32_u24 v49, %s, s41, v49" % cur_p),
+                q("s_ff1_i32_b64 %s, vcc" % lane),
+                q("v_writelane_b32 %%[raw], %s, %d" % (lane, j)),
+                q("v_readfirstlane_b32 %s, v48" % rnew[0]),
+                q("v_readfirstlane_b32 %s, v49" % rnew[1]),
+                q("v_readfirstlane_b32 %s, v44" % lp_lo),
+                q("v_readfirstlane_b32 %s, v45" % lp_hi),
+                q("s_mov_b64 exec, -1")]
+        if j % 2:
+            out += [q("s_min_u32 s58, %s, %s" % (rcur[1], rnew[1])),  # high words of the new ranges of symbols j - 1 and j
+                    q("s_cmp_eq_u32 s58, 0"),
+                    q("s_cbranch_scc1 %df" % (tramp0 + j // 2))]
+        out += [q("s_sub_u32 %s, %s, %s" % (dnew[0], dcur[0], lp_lo)),
+                q("s_subb_u32 %s, %s, %s" % (dnew[1], dcur[1], lp_hi))]
+    if n % 3:  # the loop and the epilogue expect the range in s[52:53]
+        out.append(q("s_mov_b64 s[52:53], %s" % pair(RP[n % 3])))
+    out.append(q("s_add_u32 %%[i], %%[i], %d" % n))
+    return out
+
+
+def loop_conventions(e):
+    """Moves for "symbol e left the block": s[50:51] = distance in front of e, s46 / s47 / s44 = its products' low / high word and hit
+    lane, s[48:49] = its new range, s[52:53] = the range in front of it; i, v50 as the 3-copy loop wants them; then its handler."""
+    out = []
+    if DP[e % 2] != DP[0]:
+        out.append(q("s_mov_b64 s[50:51], %s" % pair(DP[e % 2])))
+    if HS[e % 2] != HS[0]:
+        out += [q("s_mov_b32 s46, %s" % HS[1][0]), q("s_mov_b32 s47, %s" % HS[1][1]), q("s_mov_b32 s44, %s" % HS[1][2])]
+    before, after = RP[e % 3], RP[(e + 1) % 3]   # -> s[52:53], s[48:49]
+    if (before, after) == (RP[0], RP[1]):
+        pass
+    elif (before, after) == (RP[1], RP[2]):      # s[48:49] -> s[52:53] first, then s[74:75] -> s[48:49]
+        out += [q("s_mov_b64 s[52:53], s[48:49]"), q("s_mov_b64 s[48:49], s[74:75]")]
+    else:                                         # (RP[2], RP[0]): s[52:53] -> s[48:49] first, then s[74:75] -> s[52:53]
+        out += [q("s_mov_b64 s[48:49], s[52:53]"), q("s_mov_b64 s[52:53], s[74:75]")]
+    if e:
+        out.append(q("s_add_u32 %%[i], %%[i], %d" % e))
+    if e // 3:
+        out.append(q("v_add_u32 v50, 0x%x, v50" % (0x600 * (e // 3))))
+    out.append(q("s_branch %db" % (40 + e % 3)))
+    return out
+
+
+def trampolines_paired(n, tramp0):
+    out = []
+    for k in range(n // 2):
+        e, o = 2 * k, 2 * k + 1
+        out.append(q("%d:" % (tramp0 + k)))
+        out += [q("s_cmp_eq_u32 %s, 0" % RP[(e + 1) % 3][1]),   # the even symbol's new range
+                q("s_cbranch_scc0 %df" % (tramp0 + 50 + k))]
+        out += loop_conventions(e)
+        out.append(q("%d:" % (tramp0 + 50 + k)))
+        out += loop_conventions(o)
+    return out
+
+
 def main():
     root = Path(__file__).resolve().parents[1] / "cool_chic_amd" / "csrc"
     head = "/* Generated by tools/gen_decoder_block.py - do not edit. */\n"
     for n, tramp0, mid in ((16, 81, False), (32, 101, True)):
         (root / ("ccd_dec_block%d.inc" % n)).write_text(head + "\n".join(block(n, tramp0, mid)) + "\n")
         (root / ("ccd_dec_tramp%d.inc" % n)).write_text(head + "\n".join(trampolines(n, tramp0)) + "\n")
+    (root / "ccd_dec_block16p.inc").write_text(head + "\n".join(block_paired(16, 201)) + "\n")
+    (root / "ccd_dec_tramp16p.inc").write_text(head + "\n".join(trampolines_paired(16, 201)) + "\n")
 
 
 if __name__ == "__main__":

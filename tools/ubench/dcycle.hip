@@ -52,7 +52,11 @@ __global__ __launch_bounds__(512) void dcycle(uint64_t* out, int n_batches, int 
             "ds_read_b64 v[42:43], v50 offset:512\n\t"
             ".p2align 6\n\t"
             "80:\n\t"
+#ifdef PAIRED
+#include "ccd_dec_block16p.inc"
+#else
 #include "ccd_dec_block16.inc"
+#endif
 #if defined(VARIANT) && VARIANT >= 1
             "s_mov_b64 exec, 0xffff\n\t"
             "v_sub_u32 v52, %[top], %[raw]\n\t"
@@ -106,7 +110,11 @@ __global__ __launch_bounds__(512) void dcycle(uint64_t* out, int n_batches, int 
             "40:\n\t" "41:\n\t" "42:\n\t"
             "s_mov_b32 %[st], 1\n\t"
             "s_branch 4f\n\t"
+#ifdef PAIRED
+#include "ccd_dec_tramp16p.inc"
+#else
 #include "ccd_dec_tramp16.inc"
+#endif
             "4:\n\t"
             "s_mov_b64 %[dst], s[50:51]\n\t"
             "s_mov_b64 %[rng], s[52:53]\n\t"
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(512) void dcycle(uint64_t* out, int n_batches, int 
             : [n] "s"(n), [smask] "s"(7u), [rdy] "v"(rdy), [zero] "v"(0u), [three] "v"(3u), [rmask] "s"(511u * 64u + 63u), [gstride] "s"(64u),
               [tabl] "v"(tabl), [l4] "v"(l4), [lat] "s"(lat_addr), [pix0] "s"(pix0)
             : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",
-              "s59", "s69", "s70", "s71", "s72", "s73", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v56", "v57");
+              "s59", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v56", "v57");
         const uint64_t t1 = __builtin_amdgcn_s_memtime();
         if (lane == 0) { out[0] = t1 - t0; out[1] = rc_range; out[2] = status; out[3] = i; out[4] = rc_dist; }
         *reinterpret_cast<volatile int*>(&junk[0]) = 0x7fffffff;  // tell the busy waves to stop
@@ -148,13 +156,19 @@ int main() {
             hipDeviceSynchronize();
         }
         hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-        printf("variant %d%s, %s: %.1f ticks per 16-symbol batch = %.1f / symbol   (status %llu, symbols %llu)\n", VARIANT,
+        printf("%svariant %d%s, %s: %.1f ticks per 16-symbol batch = %.1f / symbol   (status %llu, symbols %llu, range %016llx, dist %016llx)\n",
+#ifdef PAIRED
+               "paired test, ",
+#else
+               "",
+#endif
+               VARIANT,
 #ifdef NO_GLOBAL_STORE
                " (no global store)",
 #else
                "",
 #endif
-               busy ? "seven waves reading LDS" : "alone", double(h[0]) / nb, double(h[0]) / nb / 16, (unsigned long long)h[2], (unsigned long long)h[3]);
+               busy ? "seven waves reading LDS" : "alone", double(h[0]) / nb, double(h[0]) / nb / 16, (unsigned long long)h[2], (unsigned long long)h[3], (unsigned long long)h[1], (unsigned long long)h[4]);
     }
     return 0;
 }
