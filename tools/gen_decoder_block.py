@@ -90,7 +90,8 @@ def block_paired(n, tramp0):
         rcur, rnew = RP[j % 3], RP[(j + 1) % 3]
         dcur, dnew = DP[j % 2], DP[(j + 1) % 2]
         lp_lo, lp_hi, lane = HS[j % 2]
-        out += [q("s_lshr_b64 s[40:41], %s, 24" % pair(rcur)),
+        out += [q("%d:" % (300 + j)),
+                q("s_lshr_b64 s[40:41], %s, 24" % pair(rcur)),
                 q("ds_read_b64 %s, v50 offset:%d" % (nxt, 512 * (j + 2))),
                 q("s_waitcnt lgkmcnt(2)"),
                 q("v_mad_u64_u32 v[44:45], s[42:43], s40, %s, 0" % cur_l),
@@ -111,6 +112,7 @@ def block_paired(n, tramp0):
                     q("s_cbranch_scc1 %df" % (tramp0 + j // 2))]
         out += [q("s_sub_u32 %s, %s, %s" % (dnew[0], dcur[0], lp_lo)),
                 q("s_subb_u32 %s, %s, %s" % (dnew[1], dcur[1], lp_hi))]
+    out.append(q("%d:" % (300 + n)))
     if n % 3:  # the loop and the epilogue expect the range in s[52:53]
         out.append(q("s_mov_b64 s[52:53], %s" % pair(RP[n % 3])))
     out.append(q("s_add_u32 %%[i], %%[i], %d" % n))
@@ -140,6 +142,36 @@ def loop_conventions(e):
     return out
 
 
+def renorm_in_block(x, odd, lbl_slow):
+    """Symbol x left with a new range below 2^32.  Not zero (a sentinel goes to the loop's handler): an ordinary renormalisation,
+    done here in the block's own registers - commit the symbol, shift the next payload word in - and the block goes on with
+    symbol x + 1 (an even x: the odd symbol behind it ran on a useless scale and runs again)."""
+    rn = RP[(x + 1) % 3]
+    dc, dn = DP[x % 2], DP[(x + 1) % 2]
+    lp_lo, lp_hi, _ = HS[x % 2]
+    out = [q("s_cmp_eq_u32 %s, 0" % rn[0]),
+           q("s_cbranch_scc1 %df" % lbl_slow)]
+    if odd:  # the test sits in front of an odd symbol's subtraction
+        out += [q("s_sub_u32 %s, %s, %s" % (dn[0], dc[0], lp_lo)), q("s_subb_u32 %s, %s, %s" % (dn[1], dc[1], lp_hi))]
+    out += [q("s_sub_u32 s58, %[wpos], %[wbase]"),
+            q("s_and_b32 s58, s58, 63"),
+            q("v_readlane_b32 s57, %[wbuf], s58"),
+            q("s_mov_b32 %s, %s" % (dn[1], dn[0])),
+            q("s_mov_b32 %s, s57" % dn[0]),
+            q("s_mov_b32 %s, %s" % (rn[1], rn[0])),
+            q("s_mov_b32 %s, 0" % rn[0]),
+            q("s_add_u32 %[wpos], %[wpos], 1"),
+            q("s_cmp_eq_u32 s58, 63"),
+            q("s_cbranch_scc0 %db" % (300 + x + 1))]
+    # the 64-word payload buffer is used up: leave for the refill with the loop's conventions, symbol x committed
+    if dn != DP[0]:
+        out.append(q("s_mov_b64 s[50:51], %s" % pair(dn)))
+    if rn != RP[0]:
+        out.append(q("s_mov_b64 s[52:53], %s" % pair(rn)))
+    out += [q("s_add_u32 %%[i], %%[i], %d" % (x + 1)), q("s_branch 15f")]
+    return out
+
+
 def trampolines_paired(n, tramp0):
     out = []
     for k in range(n // 2):
@@ -147,8 +179,12 @@ def trampolines_paired(n, tramp0):
         out.append(q("%d:" % (tramp0 + k)))
         out += [q("s_cmp_eq_u32 %s, 0" % RP[(e + 1) % 3][1]),   # the even symbol's new range
                 q("s_cbranch_scc0 %df" % (tramp0 + 50 + k))]
+        out += renorm_in_block(e, False, tramp0 + 200 + k)
+        out.append(q("%d:" % (tramp0 + 200 + k)))
         out += loop_conventions(e)
         out.append(q("%d:" % (tramp0 + 50 + k)))
+        out += renorm_in_block(o, True, tramp0 + 250 + k)
+        out.append(q("%d:" % (tramp0 + 250 + k)))
         out += loop_conventions(o)
     return out
 

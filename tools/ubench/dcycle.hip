@@ -27,7 +27,7 @@ __global__ __launch_bounds__(512) void dcycle(uint64_t* out, int n_batches, int 
     __syncthreads();
     if (wave == 0) {
         uint64_t rc_dist = 12345, rc_range = ~0ull;
-        uint32_t status = 0, i = 0, seq = 0, pix0 = 0;
+        uint32_t status = 0, i = 0, seq = 0, pix0 = 0, wpos = 2;
         const uint32_t n = static_cast<uint32_t>(n_batches) * 16u;
         int raw = 0, top_l = 0;
         uint32_t v_ring = static_cast<uint32_t>(lane << 6), v_goff = static_cast<uint32_t>(lane * 700);
@@ -110,6 +110,9 @@ __global__ __launch_bounds__(512) void dcycle(uint64_t* out, int n_batches, int 
             "40:\n\t" "41:\n\t" "42:\n\t"
             "s_mov_b32 %[st], 1\n\t"
             "s_branch 4f\n\t"
+            "15:\n\t"
+            "s_mov_b32 %[st], 3\n\t"
+            "s_branch 4f\n\t"
 #ifdef PAIRED
 #include "ccd_dec_tramp16p.inc"
 #else
@@ -120,9 +123,9 @@ __global__ __launch_bounds__(512) void dcycle(uint64_t* out, int n_batches, int 
             "s_mov_b64 %[rng], s[52:53]\n\t"
             "s_waitcnt lgkmcnt(0)\n\t"
             : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [i] "+s"(i), [seq] "+s"(seq), [raw] "+v"(raw), [top] "+v"(top_l), [ring] "+v"(v_ring),
-              [goff] "+v"(v_goff), [st] "=s"(status)
+              [goff] "+v"(v_goff), [st] "=s"(status), [wpos] "+s"(wpos)
             : [n] "s"(n), [smask] "s"(7u), [rdy] "v"(rdy), [zero] "v"(0u), [three] "v"(3u), [rmask] "s"(511u * 64u + 63u), [gstride] "s"(64u),
-              [tabl] "v"(tabl), [l4] "v"(l4), [lat] "s"(lat_addr), [pix0] "s"(pix0)
+              [tabl] "v"(tabl), [l4] "v"(l4), [lat] "s"(lat_addr), [pix0] "s"(pix0), [wbase] "s"(2u), [wbuf] "v"(static_cast<uint32_t>(lane * 2654435761u))
             : "memory", "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58",
               "s59", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v56", "v57");
         const uint64_t t1 = __builtin_amdgcn_s_memtime();
