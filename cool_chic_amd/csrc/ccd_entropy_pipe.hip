@@ -176,9 +176,11 @@ __device__ __forceinline__ uint32_t window_left(double mu, double rcp, int s, co
 }
 
 struct alignas(16) RowMeta {  // per table row (= pixel of a batch in flight)
-    double rcp[kRows];      // RN(1 / b)
-    int32_t mu_idx[kRows];
-    int32_t top[kRows];     // symbol of window lane 1
+    // (entry kRows of each array, and table row kRows, are DUMMIES: a lane with nothing to store stores there - an address select
+    // instead of an exec-masked store, whose skip branch costs ~17 ticks on the producers' late path even when not taken)
+    double rcp[kRows + 2];      // RN(1 / b)
+    int32_t mu_idx[kRows + 2];
+    int32_t top[kRows + 2];     // symbol of window lane 1
 };
 
 // The workgroup's dynamic LDS.  Regions are referred to by 32-bit byte offsets (LdsRef): a generic 64-bit pointer per
@@ -1703,13 +1705,10 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     const int64_t off = q8 + (q == 0 ? kMuOffset : kScaleOffset);
                     const int64_t hi = q == 0 ? kNumMu - 1 : kNumScale - 1;
                     idx = static_cast<int32_t>(off < 0 ? 0 : (off > hi ? hi : off));
-                    if (px < cnt) {
-                        if (q == 0) {
-                            meta.mu_idx[mpx] = idx;
-                        } else {
-                            meta.rcp[mpx] = C.s_rcp[idx];
-                        }
-                    }
+                    // both stores by address select (dummy entry kRows for the lanes that have nothing to say): no exec mask, no branch
+                    const bool live = px < cnt;
+                    meta.mu_idx[live && q == 0 ? mpx : kRows] = idx;
+                    meta.rcp[live && q == 1 ? mpx : kRows] = C.s_rcp[q == 1 ? idx : 0];
                 }
                 // ---- a feature of some pixel was not exact in 16 bits (never on the streams seen so far): that pixel again,
                 // in plain int64; its table parameters replace what the lines above wrote from the sentinel
@@ -1775,10 +1774,10 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         uint2 ent;
                         ent.x = left;
                         ent.y = (e == 0 || e == 15) ? 0u : ((e == 1 && ssym == kAcLo + kAlphabet - 1) ? (1u << kRcPrecision) - left : right - left);
-                        if (valid) {
-                            tab[mine * 64 + e] = ent;
-                            if (e == 0) meta.top[mi] = top;
-                        }
+                        // (address selects instead of exec-masked stores, see RowMeta)
+                        uint2* const row = valid ? tab + mine * 64 : C.s_tab + kRows * 64;
+                        row[e] = ent;
+                        meta.top[valid && e == 0 ? mi : kRows] = top;
                     }
                 }
                 unsigned rest = MF ? narrow_mask : 0u;
@@ -1910,7 +1909,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     constexpr int kActRows = MF ? 16 : 8;
     C.s_a = reinterpret_cast<uint32_t*>(C.s_act + kProducers * kActRows * in_pad);
     C.s_tab = reinterpret_cast<uint2*>(static_cast<uint32_t*>(C.s_a) + (MF ? mf_tables(n_layers) * 256 : 0));
-    C.s_meta = reinterpret_cast<RowMeta*>(C.s_tab + kRows * 64);
+    C.s_meta = reinterpret_cast<RowMeta*>(C.s_tab + (kRows + 1) * 64);
     double* s_rcp = reinterpret_cast<double*>(C.s_meta + 1);
     C.s_rcp = s_rcp;
     double* s_exp = s_rcp + kNumScale + 1;
@@ -2193,7 +2192,7 @@ size_t entropy_pipe_lds_bytes(int dim, int n_layers, int ring_rows, int mfma) {
     const int in_pad = (dim + 3) & ~3;
     const int n_w_total = (n_layers - 1) * dim * in_pad + 4 * in_pad;
     const int n_b_total = (n_layers - 1) * dim + 4;
-    size_t n = static_cast<size_t>(kRows) * 64 * sizeof(uint2);
+    size_t n = static_cast<size_t>(kRows + 1) * 64 * sizeof(uint2);
     n += sizeof(RowMeta);
     n += static_cast<size_t>((n_w_total + 3) & ~3) * 4;
     n += static_cast<size_t>((n_b_total + 1) & ~1) * 8;
