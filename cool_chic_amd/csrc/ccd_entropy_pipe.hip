@@ -1249,7 +1249,11 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     const int dim = uni(C.dim), n_layers = uni(C.n_layers), n_sp = uni(C.n_sp), W = uni(C.W);
     const int k_left = uni(C.k_left), fin = uni(C.fin), fw = uni(C.fw);
     const uint32_t seq_base = uni(C.seq_base);
-    int32_t* act = C.s_act + pw * (MF ? 16 : 8) * in_pad;  // this wave's activation tile [kTaskPix][in_pad] (MF: [16][in_pad], the exact redo)
+    // this wave's activation tile [kTaskPix][in_pad] (MF: [16][in_pad], the exact redo) + 4 dummy words (stores of lanes that own
+    // no activation go there by address select: no exec mask, no skip branch)
+    int32_t* act = C.s_act + pw * ((MF ? 16 : 8) * in_pad + 4);
+    int32_t* const act_dummy = act + (MF ? 16 : 8) * in_pad;
+    (void)act_dummy;
     const int px = MF ? (lane & 15) : lane / kLpp;   // pixel of the task
     const int q = MF ? (lane >> 4) : lane % kLpp;    // lane within the pixel's group (MF: K-slot group of the matrix operands)
     const int ring_mask = DYN_RING ? uni(C.ring_mask) : kRingRows - 1, n_if = uni(C.n_if), mf_bits = uni(P.mfma);
@@ -1543,23 +1547,22 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 #pragma unroll
                     for (int j = 0; j < (kTaskPix * 24 + 63) / 64; ++j) {
                         const int t = lane + 64 * j, row = t / 24, e2 = t - 24 * row;
-                        if (row < cnt) *reinterpret_cast<u32x4*>(&tab0[row * 64 + 16 + 2 * e2]) = z4;
+                        uint2* const dst = row < cnt ? &tab0[row * 64 + 16 + 2 * e2] : C.s_tab + kRows * 64 + 16 + 2 * (e2 % 24);  // (dummy row)
+                        *reinterpret_cast<u32x4*>(dst) = z4;
                     }
                 }
                 // ---- gather: lane q of the pixel's group fetches inputs k = q, q + 8, ... --------------------------
-                if (px < cnt) {
+                {   // every lane, branch-free: a lane of a pixel that does not exist fills its own (unused) row of the tile, a lane
+                    // without an input stores to the dummy words; the ring read is unconditional (its offsets are 0 where there is no
+                    // spatial context: the cell of the pixel itself, in bounds) and selected afterwards
 #pragma unroll
                     for (int t = 0; t < NOUT; ++t) {
                         const int k = q + kLpp * t;
-                        if (k < in_pad) {
-                            int32_t v = fv[t];
-                            if (k < n_sp) {
-                                const int yy = y - ctx_dy_l[t], xx = x + ctx_dx_l[t];
-                                v = (yy >= 0 && xx >= 0 && xx < W && !(split && k == k_left))
-                                        ? C.s_ring[(yy & ring_mask) * 64 + ((xx + 10 * yy) & 63)] : 0;
-                            }
-                            act[px * in_pad + k] = v << 16;  // armint.py:193
-                        }
+                        const int yy = y - ctx_dy_l[t], xx = x + ctx_dx_l[t];
+                        const int32_t r = C.s_ring[(yy & ring_mask) * 64 + ((xx + 10 * yy) & 63)];
+                        const int32_t v = k < n_sp ? ((yy >= 0 && xx >= 0 && xx < W && !(split && k == k_left)) ? r : 0) : fv[t];
+                        int32_t* const dst = k < in_pad ? act + px * in_pad + k : act_dummy;
+                        *dst = v << 16;  // armint.py:193
                     }
                 }
                 PROF_ADD(prof[1], t_g);
@@ -1644,7 +1647,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         mad64(acc0[t], xleft, wleft[t]);
                         const int o = q + kLpp * t;
                         const int64_t a = acc0[t] < 0 ? 0 : acc0[t];
-                        if (o < in_pad) act[px * in_pad + o] = o < dim ? static_cast<int32_t>(a >> 16) : 0;
+                        int32_t* const dst = o < in_pad ? act + px * in_pad + o : act_dummy;
+                        *dst = o < dim ? static_cast<int32_t>(a >> 16) : 0;
                     }
 #pragma unroll
                     for (int v = 0; v < NV; ++v) xv[v] = act_row[v];
@@ -1679,7 +1683,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     for (int t = 0; t < NOUT; ++t) {
                         const int o = q + kLpp * t;
                         const int64_t a = acc[t] < 0 ? 0 : acc[t];
-                        if (o < in_pad) act[px * in_pad + o] = o < dim ? static_cast<int32_t>(a >> 16) : 0;
+                        int32_t* const dst = o < in_pad ? act + px * in_pad + o : act_dummy;
+                        *dst = o < dim ? static_cast<int32_t>(a >> 16) : 0;
                     }
 #pragma unroll
                     for (int v = 0; v < NV; ++v) xv[v] = act_row[v];
@@ -1907,7 +1912,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     const int n_b_total = (n_layers - 1) * dim + 4;
     C.s_act = reinterpret_cast<int32_t*>(C.s_b + ((n_b_total + 1) & ~1));
     constexpr int kActRows = MF ? 16 : 8;
-    C.s_a = reinterpret_cast<uint32_t*>(C.s_act + kProducers * kActRows * in_pad);
+    C.s_a = reinterpret_cast<uint32_t*>(C.s_act + kProducers * (kActRows * in_pad + 4));
     C.s_tab = reinterpret_cast<uint2*>(static_cast<uint32_t*>(C.s_a) + (MF ? mf_tables(n_layers) * 256 : 0));
     C.s_meta = reinterpret_cast<RowMeta*>(C.s_tab + (kRows + 1) * 64);
     double* s_rcp = reinterpret_cast<double*>(C.s_meta + 1);
@@ -1945,7 +1950,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         }
         if (tid < 2) C.s_b[(n_layers - 1) * dim + 2 + tid] = src[dim * 2 + tid];
     }
-    for (int i = tid; i < kProducers * kActRows * in_pad; i += kPipeThreads) C.s_act[i] = 0;
+    for (int i = tid; i < kProducers * (kActRows * in_pad + 4); i += kPipeThreads) C.s_act[i] = 0;
     if constexpr (MF) {
         __syncthreads();  // the int32 weights are staged
         mf_build_tables(C, in_pad, C.s_a, tid);
@@ -2196,7 +2201,7 @@ size_t entropy_pipe_lds_bytes(int dim, int n_layers, int ring_rows, int mfma) {
     n += sizeof(RowMeta);
     n += static_cast<size_t>((n_w_total + 3) & ~3) * 4;
     n += static_cast<size_t>((n_b_total + 1) & ~1) * 8;
-    n += static_cast<size_t>(kProducers) * (mfma ? 16 : 8) * in_pad * 4;
+    n += static_cast<size_t>(kProducers) * ((mfma ? 16 : 8) * in_pad + 4) * 4;
     if (mfma) n += static_cast<size_t>(mf_tables(n_layers)) * 1024;
     n += static_cast<size_t>(ring_rows) * 64;
     n += static_cast<size_t>(kNumScale + 1) * 8 + static_cast<size_t>(kExpN) * 8;
