@@ -1325,11 +1325,16 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // ---- IFCE features do not depend on this grid: fetch them before waiting on the decoder -------
                 int32_t fv[NOUT];
 #pragma unroll
-                for (int t = 0; t < NOUT; ++t) {
-                    const int k = q + kLpp * t;
-                    fv[t] = 0;
-                    if (!MF && px < cnt && k >= n_sp && k < dim && fin > 0)
-                        fv[t] = ifce_feat[(k - n_sp) * feat_plane + (y >> 1) * fw + (x >> 1)];
+                for (int t = 0; t < NOUT; ++t) fv[t] = 0;
+                if (!MF && fin > 0) {  // (wave-uniform) every lane loads: a lane without a feature reads the plane's first sample and drops it
+                    const int fo = (y >> 1) * fw + (x >> 1);
+#pragma unroll
+                    for (int t = 0; t < NOUT; ++t) {
+                        const int k = q + kLpp * t;
+                        const bool has = px < cnt && k >= n_sp && k < dim;
+                        const int32_t f = ifce_feat[has ? (k - n_sp) * feat_plane + fo : 0];
+                        fv[t] = has ? f : 0;
+                    }
                 }
                 // dynamic operand check (see exact_pixel): a sentinel among the task's features.  Known BEFORE the waits, so the
                 // critical path only carries one scalar test of this mask.
@@ -1694,9 +1699,9 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 // output layer (q = 0: mu, q = 1: log-scale) -> table indices -> per-pixel table parameters
                 const int mpx = slot * kBpx + half * kTaskPix + px;  // table row of the pixel
                 int32_t idx = 0;
-                if (q < 2) {
-                    const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + q * in_pad);
-                    int64_t ao[2] = {C.s_b[(n_layers - 1) * dim + q] + stab, 0};
+                {   // (every lane: lanes q >= 2 compute a discarded copy of row 1, like the stabiliser - no exec mask around the block)
+                    const int4* wr = reinterpret_cast<const int4*>(C.s_w + C.n_w_hidden + qs * in_pad);
+                    int64_t ao[2] = {C.s_b[(n_layers - 1) * dim + qs] + stab, 0};
                     int4 wv[NV];
 #pragma unroll
                     for (int v = 0; v < NV; ++v) wv[v] = wr[v];
