@@ -1564,7 +1564,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     for (int t = 0; t < NOUT; ++t) {
                         const int k = q + kLpp * t;
                         const int yy = y - ctx_dy_l[t], xx = x + ctx_dx_l[t];
-                        const int32_t r = C.s_ring[(yy & ring_mask) * 64 + ((xx + 10 * yy) & 63)];
+                        int32_t r = C.s_ring[(yy & ring_mask) * 64 + ((xx + 10 * yy) & 63)];
+                        asm volatile("" : "+v"(r));  // (a use the compiler cannot sink the read behind: it stays unconditional)
                         const int32_t v = k < n_sp ? ((yy >= 0 && xx >= 0 && xx < W && !(split && k == k_left)) ? r : 0) : fv[t];
                         int32_t* const dst = k < in_pad ? act + px * in_pad + k : act_dummy;
                         *dst = v << 16;  // armint.py:193
@@ -1783,7 +1784,11 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                         const uint32_t right = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(left), 0x111, 0xf, 0xf, false));
                         uint2 ent;
                         ent.x = left;
-                        ent.y = (e == 0 || e == 15) ? 0u : ((e == 1 && ssym == kAcLo + kAlphabet - 1) ? (1u << kRcPrecision) - left : right - left);
+                        // P = right - left; the window's top entry of a window that reaches symbol 63 runs to 2^24; the two sentinels
+                        // get 0 - as arithmetic on selects (written with ?: inside ?: this compiled to three nested skip branches)
+                        const uint32_t to_full = (e == 1 && ssym == kAcLo + kAlphabet - 1) ? (1u << kRcPrecision) - right : 0u;
+                        const uint32_t keep = (e == 0 || e == 15) ? 0u : ~0u;
+                        ent.y = (right - left + to_full) & keep;
                         // (address selects instead of exec-masked stores, see RowMeta)
                         uint2* const row = valid ? tab + mine * 64 : C.s_tab + kRows * 64;
                         row[e] = ent;
