@@ -262,8 +262,12 @@ __device__ __forceinline__ uint64_t uni(uint64_t v) {
 }
 
 // Spin until *p >= want (sequence numbers only grow). Returns false on abort / timeout.
-__device__ __forceinline__ bool wait_ge(const uint32_t* p, uint32_t want, uint32_t* s_abort) {
-    if (static_cast<int32_t>(lds_load_acquire(p) - want) >= 0) return true;
+// (the wanted values are wave-uniform but reach these functions in vector registers: stated scalar here, or every poll compares
+// on the vector ALU and branches on VCC.  The first look is kept apart from the loop: where the producers are the limit it
+// succeeds, and the loop's exit bookkeeping stays off that path.)
+__device__ __forceinline__ bool wait_ge(const uint32_t* p, uint32_t want_v, uint32_t* s_abort) {
+    const uint32_t want = uni(want_v);
+    if (__builtin_expect(static_cast<int32_t>(lds_load_acquire(p) - want) >= 0, 1)) return true;
     unsigned spins = 0;
     while (static_cast<int32_t>(lds_load_acquire(p) - want) < 0) {
         // no s_sleep: the waits of this pipeline are short, and waking up costs more than the polling LDS reads (measured)
@@ -276,11 +280,16 @@ __device__ __forceinline__ bool wait_ge(const uint32_t* p, uint32_t want, uint32
 }
 
 // The decoder's progress is a pair (batches, pixels) in one aligned 64-bit LDS word: one read serves both conditions.
-__device__ __forceinline__ bool wait_ge2(const uint32_t* p, uint32_t want_batches, uint32_t want_pixels, uint32_t* s_abort) {
+__device__ __forceinline__ bool progress_reached(const uint32_t* p, uint32_t want_batches, uint32_t want_pixels) {
+    const uint64_t v = uni(__hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+    // (| of two sign bits, not &&: one scalar test)
+    return static_cast<int32_t>((static_cast<uint32_t>(v) - want_batches) | (static_cast<uint32_t>(v >> 32) - want_pixels)) >= 0;
+}
+__device__ __forceinline__ bool wait_ge2(const uint32_t* p, uint32_t want_batches_v, uint32_t want_pixels_v, uint32_t* s_abort) {
+    const uint32_t want_batches = uni(want_batches_v), want_pixels = uni(want_pixels_v);
+    if (__builtin_expect(progress_reached(p, want_batches, want_pixels), 1)) return true;
     unsigned spins = 0;
-    while (true) {
-        const uint64_t v = uni(__hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-        if (static_cast<int32_t>(static_cast<uint32_t>(v) - want_batches) >= 0 && static_cast<int32_t>(static_cast<uint32_t>(v >> 32) - want_pixels) >= 0) break;
+    while (!progress_reached(p, want_batches, want_pixels)) {
         if ((++spins & 1023u) == 0) {
             if (lds_load_acquire(s_abort) != 0) return false;
             if (spins > kSpinLimit) { lds_store_release(s_abort, static_cast<uint32_t>(-CCD_ERR_HIP)); return false; }
