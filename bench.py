@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X Cool-chic decoder on BASELINE.json's metric: decoded Mpixel/s.
 
-    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong] [--legs a,b,..] [--no-cpu-baseline]
+    python bench.py --gpus N --steps K --warmup W [--scaling strong|weak|throughput] [--legs a,b,..] [--no-cpu-baseline]
     (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 `value` = BASELINE configs[1] (config.workload = "kodak24"): the Kodak-24 set - 24 RGB 8-bit 512x768 frames (18
@@ -16,15 +16,20 @@ Beside the metric (never as `value`), rank 0 reports one leg per other BASELINE 
 `more_frames_in_flight` (kodak24 x 8: the chip-filling regime), `with_png_packing`, `end_to_end_from_bytes`, the
 per-orientation entropy times and the float-stage roofline.
 
-N GPUs: --scaling weak (default): every rank decodes its own 24 frames; --scaling strong: ONE fixed set (kodak24 x 8 =
-192 frames) is split round-robin over the ranks.  Either way rank 0 gathers the decoded planes over RCCL inside the
-timed region.  BASELINE's own sets (24 / 41 frames, 66 cool-chics per GOP) keep 9-26 % of ONE GPU's CUs busy - a stream
-is one serial range-decoder chain on one CU - so they do not strong-scale: their time is the slowest stream's.
+N GPUs: --scaling strong (default) = what BASELINE.json names: the 24 frames of kodak24 sharded round-robin over the ranks
+(frame i -> rank i mod N), rank 0 gathers the decoded planes over RCCL inside the timed region.  BASELINE's own sets (24 /
+41 frames, 66 cool-chics per GOP) keep 9-26 % of ONE GPU's CUs busy - a stream is one serial range-decoder chain on one
+CU, and the step time is the slowest stream's - so they CANNOT strong-scale: the expected curve is flat (`expected_scaling`
+in the line says so).  Beside the metric an N > 1 run measures, with all ranks, `clic41_sharded` (BASELINE configs[2]: the
+41 pictures round-robin, strong) and `throughput_regime` (every rank its own 264 streams = kodak24 x 11, >= one stream
+per CU: the only regime that scales; also available as the metric with --scaling throughput).  --scaling weak: every
+rank its own copy of kodak24.
 
 `roofline` = the dominant kernel (entropy, a latency chain: its HBM fraction only says how far from that roof it sits);
 `roofline_float_stages` = the fused float kernel against the fp32 peak (it is compute-bound: 4.33 B/px, ~1.7 kflop/px)
-and as algorithmic GB/s; `cpu_baseline` = the CPU oracle (single-thread C port of the reference's algorithm) on a
-bounded sample.
+and as algorithmic GB/s; `rate_model` = the one genuinely HBM-bound kernel of the build (16 B / symbol) against the HBM
+peak; `cpu_baseline` = the CPU oracle (C port of the reference's algorithm) MEASURED on the host cores: every stream of
+the set at once, one oracle call per core (`cores` = threads used), with the one-core figure beside it.
 """
 import argparse
 import ctypes as C
@@ -42,9 +47,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
-SYMBOL_FLOOR_TICKS = 117.5  # bare symbol loop of the entropy kernel's decoder, ticks per symbol (tools/ubench/dcycle.hip)
+SYMBOL_FLOOR_TICKS = 111.0  # bare unrolled symbol block of the entropy kernel's decoder (paired tests), ticks per symbol (tools/ubench/dcycle.hip)
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
-PROFILE_DIRS = ["profiles/r03", "profiles/r02", "profiles/r01"]
+PROFILE_DIRS = ["profiles/r04", "profiles/r03", "profiles/r02", "profiles/r01"]
 
 
 def build_kodak24(device: int = 0):
@@ -55,8 +60,15 @@ def build_kodak24(device: int = 0):
     return [(*synth.split_image_stream(s), hw) for s, hw in zip(streams, sizes)], streams
 
 
-def cpu_sample(streams, px_each, budget_s: float, what: str):
-    """The oracle (single-thread C restatement of the reference algorithm) on a bounded sample of `streams`."""
+def cpu_sample(streams, px_each, budget_s: float, what: str, parallel: bool = True):
+    """The oracle (plain-C restatement of the reference algorithm, one thread per stream) timed on this host:
+    (a) ONE core on a bounded sample of `streams` (the first streams until `budget_s` is spent);
+    (b) `parallel`: EVERY stream of the set at once, one oracle call per stream on min(cores, streams) threads (the calls are
+        ctypes calls into libcc_oracle.so: they release the GIL and run concurrently; threads, not processes, because this
+        process holds a HIP context).  Streams are independent, so this is the CPU's whole-set throughput, measured.
+    `value` / `cores` are (b) when it ran, else (a)."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle import oracle_py
 
     oracle_py.build()
@@ -70,12 +82,20 @@ def cpu_sample(streams, px_each, budget_s: float, what: str):
             break
     dt = time.perf_counter() - t0
     cores = os.cpu_count() or 1
-    return {"value": px / dt / 1e6, "unit": "Mpixel/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} of {len(streams)} {what}, full decode to integer planes, {dt:.1f} s",
-            "host_cores_available": cores,
-            # streams are independent: one oracle process per host core is the honest CPU ceiling for a set of streams
-            "extrapolated_all_cores": {"value": px / dt / 1e6 * min(cores, len(streams)), "unit": "Mpixel/s",
-                                       "note": f"one stream per core, min(cores, streams) = {min(cores, len(streams))} at once (not run)"}}
+    one = {"value": px / dt / 1e6, "unit": "Mpixel/s", "cores": 1,
+           "sample": f"first {n} of {len(streams)} {what}, full decode to integer planes, {dt:.1f} s"}
+    out = {"value": one["value"], "unit": "Mpixel/s", "cores": 1, "kind": "port", "sample": one["sample"], "host_cores_available": cores}
+    n_thr = min(cores, len(streams))
+    if parallel and n_thr > 1:
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=n_thr) as ex:
+            list(ex.map(oracle_py.decode_video, streams))
+        dt_all = time.perf_counter() - t0
+        out.update({"value": sum(px_each) / dt_all / 1e6, "cores": n_thr,
+                    "sample": f"all {len(streams)} {what} at once, one oracle call per stream on {n_thr} threads (one per core, "
+                              f"{cores} cores available), full decode to integer planes, {dt_all:.1f} s wall",
+                    "one_core": one})
+    return out
 
 
 def event_ms(stream, fn, reps: int, device: int) -> float:
@@ -283,8 +303,77 @@ def gop_leg(device, sh, stream, steps, cpu_budget, want_cpu):
     if want_cpu:
         # a 3-frame GOP of the same cool-chics (I0 I2 B1) is the bounded CPU sample
         small, info = synth.gop1080p(2)
-        leg["cpu_baseline"] = cpu_sample([small], [info["frames"] * H * W], cpu_budget, "3-frame 1080p GOP (I0 I2 B1)")
+        leg["cpu_baseline"] = cpu_sample([small], [info["frames"] * H * W], cpu_budget, "3-frame 1080p GOP (I0 I2 B1)", parallel=False)
     return leg
+
+
+def timed_set(mine, world, rank, local_rank, backend, red_dev, steps, warmup):
+    """One image set, this rank's share of it: `mine` = [(cc_header, bytes_nn, bytes_latent, (H, W))].  Inputs go to HBM, then
+    `warmup` untimed and `steps` timed steps; a step = decode of every frame of the share + (N > 1) the gather of the decoded
+    integer planes to rank 0 inside the timed region.  Barrier + device synchronisation on both sides, MAX over ranks.
+    Returns {"dt", "batch" (still open), "gathered" (rank 0: per-rank byte messages of the last step), "stream", "sh"}."""
+    from cool_chic_amd import DecodeBatch
+    from cool_chic_amd.parallel import EqualSizeGather
+
+    dev = f"cuda:{local_rank}"
+    batch = DecodeBatch(local_rank)
+    for hdr, nn, lat, _ in mine:
+        batch.add(hdr, nn, lat, 8, 0)
+    stream = torch.cuda.current_stream(local_rank)
+    sh = stream.cuda_stream
+    n = len(mine)
+    planes = [torch.as_tensor(batch.plane_device(s_, p), device=dev).reshape(-1) for s_ in range(n) for p in range(3)]
+    n_bytes = sum(int(p.numel()) * p.element_size() for p in planes)
+    gatherer = None
+    if world > 1:  # equal message sizes: pad to the largest share
+        t = torch.tensor([n_bytes], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        pad = int(t.item()) - n_bytes
+        if pad or not planes:
+            planes.append(torch.zeros(pad, dtype=torch.uint8, device=dev))
+        gatherer = EqualSizeGather(int(t.item()), dev, dst=0)
+    gathered = [None]
+
+    def step():
+        if n:
+            batch.run(sh)
+        if gatherer is not None:  # decoded integer planes of this rank's frames -> writer rank (RCCL over xGMI), inside the timed region
+            gathered[0] = gatherer(planes)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(local_rank)
+
+    for _ in range(warmup):
+        step()
+    batch.wait(sh)  # raises on decode errors
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    batch.wait(sh)
+    return {"dt": dt, "batch": batch, "gathered": gathered[0], "stream": stream, "sh": sh}
+
+
+def verify_gathered(name, gathered, frames_of_rank):
+    """Rank 0: the planes of EVERY rank's frames as they arrived in the gather of the last timed step, against the oracle's
+    hashes.  frames_of_rank(r) = [(stream index in the workload, (H, W))] in the order rank r packed them (8-bit RGB)."""
+    frames_g, index_g = [], []
+    for r, msg in enumerate(gathered):
+        host = msg.cpu().numpy()
+        off = 0
+        for idx, (h, w) in frames_of_rank(r):
+            frames_g.append([host[off + p * h * w: off + (p + 1) * h * w].reshape(h, w) for p in range(3)])
+            index_g.append(idx)
+            off += 3 * h * w
+    return verify_frames(name, frames_g, stream_of=lambda i: index_g[i])
 
 
 def main():
@@ -292,8 +381,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--legs", default="all", help="comma list of clic41,gop1080p33,uhd4k,wide,png,e2e,float,envelope or all / none (rank 0, beside the metric)")
+    ap.add_argument("--scaling", choices=["strong", "weak", "throughput"], default="strong",
+                    help="strong (default): BASELINE's kodak24, its 24 frames round-robin over the ranks; weak: every rank its own "
+                         "kodak24; throughput: every rank its own kodak24 x 11 = 264 streams (>= one per CU)")
+    ap.add_argument("--legs", default="all", help="comma list of clic41,gop1080p33,uhd4k,wide,png,e2e,float,envelope,rate (rank 0, N = 1) and sharded (N > 1: "
+                    "clic41_sharded + throughput_regime with all ranks), or all / none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes (roofline.traffic then "
                     "comes from the tracked profile)")
@@ -316,88 +408,74 @@ def main():
         else:
             dist.init_process_group("gloo")
     red_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"  # where the scalar reductions live
-    all_legs = ["clic41", "gop1080p33", "uhd4k", "wide", "png", "e2e", "float", "envelope"]
+    all_legs = ["clic41", "gop1080p33", "uhd4k", "wide", "png", "e2e", "float", "envelope", "rate"]
     legs = all_legs if args.legs == "all" else ([] if args.legs == "none" else args.legs.split(","))
     if world > 1 and args.legs == "all":
-        legs = []  # the scaling runs measure the metric; the other configurations are single-GPU legs of the N = 1 run
+        legs = ["sharded"]  # the other configurations are single-GPU legs of the N = 1 run; with N ranks: the sharded sets
     want_cpu = not args.no_cpu_baseline
 
     from cool_chic_amd import DecodeBatch, synth
     from cool_chic_amd.parallel import EqualSizeGather, shard_indices
 
     items, streams = build_kodak24(local_rank)
-    copies = 8 if args.scaling == "strong" else 1
-    mine = list(items) * copies
-    if args.scaling == "strong":
-        mine = [mine[i] for i in shard_indices(len(mine), rank, world)]
-        px_per_step = copies * sum(h * w for *_, (h, w) in items)           # the whole fixed set
-    else:
-        px_per_step = world * sum(h * w for *_, (h, w) in items)           # every rank its own set
+    n_kodak = len(items)
+    kodak_px = sum(h * w for *_, (h, w) in items)
+    THROUGHPUT_COPIES = 11  # 264 streams per GPU >= its 256 CUs
+    if args.scaling == "strong":      # BASELINE's set itself, sharded: frame i -> rank i mod N
+        ids_of = lambda r: shard_indices(n_kodak, r, world)
+        px_per_step = kodak_px
+    elif args.scaling == "weak":      # every rank its own copy of the set
+        ids_of = lambda r: list(range(n_kodak))
+        px_per_step = world * kodak_px
+    else:                             # throughput: enough streams per GPU to give every CU one
+        ids_of = lambda r: list(range(n_kodak)) * THROUGHPUT_COPIES
+        px_per_step = world * THROUGHPUT_COPIES * kodak_px
+    mine = [items[i] for i in ids_of(rank)]
     n_frames = len(mine)
-    batch = DecodeBatch(local_rank)
-    for hdr, nn, lat, _ in mine:
-        batch.add(hdr, nn, lat, 8, 0)
-    stream = torch.cuda.current_stream(local_rank)
-    sh = stream.cuda_stream
     dev = f"cuda:{local_rank}"
+    run = timed_set(mine, world, rank, local_rank, args.backend, red_dev, args.steps, args.warmup)
+    dt, batch, stream, sh = run["dt"], run["batch"], run["stream"], run["sh"]
+    gathered = [run["gathered"]]
 
-    planes = [torch.as_tensor(batch.plane_device(s, p), device=dev).reshape(-1) for s in range(n_frames) for p in range(3)]
-    n_bytes = sum(int(p.numel()) * p.element_size() for p in planes)
-    if world > 1:  # equal message sizes: pad to the largest share
-        t = torch.tensor([n_bytes], dtype=torch.int64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        pad = int(t.item()) - n_bytes
-        if pad:
-            planes.append(torch.zeros(pad, dtype=torch.uint8, device=dev))
-        gatherer = EqualSizeGather(int(t.item()), dev, dst=0)
-    else:
-        gatherer = None
-
-    gathered = [None]
-
-    def step():
-        batch.run(sh)
-        if gatherer is not None:  # decoded integer planes of this rank's frames -> writer rank (RCCL over xGMI), inside the timed region
-            gathered[0] = gatherer(planes)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(local_rank)
-
-    for _ in range(args.warmup):
-        step()
-    batch.wait(sh)  # raises on decode errors
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    batch.wait(sh)
+    # ---- N > 1: the sets that BASELINE shards, and the regime that scales, measured with all ranks (collective: every rank runs this)
+    sharded = {}
+    if world > 1 and "sharded" in legs:
+        # (a) BASELINE configs[2]: the 41 CLIC pictures round-robin over the ranks; each rank manufactures only its own streams
+        c_ids = shard_indices(len(synth.CLIC41_SIZES), rank, world)
+        c_streams = synth.clic41_subset(c_ids)
+        c_mine = [(*synth.split_image_stream(st_), synth.CLIC41_SIZES[i]) for st_, i in zip(c_streams, c_ids)]
+        n_c = 3
+        rc = timed_set(c_mine, world, rank, local_rank, args.backend, red_dev, n_c, 1)
+        c_px = sum(h * w for h, w in synth.CLIC41_SIZES)
+        if rank == 0:
+            sharded["clic41_sharded"] = {
+                "value": c_px * n_c / rc["dt"] / 1e6, "unit": "Mpixel/s", "n_gpus": world, "steps": n_c, "ms_per_step": rc["dt"] / n_c * 1e3,
+                "scaling": "strong", "frames": len(synth.CLIC41_SIZES), "frames_on_rank0": len(c_mine),
+                "expected_scaling": "flat beyond ~2 GPUs: the step is the serial chain of the largest (2.8 Mpx) stream on one CU; 41 streams occupy 16 % of ONE GPU",
+                "verified": verify_gathered("clic41", rc["gathered"], lambda r: [(i, synth.CLIC41_SIZES[i]) for i in shard_indices(len(synth.CLIC41_SIZES), r, world)])}
+        rc["batch"].close()
+        # (b) the regime that scales: every rank its own 264 streams (weak)
+        t_mine = list(items) * THROUGHPUT_COPIES
+        n_t = 3
+        rt = timed_set(t_mine, world, rank, local_rank, args.backend, red_dev, n_t, 1)
+        if rank == 0:
+            sharded["throughput_regime"] = {
+                "value": world * THROUGHPUT_COPIES * kodak_px * n_t / rt["dt"] / 1e6, "unit": "Mpixel/s", "n_gpus": world, "steps": n_t,
+                "ms_per_step": rt["dt"] / n_t * 1e3, "scaling": "weak", "streams_per_gpu": len(t_mine),
+                "note": "every rank decodes its own kodak24 x 11 (>= one stream per CU) and rank 0 gathers all planes inside the timed region: "
+                        "the only regime of this format that scales over GPUs (expected ~N x)",
+                "verified": verify_gathered("kodak24", rt["gathered"], lambda r: [(i % n_kodak, items[i % n_kodak][3]) for i in range(len(t_mine))])}
+        rt["batch"].close()
 
     res = None
     if rank == 0:
         # ---- what was timed, against the CPU oracle (hashes of its integer planes for the same 24 streams): this rank's own
         # frames from its batch, and - N > 1 - every rank's frames as they arrived in the gather of the last timed step
-        n_kodak = len(items)
-        own_index = (lambda k: (rank + k * world) % n_kodak) if args.scaling == "strong" else (lambda k: k % n_kodak)
-        verified = verify_frames("kodak24", [batch.planes(s) for s in range(n_frames)], stream_of=own_index,
-                                 streams=streams if args.scaling == "weak" else None)
+        my_ids = ids_of(rank)
+        verified = verify_frames("kodak24", [batch.planes(s_) for s_ in range(n_frames)], stream_of=lambda k: my_ids[k],
+                                 streams=streams if n_frames == n_kodak else None)
         if world > 1 and gathered[0] is not None:
-            fb = 3 * 512 * 768  # bytes of one frame's planes in a rank's message (all 8-bit 512 x 768 RGB)
-            frames_g, index_g = [], []
-            for r, msg in enumerate(gathered[0]):
-                host = msg.cpu().numpy()
-                n_r = len(shard_indices(copies * n_kodak, r, world)) if args.scaling == "strong" else n_kodak
-                for k in range(n_r):
-                    frames_g.append([host[k * fb + p * (fb // 3): k * fb + (p + 1) * (fb // 3)] for p in range(3)])
-                    index_g.append(((r + k * world) if args.scaling == "strong" else k) % n_kodak)
-            verified["gathered"] = verify_frames("kodak24", frames_g, stream_of=lambda i: index_g[i])
+            verified["gathered"] = verify_gathered("kodak24", gathered[0], lambda r: [(i, items[i][3]) for i in ids_of(r)])
         # ---- per-stage timing with HIP events on the launch stream (roofline evidence); stage 1 (per-level upsampling) is
         # empty on the fused path
         stage_ms = {name: event_ms(stream, lambda st=st: batch.run(sh, stage=st), args.steps, local_rank)
@@ -418,7 +496,7 @@ def main():
         n_lat_px = latent_px(batch, n_frames)
 
         pmc, pmc_from = {}, None
-        if args.scaling == "weak" and world == 1 and not args.no_live_traffic:
+        if args.scaling != "throughput" and world == 1 and not args.no_live_traffic:
             pmc = measure_traffic_live()  # two short rocprofv3 --pmc passes of the same workload, outside every timed region
             if pmc:
                 pmc_from = "measured in this run"
@@ -452,11 +530,18 @@ def main():
         res = {
             "metric": "decoded Mpixel/s", "value": px_per_step * args.steps / dt / 1e6, "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "int64+f64 entropy / f32 synthesis",
+            "higher_is_better": True, "scaling": "strong" if args.scaling == "strong" else "weak", "vs_baseline": None,
+            "dtype": "int64+f64 entropy / f32 synthesis",
             "data": "synthetic (kodim14.cool real + 23 streams re-encoded from rolled/transposed kodim14 latents)",
-            "config": {"workload": "kodak24" if args.scaling == "weak" else "kodak24 x 8 (192 frames, one fixed set split over the ranks)",
-                       "frames_per_gpu": n_frames, "frame": "512x768 RGB 8-bit, HOP decoder", "symbols_per_step_rank0": nsym,
-                       "parallelism": f"frames x{world} (round-robin, gather of planes to rank 0)"},
+            "config": {"workload": {"strong": "kodak24", "weak": "kodak24 (every rank its own copy)",
+                                    "throughput": f"kodak24 x {THROUGHPUT_COPIES} per GPU ({THROUGHPUT_COPIES * n_kodak} streams in flight per GPU)"}[args.scaling],
+                       "frames_on_rank0": n_frames, "frame": "512x768 RGB 8-bit, HOP decoder", "symbols_per_step_rank0": nsym,
+                       "parallelism": (f"frame i -> rank i mod {world} (the set's 24 frames sharded), gather of planes to rank 0" if args.scaling == "strong"
+                                       else f"every rank its own frames x{world}, gather of planes to rank 0")},
+            # BASELINE's sets cannot strong-scale, by the format: a stream is ONE serial range-decoder chain on one CU and the step is the
+            # slowest stream's, so 24 frames on N GPUs take as long as on one (they occupy 9 % of one GPU's CUs); see throughput_regime
+            "expected_scaling": ("flat: one serial chain per stream - the step time is the slowest stream's on any number of GPUs (DESIGN.md 6)"
+                                 if args.scaling == "strong" else "~N x: every rank decodes its own frames"),
             "parity": "integer stages bit-exact vs reference fixtures; float stages bit-exact vs CPU oracle; integer planes <=1 LSB on "
                       "<=2e-5 of samples vs the reference decoder's output = within the reference's own thread-count noise floor "
                       "(tests/test_gpu_parity.py)",
@@ -466,13 +551,13 @@ def main():
             "slots_on_unfused_float_path": sum(1 for k in kernels if not k & 4),
             "entropy_msym_per_s": nsym / (stage_ms["entropy"] / 1e3) / 1e6,
             # what actually bounds the dominant kernel: every stream is ONE serial range-decoder recurrence; its bare symbol
-            # loop, fully unrolled, runs at 117.5 ticks of the 2.4 GHz shader clock (tools/ubench/dcycle.hip variant 0: the generated
-            # 16-symbol block of decoder_grid + the least a loop around it needs; the production cycle with its hand-over runs at
-            # 127.5 there), so n streams cannot exceed n * 2.4e9 / 117.5 symbols/s however many CUs idle
+            # block, fully unrolled, runs at 111.0 ticks of the 2.4 GHz shader clock (tools/ubench/dcycle.hip: the generated
+            # 16-symbol block of decoder_grid with paired tests + the least a loop around it needs; the production cycle with its
+            # hand-over runs at 122.3 there), so n streams cannot exceed n * 2.4e9 / 111 symbols/s however many CUs idle
             "serial_chain_bound": {"achieved": nsym / (stage_ms["entropy"] / 1e3) / 1e6, "peak": n_frames * 2.4e9 / SYMBOL_FLOOR_TICKS / 1e6,
                                    "unit": "Msymbol/s", "frac": (nsym / (stage_ms["entropy"] / 1e3)) / (n_frames * 2.4e9 / SYMBOL_FLOOR_TICKS),
                                    "streams": n_frames, "ticks_per_symbol_floor": SYMBOL_FLOOR_TICKS},
-            "roofline": {"bound": "hbm", "kernel": f"entropy_pipe_kernel<5, false> ({n_frames} streams, one workgroup each)", "achieved": ent_ach,
+            "roofline": {"bound": "hbm", "kernel": f"entropy_pipe_kernel<5, false, false> ({n_frames} streams, one workgroup each)", "achieved": ent_ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ent_ach / HBM_PEAK_GBS, "traffic": traffic("entropy_pipe_kernel"),
                          "algorithmic_bytes": ent_bytes, "ms_per_launch": stage_ms["entropy"],
                          "note": "latency-bound serial chain (one range decoder per stream): see entropy_msym_per_s, serial_chain_bound "
@@ -483,6 +568,7 @@ def main():
                               "WRITE_SIZE x 1 (profiles/r03/pmc_calibration.json)") if pmc_from == "measured in this run" else
                              f"tracked profile {pmc_from} (rocprofv3 not usable in this run)") if pmc_from else None,
         }
+        res.update(sharded)
         # ---- per-orientation entropy time: the 6 portrait streams (more, shorter wavefront steps + a network trained on a
         # landscape picture) set the step time
         if "float" in legs:
@@ -554,6 +640,69 @@ def main():
                                             "what": "24 .cool files in host memory -> integer planes in host memory: batch creation, per-stream "
                                                     "parsing + staged asynchronous uploads (ccd_batch_add), decode, one plane-block copy per frame "
                                                     "into pinned memory; comparable with cpu_baseline"}
+            # ---- the surface users call: cc_decode.py -i kodim14.cool -o x.png = decode_video(path, decoded_path), in-process:
+            # read + parse + upload + decode + PNG packed on the device + file written (cc_decode.py:12-20, decode.py:26-91)
+            import contextlib
+            import io
+            import tempfile
+
+            from cool_chic_amd.bitstream.decode import decode_video
+
+            with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+                src, dst = os.path.join(tmp, "kodim14.cool"), os.path.join(tmp, "kodim14.png")
+                with open(src, "wb") as f:
+                    f.write(streams[0])
+
+                def file_to_file():
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        decode_video(src, dst, device=local_rank)
+
+                file_to_file()
+                ms_f2f = wall_ms(file_to_file, 5, local_rank)
+                from PIL import Image
+
+                got_png = np.asarray(Image.open(dst)).transpose(2, 0, 1)
+                png_ok = verify_frames("kodak24", [[got_png[0], got_png[1], got_png[2]]])
+
+                def one_from_bytes():
+                    b1 = DecodeBatch(local_rank, keep_float=False)
+                    b1.add(*synth.split_image_stream(streams[0]), 8, 0)
+                    b1.run(sh)
+                    out1 = b1.all_planes(sh)
+                    b1.close()
+                    return out1
+
+                one_from_bytes()
+                ms_one = wall_ms(one_from_bytes, 5, local_rank)
+                res["cc_decode_file_to_png"] = {
+                    "ms": ms_f2f, "value": 512 * 768 / ms_f2f / 1e3, "unit": "Mpixel/s", "png_bytes": os.path.getsize(dst),
+                    "verified_png_readback": png_ok, "same_stream_bytes_to_host_planes_ms": ms_one,
+                    "what": "decode_video('kodim14.cool', 'kodim14.png') in-process = cc_decode.py's work for ONE picture: file read, parse, "
+                            "upload, decode (its serial chain: ~40 ms), PNG packed on the device, file written; PIL reads the file back"}
+        # ---- the rate model (arm.py:448-485): the one genuinely HBM-bound kernel of the build, 16 B per symbol
+        if "rate" in legs:
+            from cool_chic_amd.component.core.arm import compute_rate, total_rate_bits  # noqa: F401
+
+            n_sym = 1 << 26
+            g_ = torch.Generator(device=dev).manual_seed(5)
+            xr = torch.randint(-64, 64, (n_sym,), generator=g_, device=dev).float()
+            mur = xr + torch.randn(n_sym, generator=g_, device=dev) * 1.5
+            scr = torch.exp(torch.rand(n_sym, generator=g_, device=dev) * 4 - 2)
+            out_r = torch.empty_like(xr)
+            from cool_chic_amd._lib import check as _check, lib as _lib_
+
+            def rate_once():
+                _check(_lib_().ccd_compute_rate(local_rank, C.c_void_p(sh or None), C.c_void_p(xr.data_ptr()), C.c_void_p(mur.data_ptr()),
+                                                C.c_void_p(scr.data_ptr()), n_sym, C.c_void_p(out_r.data_ptr()), None), "ccd_compute_rate")
+
+            rate_once()
+            ms_r = event_ms(stream, rate_once, 20, local_rank)
+            gbs = 16.0 * n_sym / ms_r / 1e6
+            res["rate_model"] = {"kernel": "rate_kernel_v4 (compute_rate, arm.py:448-485)", "symbols": n_sym, "ms_per_launch": ms_r,
+                                 "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                 "algorithmic_bytes": 16 * n_sym, "gsymbols_per_s": n_sym / ms_r / 1e6,
+                                 "note": "12 B in (x, mu, scale f32) + 4 B out per symbol; HIP events on the launch stream, 20 launches"}
+            del xr, mur, scr, out_r
         # ---- the metric's set re-encoded against a network OUTSIDE the r02 static envelope of the pipelined entropy kernel
         # (worst-case IFCE feature >= 2^15, like three of the six networks the reference encoder produced in the build
         # container): same kernel, features checked on the device, no pixel redone
@@ -574,21 +723,22 @@ def main():
                 "pixels_redone_in_int64": int(sum(int(be.slot_stats(s_)[39]) for s_ in range(len(k_e)))),
                 "verified": verify_frames("kodak24_wide_envelope", [be.planes(s_) for s_ in range(len(k_e))], streams=wl_e["streams"])}
             be.close()
-        # ---- the same 24 streams eight times over in ONE batch: a stream occupies one CU for its serial chain, so kodak24 keeps
-        # 24 of the 256 CUs busy; this is what the chip does when an image set is large enough to fill it
+        # ---- the same 24 streams eleven times over in ONE batch (264 streams): a stream occupies one CU for its serial chain, so
+        # kodak24 keeps 24 of the 256 CUs busy; this is what the chip does when an image set is large enough to fill it
         if "wide" in legs:
             wide = DecodeBatch(local_rank)
-            for _ in range(8):
+            for _ in range(THROUGHPUT_COPIES):
                 for hdr, nn, lat, _ in items:
                     wide.add(hdr, nn, lat, 8, 0)
             wide.run(sh); wide.wait(sh)
             n_wide = max(2, min(args.steps, 4))
             ms_w = wall_ms(lambda: wide.run(sh), n_wide, local_rank)
             wide.wait(sh)
-            wide_verified = verify_frames("kodak24", [wide.planes(s_) for s_ in range(8 * len(items))], stream_of=lambda i: i % len(items))
-            res["more_frames_in_flight"] = {"frames_in_flight": 8 * len(items), "value": 8 * sum(h * w for *_, (h, w) in items) / ms_w / 1e3,
+            wide_verified = verify_frames("kodak24", [wide.planes(s_) for s_ in range(THROUGHPUT_COPIES * len(items))], stream_of=lambda i: i % len(items))
+            res["more_frames_in_flight"] = {"frames_in_flight": THROUGHPUT_COPIES * len(items), "value": THROUGHPUT_COPIES * kodak_px / ms_w / 1e3,
                                             "unit": "Mpixel/s", "n_gpus": 1, "steps": n_wide, "ms_per_step": ms_w, "verified": wide_verified,
-                                            "note": "kodak24 x 8 in one batch on rank 0: not the metric's configuration, shown for occupancy"}
+                                            "note": f"kodak24 x {THROUGHPUT_COPIES} in one batch on rank 0 (>= one stream per CU): not the metric's "
+                                                    "configuration; the per-GPU figure of the throughput regime (--scaling throughput)"}
             wide.close()
         # ---- the other BASELINE configurations, each on this one GPU
         extra = {}
@@ -601,7 +751,7 @@ def main():
         if extra:
             res["baseline_configs"] = extra
         if want_cpu:
-            res["cpu_baseline"] = cpu_sample(streams, [h * w for *_, (h, w) in items], 12.0, "kodak24 streams")
+            res["cpu_baseline"] = cpu_sample(streams, [h * w for *_, (h, w) in items], 8.0, "kodak24 streams")
             # measured once in the build container (8-core Xeon 2.1 GHz, torch 2.10 CPU): the reference's own PyTorch decode of
             # kodim14.cool with the C range coder behind the constriction shim (tools/ref_baseline.py) - see BASELINE.md section 3
             ref_path = os.path.join(ROOT, "profiles", "r02", "reference_pytorch_container.json")

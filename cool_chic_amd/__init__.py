@@ -16,4 +16,13 @@ package is the thin host-side mirror of the reference's decode surface:
 from ._lib import CcdError, lib  # noqa: F401
 from .batch import DecodeBatch  # noqa: F401
 
+
+
+def pool_trim(device: int = 0) -> None:
+    """Returns the device / pinned blocks that destroyed batches left in the library's per-device cache to the HIP runtime
+    (include/ccd.h: ccd_pool_trim; caps: CCD_POOL_MAX_MB, CCD_PINNED_POOL_MAX_MB).  The cache is invisible to PyTorch's
+    allocator: call this before a memory-hungry torch workload shares the GPU."""
+    lib().ccd_pool_trim(int(device))
+
+
 __version__ = "0.1.0"

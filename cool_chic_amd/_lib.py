@@ -99,6 +99,7 @@ SIGNATURES = {
     "ccd_batch_copy_planes_async": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_void_p]),
     "ccd_pool_trim": (None, [C.c_int]),
     "ccd_network_fits_fast_path": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "ccd_network_kernel_class": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
     "ccd_debug_fd_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "ccd_batch_set_option": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "ccd_batch_output": (C.c_void_p, [C.c_void_p, C.c_int]),

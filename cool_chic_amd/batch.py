@@ -165,6 +165,14 @@ class DecodeBatch:
             out.append(planes)
         return out
 
+    def planes_block_device(self, slot: int) -> Tuple[_DevArray, List[Tuple[int, Tuple[int, int]]]]:
+        """The slot's three integer planes as the ONE device block they occupy (uint8 bytes) + [(byte offset, (h, w))] per
+        plane: a consumer that must outlive the batch copies the block once and views the planes in its copy."""
+        total, off = C.c_size_t(), (C.c_size_t * 3)()
+        check(lib().ccd_batch_planes_layout(self._h, slot, C.byref(total), off), "ccd_batch_planes_layout")
+        ptr = lib().ccd_batch_plane(self._h, slot, 0, None, None)
+        return _DevArray(ptr, (total.value,), "|u1", self), [(off[p], self.plane_shape(slot, p)) for p in range(3)]
+
     def output_device(self, slot: int) -> _DevArray:
         h = self.header(slot)
         ptr = lib().ccd_batch_output(self._h, slot)

@@ -25,6 +25,15 @@ def _planes_to_frame_data(planes: List[torch.Tensor], bitdepth: int, frame_data_
     return FrameData(bitdepth, frame_data_type, torch.cat(f, dim=1))
 
 
+def _own_planes(batch: DecodeBatch, slot: int, bitdepth: int, device) -> List[torch.Tensor]:
+    """The slot's integer planes in memory the caller owns: ONE device-to-device copy of the block the three planes share
+    (the arena goes back to the pool when the batch closes), then three views of the copy."""
+    block, layout = batch.planes_block_device(slot)
+    own = torch.as_tensor(block, device=device).clone()
+    dt, sb = (torch.uint8, 1) if bitdepth == 8 else (torch.uint16, 2)
+    return [own[off: off + h * w * sb].view(dt).view(h, w) for off, (h, w) in layout]
+
+
 def _split_frame(bitstream_bytes: bytes):
     """decode.py:115-143: frame header, then per cool-chic header + NN bytes + latent bytes."""
     fh = FrameHeader()
@@ -62,7 +71,7 @@ def decode_frame(bitstream_bytes: bytes, reference_frames: List[FrameData], verb
         stream = torch.cuda.current_stream(device).cuda_stream
         batch.run(stream)
         batch.wait(stream)
-        planes = [torch.as_tensor(batch.plane_device(0, p), device=f"cuda:{device}").clone() for p in range(3)]
+        planes = _own_planes(batch, 0, bitdepth, f"cuda:{device}")
     finally:
         batch.close()
     return _planes_to_frame_data(planes, bitdepth, fdt), rest
@@ -89,19 +98,20 @@ def decode_video(bitstream_path: str, decoded_path: Optional[str] = None, max_de
         batch = DecodeBatch(device)
         try:
             meta = []
-            for _ in range(max_decoding_order + 1):
+            structure = vh.get_coding_structure()
+            for k in range(max_decoding_order + 1):
                 fh, ccs, bitstream_bytes = _split_frame(bitstream_bytes)
+                if fh.get_value("frame_type") != "I":
+                    raise ValueError(f"frame {k} (coding order): header says {fh.get_value('frame_type')}, the coding structure I")
                 ch, nn, lat = ccs[0]
                 bd, fdt = fh.get_value("bitdepth"), fh.get_value("frame_data_type")
                 batch.add(ch.raw, nn, lat, bd, _FDT_INDEX[fdt])
-                meta.append((fh.get_value("display_index"), bd, fdt))
+                meta.append((structure[k]["display_order"], bd, fdt))  # decode.py:67: the structure says which frame this is
             stream = torch.cuda.current_stream(device).cuda_stream
             batch.run(stream)
             batch.wait(stream)
             for slot, (di, bd, fdt) in enumerate(meta):
-                planes = [torch.as_tensor(batch.plane_device(slot, p), device=f"cuda:{device}").clone()
-                          for p in range(3)]
-                frames[di] = _planes_to_frame_data(planes, bd, fdt)
+                frames[di] = _planes_to_frame_data(_own_planes(batch, slot, bd, f"cuda:{device}"), bd, fdt)
         finally:
             batch.close()
         print(f"Decoding {len(frames)} intra frame(s) time = {time.time() - start:6.2f} seconds.")
@@ -144,23 +154,26 @@ def _decode_gop(rest: bytes, n_decode: int, device: int, group, verbosity: int =
         if verbosity:
             print(fh.pretty_string())
         parsed.append((fh, ccs))
-    display = [fh.get_value("display_index") for fh, _ in parsed]
+    # decode.py:67-75: which frame sits at coding index k and what it predicts from come from the VIDEO header's coding
+    # structure; the frame headers' display_index / index_references are never read there.  Only the header's frame_type is
+    # used (cool-chics per frame, reconstruction): one that contradicts the structure makes the reference index references it
+    # was not given, so that alone is rejected.  Without a structure (decode_frame-style callers) the headers are followed.
+    if structure is not None:
+        for k, (fh, _) in enumerate(parsed):
+            if fh.get_value("frame_type") != structure[k]["frame_type"]:
+                raise ValueError(f"frame {k} (coding order): header says {fh.get_value('frame_type')}, "
+                                 f"the coding structure {structure[k]['frame_type']}{structure[k]['display_order']}")
+        display = [structure[k]["display_order"] for k in range(n_decode)]
+        ref_display = [list(structure[k]["index_references"]) for k in range(n_decode)]
+    else:
+        display = [fh.get_value("display_index") for fh, _ in parsed]
+        ref_display = [list(fh.get_value("index_references")) for fh, _ in parsed]
     if len(set(display)) != len(display):
         raise ValueError("two frames share a display index")
-    # decode.py:52-75: order and references are the VIDEO header's coding structure; the frame headers must agree with it
-    for k, (fh, _) in enumerate(parsed):
-        if structure is None:
-            break
-        want = structure[k]
-        if (fh.get_value("display_index"), fh.get_value("frame_type"), fh.get_value("index_references")) != \
-                (want["display_order"], want["frame_type"], want["index_references"]):
-            raise ValueError(f"frame {k} (coding order): header says {fh.get_value('frame_type')}{fh.get_value('display_index')} "
-                             f"refs {fh.get_value('index_references')}, the coding structure {want['frame_type']}{want['display_order']} "
-                             f"refs {want['index_references']}")
     coding_of_display = {d: k for k, d in enumerate(display)}
     references = []
-    for k, (fh, _) in enumerate(parsed):
-        refs = [coding_of_display.get(r, n_decode) for r in fh.get_value("index_references")]
+    for k in range(n_decode):
+        refs = [coding_of_display.get(r, n_decode) for r in ref_display[k]]
         if any(r >= k for r in refs):
             raise ValueError("a frame references a frame that is not decoded before it")
         references.append(refs)
@@ -192,7 +205,7 @@ def _decode_gop(rest: bytes, n_decode: int, device: int, group, verbosity: int =
         def produce(k, refs):
             fh = parsed[k][0]
             if fh.get_value("frame_type") == "I":
-                return [torch.as_tensor(batch.plane_device(slots[k][0], p), device=dev).clone() for p in range(3)]
+                return _own_planes(batch, slots[k][0], fh.get_value("bitdepth"), dev)
             outs = [torch.as_tensor(batch.output_device(s), device=dev) for s in slots[k]]
             ref_fd = [to_frame_data(r, pl) for r, pl in zip(references[k], refs)]
             return _integer_planes(reconstruct_inter_frame(fh, outs[0], outs[1], ref_fd), dev)

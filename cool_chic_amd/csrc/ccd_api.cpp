@@ -73,7 +73,8 @@ namespace {
 // per image set, and hipMalloc / hipFree / hipHostMalloc of its arenas were a fifth of the time from bytes to planes
 // (24 hipFree = 4.4 ms per Kodak set; 64 arenas of 50-100 MB per 1080p GOP).  Blocks are handed out in size classes
 // (power of two up to 1 MB, then eighths of a power of two: <= 12.5 % slack) and come back on destroy; the cache is capped
-// (CCD_POOL_MAX_MB, default 32768; CCD_PINNED_POOL_MAX_MB, default 4096) - beyond the cap a block is really freed.
+// (CCD_POOL_MAX_MB, default 8192; CCD_PINNED_POOL_MAX_MB, default 2048: the cache is invisible to PyTorch's allocator, so it
+// stays a few percent of the device) - beyond the cap a block is really freed.
 // ccd_pool_trim() empties the caches.  The current device must be the block's device (callers hipSetDevice first).
 class BlockPool {
 public:
@@ -136,7 +137,7 @@ public:
 private:
     static int key(int device, Kind kind) { return device * 2 + kind; }
     static size_t cap(Kind kind) {
-        static const size_t caps[2] = {env_mb("CCD_POOL_MAX_MB", 32768), env_mb("CCD_PINNED_POOL_MAX_MB", 4096)};
+        static const size_t caps[2] = {env_mb("CCD_POOL_MAX_MB", 8192), env_mb("CCD_PINNED_POOL_MAX_MB", 2048)};
         return caps[kind];
     }
     static size_t env_mb(const char* name, size_t dflt) {
@@ -170,8 +171,6 @@ struct DeviceShared {
     // stream is a serial chain on one CU, so launches that queue behind each other on ONE stream add their durations
     static constexpr int kSide = 8;
     hipStream_t side[kSide] = {};
-    hipEvent_t side_done[kSide] = {};
-    hipEvent_t fork = nullptr;
 };
 int device_shared(int device, DeviceShared** out);
 
@@ -246,8 +245,19 @@ struct ccd_batch {
     int32_t* d_status_all = nullptr;     // [slots][64]
     hipEvent_t up_done = nullptr;        // recorded on the upload stream behind the last ccd_batch_add
     hipStream_t up_stream = nullptr;     // the device's shared upload stream
-    hipStream_t last_stream = nullptr;   // the stream of the last ccd_batch_run_stage (drained before the arenas are recycled)
-    bool last_stream_valid = false;
+    // every stream the caller handed to ccd_batch_run_stage / ccd_batch_wait / ccd_batch_copy_*: all of them are drained before a
+    // block of this batch goes back to the pool (or its tables are replaced), not only the last one
+    std::vector<hipStream_t> streams_used;
+    void note_stream(hipStream_t st) { if (std::find(streams_used.begin(), streams_used.end(), st) == streams_used.end()) streams_used.push_back(st); }
+    int drain_streams() {
+        int rc = CCD_OK;
+        for (hipStream_t st : streams_used) if (hipStreamSynchronize(st) != hipSuccess) rc = CCD_ERR_HIP;
+        return rc;
+    }
+    // fork / join of the entropy launches over the device's side streams: the EVENTS belong to the batch (two host threads
+    // running two batches on one GPU share the side streams, which only serialises their launches, but never an event)
+    hipEvent_t fork = nullptr;
+    hipEvent_t side_done[DeviceShared::kSide] = {};
     bool uploads_unconfirmed = false;    // slots were added since the last ccd_batch_wait: launches order themselves behind up_done
     int n_pipe = 0, n_generic = 0;
     struct PipeGroup { int nv, mfma, dyn, first, n; size_t lds; };
@@ -345,10 +355,8 @@ int device_shared(int device, DeviceShared** out) {
             return CCD_ERR_HIP;
         }
         d.d_scale_table = st; d.d_rcp_table = rt; d.up_stream = us;
-        bool ok = hipEventCreateWithFlags(&d.fork, hipEventDisableTiming) == hipSuccess;
-        for (int k = 0; k < DeviceShared::kSide && ok; ++k)
-            ok = hipStreamCreateWithFlags(&d.side[k], hipStreamNonBlocking) == hipSuccess &&
-                 hipEventCreateWithFlags(&d.side_done[k], hipEventDisableTiming) == hipSuccess;
+        bool ok = true;
+        for (int k = 0; k < DeviceShared::kSide && ok; ++k) ok = hipStreamCreateWithFlags(&d.side[k], hipStreamNonBlocking) == hipSuccess;
         if (!ok) return CCD_ERR_HIP;
     }
     *out = &d;
@@ -383,7 +391,9 @@ void ccd_batch_destroy(ccd_batch* b) {
     (void)hipSetDevice(b->device);
     // blocks go back to the pool for the next batch: nothing of this one may still be in flight
     if (b->up_done) { (void)hipEventSynchronize(b->up_done); (void)hipEventDestroy(b->up_done); }
-    if (b->last_stream_valid) (void)hipStreamSynchronize(b->last_stream);
+    (void)b->drain_streams();  // launches and copies on EVERY stream the caller used with this batch
+    if (b->fork) (void)hipEventDestroy(b->fork);
+    for (hipEvent_t e : b->side_done) if (e) (void)hipEventDestroy(e);
     for (auto& s : b->slots) { s->arena.release(); s->staging.drop(); }
     b->tables.drop(); b->tables_staging.drop(); b->status_host.drop();
     delete b;
@@ -915,7 +925,7 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
     const size_t o_stat = o_zmap + up256(sizeof(uint32_t) * std::max<size_t>(zmap.size(), 1));
     const size_t total = o_stat + up256(static_cast<size_t>(std::max(n, 1)) * 64 * sizeof(int32_t));
     // the previous tables may still be read by launches in flight on the caller's stream (a batch that grew between runs)
-    if (b->tables.p && b->last_stream_valid) HIP_TRY(hipStreamSynchronize(b->last_stream));
+    if (b->tables.p && b->drain_streams() < 0) return CCD_ERR_HIP;
     if (!b->tables.get(b->device, BlockPool::kDevice, total) || !b->tables_staging.get(b->device, BlockPool::kPinned, total) ||
         !b->status_host.get(b->device, BlockPool::kPinned, static_cast<size_t>(std::max(n, 1)) * 64 * sizeof(int32_t)))
         return CCD_ERR_NOMEM;
@@ -1021,9 +1031,9 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
     HIP_TRY(hipSetDevice(b->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (b->uploads_unconfirmed) HIP_TRY(hipStreamWaitEvent(st, b->up_done, 0));  // the slots' uploads (ccd_batch_add) come first
+    b->note_stream(st);
     int rc = upload_params(b, st);
     if (rc < 0) return rc;
-    b->last_stream = st; b->last_stream_valid = true;
     if (stage == 0) {
         // One launch per kernel instantiation in use.  The first goes to the caller's stream; the others fork to side streams
         // and join again, so that they overlap (each stream of a launch occupies one CU for its whole serial chain: queued on
@@ -1033,7 +1043,8 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
         if (n_launch > 1) {
             rc = device_shared(b->device, &sh);
             if (rc < 0) return rc;
-            HIP_TRY(hipEventRecord(sh->fork, st));
+            if (!b->fork) HIP_TRY(hipEventCreateWithFlags(&b->fork, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(b->fork, st));
         }
         int k = 0;
         std::vector<int> used;
@@ -1042,15 +1053,16 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
             const int side = (idx - 1) % DeviceShared::kSide;
             if (std::find(used.begin(), used.end(), side) == used.end()) {
                 used.push_back(side);
-                (void)hipStreamWaitEvent(sh->side[side], sh->fork, 0);
+                (void)hipStreamWaitEvent(sh->side[side], b->fork, 0);
             }
             return sh->side[side];
         };
         for (const auto& g : b->pipe_groups) HIP_TRY(launch_entropy_pipe(b->d_params + g.first, g.n, g.nv, g.mfma, g.dyn, g.lds, stream_for(k++)));
         if (b->n_generic > 0) HIP_TRY(launch_entropy(b->d_params + b->n_pipe, b->n_generic, b->lds_generic, stream_for(k++)));
         for (int side : used) {
-            HIP_TRY(hipEventRecord(sh->side_done[side], sh->side[side]));
-            HIP_TRY(hipStreamWaitEvent(st, sh->side_done[side], 0));
+            if (!b->side_done[side]) HIP_TRY(hipEventCreateWithFlags(&b->side_done[side], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(b->side_done[side], sh->side[side]));
+            HIP_TRY(hipStreamWaitEvent(st, b->side_done[side], 0));
         }
         return CCD_OK;
     }
@@ -1083,12 +1095,15 @@ int ccd_batch_wait(ccd_batch* b, void* stream) {
     if (!b) return CCD_ERR_ARG;
     HIP_TRY(hipSetDevice(b->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const size_t n = b->slots.size();
-    if (n && static_cast<size_t>(b->n_params_uploaded) == n && b->d_status_all) {
+    b->note_stream(st);
+    // slots added after the last run have no status yet: the words of the slots that DID run are refreshed all the same (their
+    // array and its pinned copy were sized for them)
+    const size_t n = std::min(b->slots.size(), static_cast<size_t>(b->n_params_uploaded));
+    if (n && b->d_status_all) {
         // the status words of all slots are one array: one copy into pinned memory, one wait
         HIP_TRY(hipMemcpyAsync(b->status_host.p, b->d_status_all, n * 64 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        b->uploads_unconfirmed = false;  // every launch behind the uploads has finished
+        if (n == b->slots.size()) b->uploads_unconfirmed = false;  // every launch behind the uploads has finished
         const int32_t* hs = b->status_host.as<int32_t>();
         int first = CCD_OK;
         for (size_t i = 0; i < n; ++i) {
@@ -1163,6 +1178,7 @@ static int copy_out(ccd_batch* b, const void* src, void* dst, size_t bytes, void
     if (!src || !dst) return CCD_ERR_ARG;
     HIP_TRY(hipSetDevice(b->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    b->note_stream(st);
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return CCD_OK;
@@ -1195,6 +1211,7 @@ int ccd_batch_copy_planes_async(ccd_batch* b, int first_slot, int n_slots, void*
     if (!b || !host_blocks || first_slot < 0 || n_slots < 0 || first_slot + n_slots > static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
     HIP_TRY(hipSetDevice(b->device));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    b->note_stream(st);  // the copies read the arenas: drained before the blocks are recycled (ccd_batch_destroy)
     int rc = CCD_OK;
     for (int i = 0; i < n_slots; ++i) {
         const Slot& s = *b->slots[first_slot + i];
@@ -1309,18 +1326,22 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
     // reconstruction then walks the frames in coding order (decode.py:67-81).
     std::vector<ccd_frame_header> fhs(n_frames);
     std::vector<int> first_slot(n_frames, 0);
-    // decode.py:52-75: the coding order and every frame's references come from the VIDEO header's coding structure; a frame
-    // header that says otherwise describes a stream the reference would decode differently (or not at all): rejected
+    // decode.py:52-75: the coding order and every frame's references come from the VIDEO header's coding structure
     std::vector<CodedFrame> cs;
     rc = coding_structure(*vh, cs);
     for (int f = 0; f < n_frames && rc >= 0; ++f) {
         used = read_frame_header(bs + pos, n - pos, &fhs[f]);
         if (used < 0) { rc = used; break; }
         {
+            // decode.py:67-75 takes the display index and the references of the frame at this coding index from the STRUCTURE and
+            // never reads those fields of the frame header; the header's frame_type decides how many cool-chics follow and how the
+            // frame is reconstructed (decode.py:119-128, 156-189): with a type other than the structure's the reference's
+            // reconstruction indexes reference frames it was not given (IndexError) - only that is rejected
             const CodedFrame& want = cs[f];
-            bool same = fhs[f].display_index == want.display_order && fhs[f].frame_type == want.frame_type && fhs[f].n_refs == want.n_refs;
-            for (int k = 0; same && k < want.n_refs; ++k) same = fhs[f].index_references[k] == want.refs[k];
-            if (!same) { rc = CCD_ERR_VALUE; break; }
+            if (fhs[f].frame_type != want.frame_type) { rc = CCD_ERR_VALUE; break; }
+            fhs[f].display_index = want.display_order;
+            fhs[f].n_refs = want.n_refs;
+            for (int k = 0; k < want.n_refs; ++k) fhs[f].index_references[k] = want.refs[k];
         }
         pos += static_cast<size_t>(used);
         first_slot[f] = ccd_batch_size(b);
@@ -1454,6 +1475,21 @@ int ccd_network_fits_fast_path(const uint8_t* cc_header, size_t n_hdr, const uin
     int max_w = 0;
     for (int g = 0; g < h->n_grids; ++g) max_w = std::max(max_w, static_cast<int>(h->grid_w[g]));
     return entropy_pipe_supports(h->total_context_arm, h->n_hidden_layers_arm + 1, (net.arm.w32 && net.feat_i32 && !net.arm.dyn_act) ? 1 : 0, max_w) ? 1 : 0;
+}
+
+int ccd_network_kernel_class(const uint8_t* cc_header, size_t n_hdr, const uint8_t* bytes_nn, size_t n_nn) {
+    if (!cc_header || !bytes_nn) return CCD_ERR_ARG;
+    std::unique_ptr<ccd_cc_header> h(new (std::nothrow) ccd_cc_header());
+    if (!h) return CCD_ERR_NOMEM;
+    int rc = read_cc_header(cc_header, n_hdr, h.get());
+    if (rc < 0) return rc;
+    Network net;
+    rc = decode_network(*h, bytes_nn, n_nn, net);
+    if (rc < 0) return rc;
+    int max_w = 0;
+    for (int g = 0; g < h->n_grids; ++g) max_w = std::max(max_w, static_cast<int>(h->grid_w[g]));
+    const bool pipe = entropy_pipe_supports(h->total_context_arm, h->n_hidden_layers_arm + 1, (net.arm.w32 && net.feat_i32 && !net.arm.dyn_act) ? 1 : 0, max_w);
+    return (pipe ? 1 : 0) | (pipe && net.arm.dyn_feat ? 16 : 0) | (((h->total_context_arm + 3) / 4 & 15) << 8) | (((h->n_hidden_layers_arm + 1) & 15) << 12);
 }
 
 int ccd_debug_fd_profile(uint64_t* out16, int reset) {

@@ -168,6 +168,15 @@ def clic41() -> Tuple[List[bytes], List[Tuple[int, int]]]:
     return streams, list(CLIC41_SIZES)
 
 
+def clic41_subset(indices: Sequence[int]) -> List[bytes]:
+    """Streams `indices` of clic41() (each is built independently of the others): what one rank of a sharded run manufactures."""
+    idx = list(indices)
+    if not idx:
+        return []
+    with _pool(len(idx)) as ex:
+        return list(ex.map(lambda i: image_stream(CLIC41_SIZES[i][0], CLIC41_SIZES[i][1], 2000 + i), idx))
+
+
 def uhd4k() -> Tuple[List[bytes], List[Tuple[int, int]]]:
     """BASELINE configs[4]: one 3840x2160 RGB 8-bit picture, latent 0-8 + hyperlatent 4-8 (14 grids, 11.1 M symbols)."""
     return [image_stream(2160, 3840, 0)], [(2160, 3840)]

@@ -11,7 +11,8 @@
  *
  * Conventions: plain pointers and sizes, no torch types; status-code
  * returns (0 = ok, <0 = error, see ccd_strerror); caller-owned output buffers; one HIP stream
- * per call, no hidden global state; inputs are never modified.  Device pointers are ordinary
+ * per call; process-wide state is limited to per-device caches and helper streams (see the note at ccd_pool_trim); inputs are
+ * never modified.  Device pointers are ordinary
  * hipMalloc'ed addresses (e.g. torch.Tensor.data_ptr()); `stream` is a hipStream_t passed as
  * void* (e.g. torch.cuda.current_stream().cuda_stream), NULL = the default stream.
  *
@@ -104,7 +105,10 @@ int ccd_read_cc_header(const uint8_t* p, size_t n, ccd_cc_header* h);
  * the frames a video header implies, in CODING order.  Each array receives h->n_frames entries (refs: 2 per frame, display
  * orders, -1 where unused; frame_type 0 I / 1 P / 2 B; depth as the reference counts it).  Returns n_frames, or
  * CCD_ERR_VALUE where the reference asserts (first frame not intra, last frame neither intra nor P, a frame both I and P).
- * ccd_decode_video decodes in this order and rejects a stream whose frame headers disagree with it. */
+ * Positions listed twice are CCD_ERR_VALUE too: the reference only prints a warning, builds a structure that lacks a display
+ * index and fails after decoding (decode.py:86 on None).  ccd_decode_video decodes in this order with these references, like
+ * decode.py:67-75 (the frame headers' display_index / index_references are not read there), and rejects a frame header whose
+ * frame_type contradicts the structure. */
 int ccd_get_coding_structure(const ccd_video_header* h, int32_t* display_order, int32_t* frame_type, int32_t* refs, int32_t* depth);
 
 /* ---- one cool-chic: encode_decode_coolchic(mode="decode"), coolchic.py:29-207 ------------- */
@@ -192,7 +196,17 @@ int ccd_batch_copy_dense(ccd_batch* b, int slot, float* host, void* stream);
 int ccd_batch_planes_layout(const ccd_batch* b, int slot, size_t* total_bytes, size_t* off3);
 int ccd_batch_copy_planes_async(ccd_batch* b, int first_slot, int n_slots, void* const* host_blocks, void* stream);
 /* Device and pinned-host blocks of destroyed batches are cached per device for the next batch (a batch per image set is the
- * normal use); this returns them to the runtime.  CCD_POOL_MAX_MB / CCD_PINNED_POOL_MAX_MB cap the caches (32768 / 4096). */
+ * normal use); this returns them to the runtime.  The environment variables CCD_POOL_MAX_MB / CCD_PINNED_POOL_MAX_MB cap the
+ * caches (defaults 8192 / 2048 MB: the cache is invisible to other allocators of the process, e.g. PyTorch's; a block beyond
+ * the cap is freed at once, and an allocation that fails trims the cache and retries).
+ *
+ * Threading and global state.  Per device and for the life of the process the library keeps: that block cache, the two
+ * Laplace tables, ONE upload stream and eight side streams (entropy launches of one batch that need different kernel
+ * instantiations fork onto them and join the caller's stream again).  All of it is created under a lock; the fork / join
+ * events belong to the batch.  Different batches may be driven from different host threads on one device; ONE batch is not
+ * thread-safe.  ccd_batch_destroy drains every stream the caller passed to ccd_batch_run[_stage], ccd_batch_wait and
+ * ccd_batch_copy_* before the batch's blocks return to the cache; work the caller enqueued on OTHER streams that reads
+ * pointers obtained from ccd_batch_plane / _output / _latent must be finished by the caller before the destroy. */
 void ccd_pool_trim(int device);
 
 /* ---- whole file: decode_video(), decode.py:26-91 ----------------------------------------- */
@@ -302,6 +316,11 @@ int ccd_debug_laplace_sweep(int device, int which, int scale_first, int n_scales
  * any stream seen so far).  0 when it needs the generic 64-bit kernel (~7x slower; no network the reference encoder produced
  * does), < 0 on a malformed header / payload. */
 int ccd_network_fits_fast_path(const uint8_t* cc_header, size_t n_hdr, const uint8_t* bytes_nn, size_t n_nn);
+/* Host only: WHICH entropy-kernel instantiation a batch with default options gives this cool-chic (tests and DESIGN.md's
+ * instantiation table): bit 0 = pipelined kernel (else the generic one), bit 4 = its instantiation with the device check of the
+ * IFCE features (worst-case feature >= 2^15), bits 8..11 = NV = ceil(ARM inputs / 4), bits 12..15 = ARM layers (hidden + output).
+ * Same bits 0 and 4 as ccd_batch_slot_kernels.  < 0 on a malformed header / payload. */
+int ccd_network_kernel_class(const uint8_t* cc_header, size_t n_hdr, const uint8_t* bytes_nn, size_t n_nn);
 
 /* Profile builds only (-DCCD_FD_PROFILE): cycles per phase of the fused float kernel, summed over wave 0 of every
  * workgroup since the last reset; returns 1 with out16 filled, 0 when the library was built without the counters. */

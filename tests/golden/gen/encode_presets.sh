@@ -1,0 +1,26 @@
+#!/bin/bash
+# Build container only: encodes small streams with the REFERENCE encoder (cc_encode.py --debug, i.e. the
+# same short training samples/encode.py --debug runs) for the decoder presets the r03 fixtures did not
+# cover (cfg/dec/intra/{mop,vhop}.cfg, cfg/dec/residue/{hop,mop,vlop}.cfg, cfg/dec/motion/mop.cfg), then
+# dumps the reference DECODER's per-stage results with dump_reference.py.  Nothing here runs on the GPU box.
+#
+#   tests/golden/gen/encode_presets.sh <name> <input under /root/reference/test/data> <n_frames> <intra cfg> [<residue cfg> <motion cfg>]
+set -e
+NAME=$1; IN=$2; NF=$3; INTRA=$4; RES=${5:-lop}; MOT=${6:-lop}
+HERE=$(cd "$(dirname "$0")" && pwd)
+export PYTHONDONTWRITEBYTECODE=1
+export PYTHONPATH=$HERE/shims:/root/reference
+W=/tmp/ccgen/$NAME
+rm -rf $W; mkdir -p $W
+cd /root/reference
+PPOS=""
+if [ "$NF" -gt 1 ]; then PPOS="--p_pos=-1"; fi
+for ((k = 0; k < NF; k++)); do
+    if [ $k -eq 0 ]; then R=/root/reference/cfg/dec/intra/$INTRA.cfg; else R=/root/reference/cfg/dec/residue/$RES.cfg; fi
+    python3 cc_encode.py --input=/root/reference/test/data/$IN --workdir=$W/ --intra_pos=0 $PPOS --n_frames=$NF \
+        --output=$W/$NAME.cool --coding_idx=$k --debug \
+        --dec_cfg_residue=$R --dec_cfg_motion=/root/reference/cfg/dec/motion/$MOT.cfg > $W/enc$k.log 2>&1
+done
+ls -la $W/$NAME.cool
+cp $W/$NAME.cool $HERE/../$NAME.cool
+python3 $HERE/dump_reference.py $HERE/../$NAME.cool $NAME

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import IMAGE_STREAMS, SMALL_STREAMS, load_golden, reference_planes
+from conftest import IMAGE_STREAMS, SMALL_STREAMS, VIDEO_STREAMS, load_golden, reference_planes
 
 pytestmark = pytest.mark.gpu
 
@@ -128,6 +128,66 @@ def test_dynamic_operand_redo(gpu, oracle, name, bits):
             assert n_redo > 0, "the lowered limit must drive pixels through the redo"
         for g in range(len([k for k in z.files if k.startswith("cc0.latent")])):
             assert np.array_equal(b.latent(0, g), z[f"cc0.latent{g}"]), f"grid {g} vs reference fixture ({n_redo} pixels redone)"
+    finally:
+        b.close()
+
+
+@pytest.mark.parametrize("variant", ["static", "dyn14", "dyn9"])
+def test_arm_sweep_every_instantiation(gpu, oracle, variant):
+    """EVERY instantiation of the pipelined entropy kernel the library ships: 91 streams with 3 .. 32 ARM inputs (NV = ceil(inputs
+    / 4) = 1 .. 8), 0 .. 3 (and 6 / 7) hidden layers, with and without IFCE, 32 x 320 pictures whose three finest grids run the
+    producers' 8-, 4- and 2-pixel tasks - all in ONE batch, so that its up to 16 kernel instantiations fork over the side streams
+    and join.  "static": the instantiation the network's worst-case feature selects; "dyn14": the one with the device check of the
+    features forced for every stream (limit 2^14: nothing is redone); "dyn9": limit 2^9, pixels go through the int64 redo whose
+    lane broadcast depends on NV.  Bars: latents == what the REFERENCE decoder decoded (sha256 per grid in the fixture), output
+    and integer planes == the oracle's, bit for bit."""
+    import hashlib
+
+    from conftest import load_arm_sweep
+    from cool_chic_amd._lib import lib
+
+    sweep = load_arm_sweep()
+    names = list(sweep)
+    b = gpu(0, **({} if variant == "static" else {"range_bits": int(variant[3:])}))
+    try:
+        triples = []
+        for n in names:
+            hdr, nn, lat = oracle.split_stream(sweep[n][0])[1][0][1][0]
+            triples.append((hdr, nn, lat))
+            b.add(hdr, nn, lat, 8, 0)
+        b.run()
+        b.wait()
+        seen, n_redo = set(), 0
+        for i, n in enumerate(names):
+            hdr, nn, lat = triples[i]
+            cls = lib().ccd_network_kernel_class(hdr, len(hdr), nn, len(nn))
+            k = b.slot_kernels(i)
+            assert b.slot_status(i) == 0, n
+            assert k & 1 and cls & 1, f"{n}: the pipelined entropy kernel must serve every shape of the sweep"
+            assert bool(k & 16) == (variant != "static" or bool(cls & 16)), n
+            assert k & 4, f"{n}: fused float kernel"
+            seen.add(((cls >> 8) & 15, bool(k & 16)))
+            n_redo += int(b.slot_stats(i)[39])
+            h = b.header(i)
+            got = [hashlib.sha256(np.ascontiguousarray(b.latent(i, g)).tobytes()).hexdigest() for g in range(h.n_grids)]
+            assert got == sweep[n][1], f"{n}: latents vs the reference decoder"
+        # every width ran; both variants of every width over the three runs of this test
+        assert {nv for nv, _ in seen} == set(range(1, 9))
+        if variant == "static":
+            assert all((nv, False) in seen for nv in range(1, 9))
+            assert n_redo == 0
+        else:
+            assert all((nv, True) in seen for nv in range(1, 9))
+            assert (n_redo > 0) == (variant == "dyn9"), n_redo
+        # float path and integer planes against the oracle for one stream per width and depth (the float path does not depend on the ARM)
+        for i, n in enumerate(names):
+            if not (n.endswith("_h2_i2") or n.endswith("_h0_i0") or "_h7_" in n or "_h6_" in n):
+                continue
+            ref = oracle.decode_coolchic(*triples[i])
+            assert np.array_equal(b.output(i).view(np.uint32), ref["out"].view(np.uint32)), n
+            want = oracle.decode_video(sweep[n][0])[0]["planes"]
+            for p, w in zip(b.planes(i), want):
+                assert np.array_equal(p.astype(np.uint16), w), n
     finally:
         b.close()
 
@@ -322,10 +382,11 @@ def test_python_surface(gpu, oracle, tmp_path):
     assert torch.equal(t2, t)
 
 
-@pytest.mark.parametrize("stream", ["vid5", "vid5_w2", "vid5_w4"])
+@pytest.mark.parametrize("stream", VIDEO_STREAMS)
 def test_video_ipb_parity(gpu, oracle, tmp_path, stream):
-    """5-frame I/P/B YUV420 video encoded by the reference encoder (sinc-8 warp; _w2 / _w4: the same stream with the
-    2-tap bilinear / 4-tap bicubic grid_sample warp): C ABI (ccd_decode_video) and the Python mirror (decode_video /
+    """I/P/B YUV420 videos encoded by the reference encoder (vid5: 5 frames, sinc-8 warp; _w2 / _w4: the same stream with the
+    2-tap bilinear / 4-tap bicubic grid_sample warp; vid3_*: 3 frames with the decoder presets vid5 does not use - intra
+    vhop / mop, residue hop / mop / vlop, motion mop): C ABI (ccd_decode_video) and the Python mirror (decode_video /
     decode_frame) against the oracle (bit-exact) and the reference fixture (<= 1 LSB)."""
     import os
 
@@ -338,9 +399,10 @@ def test_video_ipb_parity(gpu, oracle, tmp_path, stream):
     v = Video()
     check(lib().ccd_decode_video(bs, len(bs), 0, C.byref(v)), "ccd_decode_video")
     try:
-        assert v.n_frames == 5
+        nf = len(want)
+        assert v.n_frames == nf == (5 if stream.startswith("vid5") else 3)
         n_diff = n_tot = 0
-        for i in range(5):
+        for i in range(nf):
             f = v.frames[i]
             assert "IPB"[f.frame_type] == want[i]["frame_type"] and f.bitdepth == 8 and f.frame_data_type == 1
             shapes = [(f.h, f.w), (f.ch, f.cw), (f.ch, f.cw)]
@@ -357,9 +419,9 @@ def test_video_ipb_parity(gpu, oracle, tmp_path, stream):
     # Python surface: decode_video writes a planar YUV file, frames in display order
     out_yuv = str(tmp_path / "v.yuv")
     frames = decode_video(os.path.join(GOLDEN, stream + ".cool"), decoded_path=out_yuv)
-    assert list(frames) == ["0", "1", "2", "3", "4"]
+    assert list(frames) == [str(i) for i in range(nf)]
     raw = np.fromfile(out_yuv, dtype=np.uint8)
-    expect = np.concatenate([np.concatenate([p.astype(np.uint8).ravel() for p in want[i]["planes"]]) for i in range(5)])
+    expect = np.concatenate([np.concatenate([p.astype(np.uint8).ravel() for p in want[i]["planes"]]) for i in range(nf)])
     assert np.array_equal(raw, expect)
 
 
@@ -573,16 +635,48 @@ def test_fuzzed_streams_never_hang_and_match_the_oracle(gpu, oracle):
     assert n_rejected < len(cases)  # most mutations still decode (to different symbols): both paths must agree on them
 
 
-def test_rate_model_matches_the_float32_formula(gpu):
-    """compute_rate (arm.py:448-485) on the device vs the same float32 formula in plain PyTorch on the CPU.
+def test_rate_model_matches_the_reference(gpu):
+    """compute_rate (arm.py:448-485) on the device vs what the REFERENCE's compute_rate returned for 2^16 symbols
+    (tests/golden/rate.npz, written by tests/golden/gen/dump_rate.py: symbols at the mode, half-way, tails on the 2^-16 clamp, the
+    smallest and the largest scale of the format's table), and vs the same float32 formula in plain PyTorch on 2^20 more.
     Tolerance per symbol: 2e-6 relative + 2e-6 bits + 3e-7 / p bits, p = the symbol's probability.  The last term is the
     formula's own float32 conditioning: p is a difference of two CDF values near 0.5 .. 1, so a few-ulp difference between
     two expm1 implementations (6e-8 each) moves p by ~1e-7 absolute, i.e. the rate by 1e-7 / (p ln 2) bits - 0.02 bits at
-    the 2^-16 clamp, 1e-6 bits for likely symbols.  Total over 2^20 symbols within 1e-5 relative."""
+    the 2^-16 clamp, 1e-6 bits for likely symbols.  Totals within 1e-5 relative.  Unaligned views and lengths that are not a
+    multiple of four take the kernel's scalar tail."""
+    import os
+    import re
+
     import torch
 
+    from conftest import GOLDEN, ROOT
     from cool_chic_amd.component.core.arm import compute_rate, total_rate_bits
 
+    def check(got, want):
+        p = torch.exp2(-want.double())
+        tol = 2e-6 * want.double().abs() + 2e-6 + 3e-7 / p
+        err = (got.double() - want.double()).abs()
+        assert bool((err <= tol).all()), f"worst {float((err / tol).max()):.2f} x the tolerance"
+
+    # (1) the reference's own numbers
+    z = np.load(os.path.join(GOLDEN, "rate.npz"))
+    text = open(os.path.join(ROOT, "include", "ccd_scale_table.inc")).read()
+    tab = np.array([int(t, 16) for t in re.findall(r"0x([0-9a-f]{8})u", text)], dtype=np.uint32).view(np.float32)
+    x = torch.from_numpy(z["x"].astype(np.float32)).cuda()
+    mu = torch.from_numpy((z["mu_idx"].astype(np.float64) / 256 - 64).astype(np.float32)).cuda()
+    scale = torch.from_numpy(tab[z["scale_idx"].astype(np.int64)]).cuda()
+    want = torch.from_numpy(z["rate"])
+    got = compute_rate(x, mu, scale).cpu()
+    check(got, want)
+    # the clamp gives exactly 16 bits on both sides (a symbol whose p sits within float32 noise of 2^-16 may fall on either side)
+    assert int((want == 16.0).sum()) > 100 and abs(int((got == 16.0).sum()) - int((want == 16.0).sum())) <= 20
+    assert float(got.max()) <= 16.0 and float(got.min()) >= 0.0
+    assert abs(total_rate_bits(x, mu, scale) - float(want.double().sum())) <= 1e-5 * float(want.double().sum())
+    # unaligned views / ragged lengths: the scalar tail kernel
+    for off, cnt in ((1, 1001), (3, 4098), (0, 7), (2, 65531)):
+        g2 = compute_rate(x[off:off + cnt], mu[off:off + cnt], scale[off:off + cnt]).cpu()
+        check(g2, want[off:off + cnt])
+    # (2) 2^20 more symbols against the same float32 formula in PyTorch on the CPU
     g = torch.Generator().manual_seed(11)
     n = 1 << 20
     x = torch.randint(-64, 64, (n,), generator=g).float()
@@ -599,12 +693,7 @@ def test_rate_model_matches_the_float32_formula(gpu):
 
     want = ref(x, mu, scale)
     got = compute_rate(x.cuda(), mu.cuda(), scale.cuda()).cpu()
-    err = (got - want).abs()
-    tol = 2e-6 * want.abs() + 2e-6 + 3e-7 * torch.exp2(want)
-    assert bool((err <= tol).all()), float((err - tol).max())
-    likely = want < 4.0
-    assert float(err[likely].max()) <= 2e-5
-    assert got.max() <= 16.0 and got.min() >= 0.0
+    check(got, want)
     tot = total_rate_bits(x.cuda(), mu.cuda(), scale.cuda())
     assert abs(tot - float(want.double().sum())) <= 1e-5 * float(want.double().sum())
     shaped = compute_rate(x.view(1, 1, 1024, 1024).cuda(), mu.view(1, 1, 1024, 1024).cuda(), scale.view(1, 1, 1024, 1024).cuda())
@@ -735,7 +824,7 @@ def test_streams_the_reference_cannot_decode_are_rejected(gpu, oracle):
     """Headers that parse but that the reference's decoder raises on (or that would read out of bounds here) give
     CCD_ERR_VALUE instead of garbage: latent / hyperlatent ranges that do not touch (torch.cat of grids two levels
     apart), a P / B frame whose reference has another sample
-    layout, duplicate display indices, odd-sized 4:2:0 frames."""
+    layout, a frame type that contradicts the coding structure, odd-sized 4:2:0 frames."""
     import ctypes as C
 
     from cool_chic_amd import writer
@@ -782,16 +871,38 @@ def test_streams_the_reference_cannot_decode_are_rejected(gpu, oracle):
                 out.append(h_ + n_ + l_)
         return b"".join(out)
 
-    def decode(stream):
+    def decode(stream, planes=None):
         v = Video()
         rc = lib().ccd_decode_video(stream, len(stream), 0, C.byref(v))
         if rc == 0:
+            if planes is not None:
+                for i in range(v.n_frames):
+                    fr = v.frames[i]
+                    planes.append([np.ctypeslib.as_array(fr.plane[p], shape=((fr.h, fr.w) if p == 0 else (fr.ch, fr.cw))).copy() for p in range(3)])
             lib().ccd_video_free(C.byref(v))
         return rc
 
-    assert decode(rebuild(lambda k, di, fdt: (di, fdt))) == 0
+    plain, odd = [], []
+    assert decode(rebuild(lambda k, di, fdt: (di, fdt)), plain) == 0
     assert decode(rebuild(lambda k, di, fdt: (di, 2 if k == 0 else fdt))) == -2   # I frame yuv444, its P / B users yuv420
-    assert decode(rebuild(lambda k, di, fdt: (0 if k == 4 else di, fdt))) == -2    # display index 0 twice
+    # decode.py:67-75 never reads a frame header's display_index (nor its index_references): order and references are the
+    # coding structure's, so a stream whose frame header carries another display index decodes like the untouched one
+    assert decode(rebuild(lambda k, di, fdt: (0 if k == 4 else di, fdt)), odd) == 0
+    assert len(plain) == len(odd) == 5
+    for fa, fb in zip(plain, odd):
+        for pa, pb in zip(fa, fb):
+            assert np.array_equal(pa, pb)
+    # a frame TYPE that contradicts the structure is what the reference cannot decode (its reconstruction indexes references
+    # it was not given): frame 1 in coding order is the P frame of vid5, relabelled B with a second reference
+    def retype(k, f):
+        return ("B", [0, 0], [0, 0, 0, 0]) if k == 1 else ("IPB"[f.frame_type], list(f.index_references[:f.n_refs]), list(f.global_flow[:2 * f.n_refs]))
+    out = [writer.video_header_bytes(vh.n_frames, list(vh.intra_pos[:vh.n_intras]), list(vh.p_pos[:vh.n_p_frames]))]
+    for k, (f, cc) in enumerate(frames):
+        t, refs, gf = retype(k, f)
+        out.append(writer.frame_header_bytes(f.display_index, t, f.frame_data_type, f.bitdepth, refs, gf, f.warp_filter_size))
+        for h_, n_, l_ in cc:
+            out.append(h_ + n_ + l_)
+    assert decode(b"".join(out)) == -2
 
 
 @pytest.mark.parametrize("name", ["kodak24", "kodak24_wide_envelope", "clic41", "uhd4k", "gop1080p33"])
@@ -837,10 +948,7 @@ def test_workloads_match_the_oracle(gpu, name):
         b.close()
 
 
-def test_bench_two_ranks_on_one_gpu_gloo():
-    """bench.py's multi-rank path (shard, per-rank batch, gather of the planes to rank 0, max-over-ranks timing) executed
-    with two ranks sharing this box's GPU and the host-staged "gloo" backend: the gathered set must hash to the oracle's
-    planes like the single-rank run's.  (The RCCL transport itself needs one GPU per rank: the driver's scaling runs.)"""
+def _run_bench_two_ranks(extra):
     import json
     import os
     import socket
@@ -853,16 +961,39 @@ def test_bench_two_ranks_on_one_gpu_gloo():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", "strong",
-           "--steps", "2", "--warmup", "1", "--legs", "none", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    res = json.loads(line)
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_two_ranks_on_one_gpu_gloo():
+    """bench.py --gpus 2 with its DEFAULTS (what the driver's scaling runs launch): BASELINE's kodak24 sharded round-robin over
+    the ranks (strong), per-rank batch, gather of the planes to rank 0, max-over-ranks timing - and, beside the metric, the two
+    collective legs `clic41_sharded` (BASELINE configs[2] round-robin) and `throughput_regime` (264 streams per rank) - executed
+    with two ranks sharing this box's GPU and the host-staged "gloo" backend: every gathered set must hash to the oracle's
+    planes.  (The RCCL transport itself needs one GPU per rank: the driver's scaling runs.)"""
+    res = _run_bench_two_ranks([])
     assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["steps"] == 2
-    assert res["verified"]["ok"] is True and res["verified"]["frames_checked"] == 96  # rank 0's half of the 192 frames
+    assert res["config"]["workload"] == "kodak24" and res["expected_scaling"].startswith("flat")
+    assert res["verified"]["ok"] is True and res["verified"]["frames_checked"] == 12  # rank 0's half of the 24 frames
     g = res["verified"]["gathered"]
-    assert g["ok"] is True and g["frames_checked"] == 192, g
+    assert g["ok"] is True and g["frames_checked"] == 24, g
+    c = res["clic41_sharded"]
+    assert c["scaling"] == "strong" and c["frames"] == 41 and c["frames_on_rank0"] == 21
+    assert c["verified"]["ok"] is True and c["verified"]["frames_checked"] == 41, c["verified"]
+    t = res["throughput_regime"]
+    assert t["scaling"] == "weak" and t["streams_per_gpu"] == 264
+    assert t["verified"]["ok"] is True and t["verified"]["frames_checked"] == 528, t["verified"]
+
+
+def test_bench_two_ranks_weak_scaling_gloo():
+    """--scaling weak stays available: every rank its own copy of kodak24, all 48 gathered frames verified."""
+    res = _run_bench_two_ranks(["--scaling", "weak", "--legs", "none"])
+    assert res["n_gpus"] == 2 and res["scaling"] == "weak"
+    assert res["verified"]["ok"] is True and res["verified"]["frames_checked"] == 24
+    assert res["verified"]["gathered"]["ok"] is True and res["verified"]["gathered"]["frames_checked"] == 48
 
 
 def test_pooled_blocks_are_recycled_and_results_stay_exact(gpu, oracle):

@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import IMAGE_STREAMS, ROOT, load_golden
+from conftest import IMAGE_STREAMS, ROOT, VIDEO_STREAMS, load_golden
 
 
 def test_every_declared_symbol_is_exported():
@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported():
     assert b"gfx950" in L.ccd_version()
 
 
-@pytest.mark.parametrize("name", IMAGE_STREAMS + ["vid5"])
+@pytest.mark.parametrize("name", IMAGE_STREAMS + ["vid5", "vid3_hop", "vid3_mop", "vid3_vlop"])
 def test_headers_match_reference(name):
     from cool_chic_amd.bitstream.header import CoolChicHeader, FrameHeader, VideoHeader
 
@@ -245,7 +245,44 @@ def test_header_readers_survive_garbage():
             assert rc < 0 or 0 < rc <= len(raw)
 
 
-@pytest.mark.parametrize("name", IMAGE_STREAMS + ["vid5"])
+def test_fixtures_reach_every_entropy_instantiation(oracle):
+    """ccd_network_kernel_class (host only) over every cool-chic of every fixture: which `entropy_pipe_kernel<NV, MF, DYN>` the
+    `-m gpu` parity tests execute (DESIGN.md section 2 holds the table).  The reference ENCODER's presets give NV = 2 (lop, motion
+    lop / mop, residue lop / vlop), 3 (residue mop), 4 (intra mop, residue hop), 5 (intra hop = kodim14), 7 (intra vhop); the
+    sweep fixture gives every NV = 1..8 with 1..4, 7 and 8 layers, and test_arm_sweep_every_instantiation forces both variants."""
+    from conftest import load_arm_sweep
+    from cool_chic_amd._lib import lib
+
+    def classes(stream):
+        out = []
+        for _fh, ccs in oracle.split_stream(stream)[1]:
+            for hdr, nn, _lat in ccs:
+                k = lib().ccd_network_kernel_class(hdr, len(hdr), nn, len(nn))
+                assert k > 0 and k & 1, "every fixture network fits the pipelined kernel"
+                out.append(((k >> 8) & 15, (k >> 12) & 15, bool(k & 16)))
+        return out
+
+    ref_encoded = {}
+    for name in IMAGE_STREAMS + VIDEO_STREAMS:
+        ref_encoded[name] = classes(load_golden(name)[0])
+    assert ref_encoded["kodim14"] == [(5, 3, False)] and ref_encoded["mop192"] == [(4, 3, False)] and ref_encoded["vhop192"] == [(7, 3, False)]
+    # vid3_hop: I = vhop (26 inputs), then per inter frame residue hop (14 inputs) + motion mop (8 inputs)
+    assert [c[:2] for c in ref_encoded["vid3_hop"]] == [(7, 3), (4, 3), (2, 3), (4, 3), (2, 3)]
+    # vid3_mop: I = mop (14), residue mop (12) + motion lop (8 inputs, one hidden layer)
+    assert [c[:2] for c in ref_encoded["vid3_mop"]] == [(4, 3), (3, 3), (2, 2), (3, 3), (2, 2)]
+    # vid3_vlop: I = lop (8), residue vlop (6 inputs, one hidden layer) + motion mop (8)
+    assert [c[:2] for c in ref_encoded["vid3_vlop"]] == [(2, 3), (2, 2), (2, 3), (2, 2), (2, 3)]
+    nv_ref = {c[0] for v in ref_encoded.values() for c in v}
+    assert nv_ref == {2, 3, 4, 5, 7}
+    sweep = {n: classes(s)[0] for n, (s, _) in load_arm_sweep().items()}
+    assert {c[0] for c in sweep.values()} == set(range(1, 9))
+    for nv in range(1, 9):  # every width with 1 .. 4 layers, statically without the feature check at least once
+        assert {c[1] for c in sweep.values() if c[0] == nv} >= {1, 2, 3, 4}
+        assert any(c[0] == nv and not c[2] for c in sweep.values())
+    assert {c[1] for c in sweep.values()} >= {7, 8}
+
+
+@pytest.mark.parametrize("name", IMAGE_STREAMS + VIDEO_STREAMS)
 def test_every_reference_network_fits_the_pipelined_kernel(oracle, name):
     """ccd_network_fits_fast_path (host only): the static envelope of the pipelined entropy kernel is on the WEIGHTS (int32);
     what depends on the data is checked on the device.  Every network the reference encoder produced in the build container
@@ -259,7 +296,7 @@ def test_every_reference_network_fits_the_pipelined_kernel(oracle, name):
         for hdr, nn, lat in ccs:
             assert writer.fits_fast_path(hdr, nn), f"{name}: cool-chic {n}"
             n += 1
-    assert n == (9 if name == "vid5" else 1)
+    assert n == (9 if name.startswith("vid5") else 5 if name.startswith("vid3") else 1)
 
 
 def test_coding_structure_matches_reference():
