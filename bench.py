@@ -21,7 +21,7 @@ N GPUs: --scaling strong (default) = what BASELINE.json names: the 24 frames of 
 41 frames, 66 cool-chics per GOP) keep 9-26 % of ONE GPU's CUs busy - a stream is one serial range-decoder chain on one
 CU, and the step time is the slowest stream's - so they CANNOT strong-scale: the expected curve is flat (`expected_scaling`
 in the line says so).  Beside the metric an N > 1 run measures, with all ranks, `clic41_sharded` (BASELINE configs[2]: the
-41 pictures round-robin, strong) and `throughput_regime` (every rank its own 264 streams = kodak24 x 11, >= one stream
+41 pictures round-robin, strong) and `throughput_regime` (every rank its own 256 streams = kodak24 repeated, one stream
 per CU: the only regime that scales; also available as the metric with --scaling throughput).  --scaling weak: every
 rank its own copy of kodak24.
 
@@ -383,7 +383,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scaling", choices=["strong", "weak", "throughput"], default="strong",
                     help="strong (default): BASELINE's kodak24, its 24 frames round-robin over the ranks; weak: every rank its own "
-                         "kodak24; throughput: every rank its own kodak24 x 11 = 264 streams (>= one per CU)")
+                         "kodak24; throughput: every rank its own 256 streams (kodak24 repeated: one per CU)")
     ap.add_argument("--legs", default="all", help="comma list of clic41,gop1080p33,uhd4k,wide,png,e2e,float,envelope,rate (rank 0, N = 1) and sharded (N > 1: "
                     "clic41_sharded + throughput_regime with all ranks), or all / none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -420,7 +420,9 @@ def main():
     items, streams = build_kodak24(local_rank)
     n_kodak = len(items)
     kodak_px = sum(h * w for *_, (h, w) in items)
-    THROUGHPUT_COPIES = 11  # 264 streams per GPU >= its 256 CUs
+    THROUGHPUT_STREAMS = 256  # one stream per CU: a stream is one 512-thread workgroup that owns its CU (139 KB of LDS, 230 VGPRs)
+    t_ids = [i % n_kodak for i in range(THROUGHPUT_STREAMS)]
+    t_px = sum(items[i][3][0] * items[i][3][1] for i in t_ids)
     if args.scaling == "strong":      # BASELINE's set itself, sharded: frame i -> rank i mod N
         ids_of = lambda r: shard_indices(n_kodak, r, world)
         px_per_step = kodak_px
@@ -428,8 +430,8 @@ def main():
         ids_of = lambda r: list(range(n_kodak))
         px_per_step = world * kodak_px
     else:                             # throughput: enough streams per GPU to give every CU one
-        ids_of = lambda r: list(range(n_kodak)) * THROUGHPUT_COPIES
-        px_per_step = world * THROUGHPUT_COPIES * kodak_px
+        ids_of = lambda r: t_ids
+        px_per_step = world * t_px
     mine = [items[i] for i in ids_of(rank)]
     n_frames = len(mine)
     dev = f"cuda:{local_rank}"
@@ -454,17 +456,17 @@ def main():
                 "expected_scaling": "flat beyond ~2 GPUs: the step is the serial chain of the largest (2.8 Mpx) stream on one CU; 41 streams occupy 16 % of ONE GPU",
                 "verified": verify_gathered("clic41", rc["gathered"], lambda r: [(i, synth.CLIC41_SIZES[i]) for i in shard_indices(len(synth.CLIC41_SIZES), r, world)])}
         rc["batch"].close()
-        # (b) the regime that scales: every rank its own 264 streams (weak)
-        t_mine = list(items) * THROUGHPUT_COPIES
+        # (b) the regime that scales: every rank its own 256 streams (weak)
+        t_mine = [items[i] for i in t_ids]
         n_t = 3
         rt = timed_set(t_mine, world, rank, local_rank, args.backend, red_dev, n_t, 1)
         if rank == 0:
             sharded["throughput_regime"] = {
-                "value": world * THROUGHPUT_COPIES * kodak_px * n_t / rt["dt"] / 1e6, "unit": "Mpixel/s", "n_gpus": world, "steps": n_t,
+                "value": world * t_px * n_t / rt["dt"] / 1e6, "unit": "Mpixel/s", "n_gpus": world, "steps": n_t,
                 "ms_per_step": rt["dt"] / n_t * 1e3, "scaling": "weak", "streams_per_gpu": len(t_mine),
-                "note": "every rank decodes its own kodak24 x 11 (>= one stream per CU) and rank 0 gathers all planes inside the timed region: "
+                "note": "every rank decodes its own 256 streams (kodak24 repeated: one stream per CU) and rank 0 gathers all planes inside the timed region: "
                         "the only regime of this format that scales over GPUs (expected ~N x)",
-                "verified": verify_gathered("kodak24", rt["gathered"], lambda r: [(i % n_kodak, items[i % n_kodak][3]) for i in range(len(t_mine))])}
+                "verified": verify_gathered("kodak24", rt["gathered"], lambda r: [(i, items[i][3]) for i in t_ids])}
         rt["batch"].close()
 
     res = None
@@ -534,7 +536,7 @@ def main():
             "dtype": "int64+f64 entropy / f32 synthesis",
             "data": "synthetic (kodim14.cool real + 23 streams re-encoded from rolled/transposed kodim14 latents)",
             "config": {"workload": {"strong": "kodak24", "weak": "kodak24 (every rank its own copy)",
-                                    "throughput": f"kodak24 x {THROUGHPUT_COPIES} per GPU ({THROUGHPUT_COPIES * n_kodak} streams in flight per GPU)"}[args.scaling],
+                                    "throughput": f"{THROUGHPUT_STREAMS} streams in flight per GPU (kodak24 repeated: one per CU)"}[args.scaling],
                        "frames_on_rank0": n_frames, "frame": "512x768 RGB 8-bit, HOP decoder", "symbols_per_step_rank0": nsym,
                        "parallelism": (f"frame i -> rank i mod {world} (the set's 24 frames sharded), gather of planes to rank 0" if args.scaling == "strong"
                                        else f"every rank its own frames x{world}, gather of planes to rank 0")},
@@ -723,21 +725,20 @@ def main():
                 "pixels_redone_in_int64": int(sum(int(be.slot_stats(s_)[39]) for s_ in range(len(k_e)))),
                 "verified": verify_frames("kodak24_wide_envelope", [be.planes(s_) for s_ in range(len(k_e))], streams=wl_e["streams"])}
             be.close()
-        # ---- the same 24 streams eleven times over in ONE batch (264 streams): a stream occupies one CU for its serial chain, so
+        # ---- 256 streams (the same 24 repeated) in ONE batch: a stream occupies one CU for its serial chain, so
         # kodak24 keeps 24 of the 256 CUs busy; this is what the chip does when an image set is large enough to fill it
         if "wide" in legs:
             wide = DecodeBatch(local_rank)
-            for _ in range(THROUGHPUT_COPIES):
-                for hdr, nn, lat, _ in items:
-                    wide.add(hdr, nn, lat, 8, 0)
+            for i in t_ids:
+                wide.add(*items[i][:3], 8, 0)
             wide.run(sh); wide.wait(sh)
             n_wide = max(2, min(args.steps, 4))
             ms_w = wall_ms(lambda: wide.run(sh), n_wide, local_rank)
             wide.wait(sh)
-            wide_verified = verify_frames("kodak24", [wide.planes(s_) for s_ in range(THROUGHPUT_COPIES * len(items))], stream_of=lambda i: i % len(items))
-            res["more_frames_in_flight"] = {"frames_in_flight": THROUGHPUT_COPIES * len(items), "value": THROUGHPUT_COPIES * kodak_px / ms_w / 1e3,
+            wide_verified = verify_frames("kodak24", [wide.planes(s_) for s_ in range(len(t_ids))], stream_of=lambda i: t_ids[i])
+            res["more_frames_in_flight"] = {"frames_in_flight": len(t_ids), "value": t_px / ms_w / 1e3,
                                             "unit": "Mpixel/s", "n_gpus": 1, "steps": n_wide, "ms_per_step": ms_w, "verified": wide_verified,
-                                            "note": f"kodak24 x {THROUGHPUT_COPIES} in one batch on rank 0 (>= one stream per CU): not the metric's "
+                                            "note": f"{THROUGHPUT_STREAMS} streams (kodak24 repeated) in one batch on rank 0, one per CU: not the metric's "
                                                     "configuration; the per-GPU figure of the throughput regime (--scaling throughput)"}
             wide.close()
         # ---- the other BASELINE configurations, each on this one GPU

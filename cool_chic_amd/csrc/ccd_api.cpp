@@ -21,7 +21,8 @@ size_t entropy_pipe_lds_bytes(int dim, int n_layers, int ring_rows, int mfma);
 int entropy_pipe_ring_rows(int max_grid_w);
 bool entropy_pipe_supports_mfma(int dim, int n_layers, int n_ifce_out, int narrow, int max_grid_w, long long max_abs_weight);
 bool entropy_pipe_supports(int dim, int n_layers, int narrow, int max_grid_w);
-hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, int mfma, int dyn, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, int mfma, int dyn, int shape, size_t lds_bytes, hipStream_t stream);
+int entropy_pipe_fixed_shape(int dim, int n_layers, int n_spatial);
 hipError_t launch_laplace_bounds(const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* sym,
                                  const float* scale_table, int64_t n, uint32_t* left, uint32_t* right, hipStream_t stream);
 hipError_t launch_laplace_sweep_pipe(const float* scale_table, const double* rcp_table, int scale_first, int n_scales, uint32_t* out, hipStream_t stream);
@@ -226,6 +227,7 @@ struct Slot {
     bool use_pipe = false;   // pipelined entropy kernel (32-bit operands) or the generic one
     bool use_mfma = false;   // ... with the ARM's layers on the matrix cores (limb-split int8)
     bool use_dyn = false;    // ... the instantiation that checks IFCE features on the device (worst case >= 2^15, or the test hook)
+    int fixed_shape = 0;     // ... the instantiation with a compile-time ARM shape (1: intra/hop.cfg = 14 + 6 inputs, two hidden layers)
     int ring_rows = 64;      // rows of the pipelined kernel's decoded-symbol ring
     size_t lds_generic = 0, lds_pipe = 0;
     int status = CCD_OK;
@@ -260,7 +262,7 @@ struct ccd_batch {
     hipEvent_t side_done[DeviceShared::kSide] = {};
     bool uploads_unconfirmed = false;    // slots were added since the last ccd_batch_wait: launches order themselves behind up_done
     int n_pipe = 0, n_generic = 0;
-    struct PipeGroup { int nv, mfma, dyn, first, n; size_t lds; };
+    struct PipeGroup { int nv, mfma, dyn, shape, first, n; size_t lds; };
     std::vector<PipeGroup> pipe_groups;
     float* d_scale_table = nullptr;
     double* d_rcp_table = nullptr;
@@ -279,6 +281,7 @@ struct ccd_batch {
     int opt_keep_float = 1;              // CCD_OPT_KEEP_FLOAT
     int opt_range_bits = 0;              // CCD_OPT_RANGE_BITS (tests: lowered feature limit of the dynamic operand check)
     int opt_mfma_arm = 0;                // CCD_OPT_MFMA_ARM (off: bit-exact but slower than the vector-ALU producers)
+    int opt_fixed_shape = 1;             // CCD_FIXED_SHAPE=0 (environment; A/B and tests): every network through the run-time-shape instantiations
     // upsampling: step k of every slot's pyramid in one launch
     struct UpsStep { int first_z, n_z, max_w, max_h; };
     std::vector<UpsStep> ups_steps;
@@ -378,6 +381,7 @@ int ccd_batch_create(int device, ccd_batch** out) {
     if (const char* e = std::getenv("CCD_FORCE_GENERIC")) b->force_generic = std::atoi(e);
     if (const char* e = std::getenv("CCD_FUSED_DEC")) b->opt_fused_dec = std::atoi(e);
     if (const char* e = std::getenv("CCD_MFMA_ARM")) b->opt_mfma_arm = std::atoi(e);
+    if (const char* e = std::getenv("CCD_FIXED_SHAPE")) b->opt_fixed_shape = std::atoi(e);
     b->d_scale_table = sh->d_scale_table;
     b->d_rcp_table = sh->d_rcp_table;
     b->up_stream = sh->up_stream;
@@ -468,6 +472,7 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
                      entropy_pipe_supports_mfma(h.total_context_arm, h.n_hidden_layers_arm + 1, h.output_feature_ifce, net.arm.narrow ? 1 : 0, max_w, max_w_abs);
     }
     s.use_dyn = s.use_pipe && !s.use_mfma && (net.arm.dyn_feat || b->opt_range_bits != 0);
+    s.fixed_shape = (s.use_pipe && !s.use_mfma && b->opt_fixed_shape) ? entropy_pipe_fixed_shape(h.total_context_arm, h.n_hidden_layers_arm + 1, h.spatial_context_arm) : 0;
     s.ring_rows = s.use_mfma ? std::max(entropy_pipe_ring_rows(max_w), 64) : 512;  // the matrix-core variant needs the LDS for its operand tables
     s.lds_pipe = entropy_pipe_lds_bytes(h.total_context_arm, h.n_hidden_layers_arm + 1, s.ring_rows, s.use_mfma ? 1 : 0);
     s.lds_generic = entropy_lds_bytes(h.total_context_arm, static_cast<int>(arm_blob.size()));
@@ -819,18 +824,19 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
     std::vector<int> host_slot;  // slot of host[k]: its status words are words [64 slot, 64 slot + 64) of the batch's status array
     b->pipe_groups.clear();  // the pipelined kernel is instantiated per input width nv = ceil(dim / 4): one launch per width
     for (int nv = 1; nv <= 8; ++nv)
-        for (int var = 0; var < 3; ++var) {  // vector ALU without / with the device check of the features, matrix cores
-            const int mf = var == 2 ? 1 : 0, dyn = var == 1 ? 1 : 0;
-            const int first = static_cast<int>(host.size());
-            size_t lds = 0;
-            for (int i = 0; i < n; ++i) {
-                const Slot& sl = *b->slots[i];
-                if (sl.use_pipe && (sl.ep.dim + 3) / 4 == nv && (sl.use_mfma ? 1 : 0) == mf && (sl.use_dyn ? 1 : 0) == dyn) {
-                    host.push_back(sl.ep); host_slot.push_back(i); lds = std::max(lds, sl.lds_pipe);
+        for (int var = 0; var < 3; ++var)  // vector ALU without / with the device check of the features, matrix cores
+            for (int shape = 0; shape < 2; ++shape) {  // run-time ARM shape / the compile-time instantiation of the HOP shape
+                const int mf = var == 2 ? 1 : 0, dyn = var == 1 ? 1 : 0;
+                const int first = static_cast<int>(host.size());
+                size_t lds = 0;
+                for (int i = 0; i < n; ++i) {
+                    const Slot& sl = *b->slots[i];
+                    if (sl.use_pipe && (sl.ep.dim + 3) / 4 == nv && (sl.use_mfma ? 1 : 0) == mf && (sl.use_dyn ? 1 : 0) == dyn && sl.fixed_shape == shape) {
+                        host.push_back(sl.ep); host_slot.push_back(i); lds = std::max(lds, sl.lds_pipe);
+                    }
                 }
+                if (static_cast<int>(host.size()) > first) b->pipe_groups.push_back({nv, mf, dyn, shape, first, static_cast<int>(host.size()) - first, lds});
             }
-            if (static_cast<int>(host.size()) > first) b->pipe_groups.push_back({nv, mf, dyn, first, static_cast<int>(host.size()) - first, lds});
-        }
     b->n_pipe = static_cast<int>(host.size());
     for (int i = 0; i < n; ++i) if (!b->slots[i]->use_pipe) { host.push_back(b->slots[i]->ep); host_slot.push_back(i); }
     b->n_generic = n - b->n_pipe;
@@ -1057,7 +1063,7 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
             }
             return sh->side[side];
         };
-        for (const auto& g : b->pipe_groups) HIP_TRY(launch_entropy_pipe(b->d_params + g.first, g.n, g.nv, g.mfma, g.dyn, g.lds, stream_for(k++)));
+        for (const auto& g : b->pipe_groups) HIP_TRY(launch_entropy_pipe(b->d_params + g.first, g.n, g.nv, g.mfma, g.dyn, g.shape, g.lds, stream_for(k++)));
         if (b->n_generic > 0) HIP_TRY(launch_entropy(b->d_params + b->n_pipe, b->n_generic, b->lds_generic, stream_for(k++)));
         for (int side : used) {
             if (!b->side_done[side]) HIP_TRY(hipEventCreateWithFlags(&b->side_done[side], hipEventDisableTiming));
@@ -1132,7 +1138,7 @@ int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64) {
 int ccd_batch_slot_kernels(const ccd_batch* b, int slot) {
     if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
     const Slot& s = *b->slots[slot];
-    return (s.use_pipe ? 1 : 0) | (s.use_fused_syn ? 2 : 0) | (s.use_fused_dec ? 4 : 0) | (s.use_mfma ? 8 : 0) | (s.use_dyn ? 16 : 0);
+    return (s.use_pipe ? 1 : 0) | (s.use_fused_syn ? 2 : 0) | (s.use_fused_dec ? 4 : 0) | (s.use_mfma ? 8 : 0) | (s.use_dyn ? 16 : 0) | (s.fixed_shape ? 32 : 0);
 }
 
 const float* ccd_batch_output(const ccd_batch* b, int slot) {

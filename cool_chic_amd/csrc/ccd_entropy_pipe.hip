@@ -188,6 +188,8 @@ struct alignas(16) RowMeta {  // per table row (= pixel of a batch in flight)
 // accesses are LDS accesses once a pointer travelled through a struct.
 extern __shared__ __attribute__((aligned(16))) unsigned char ccd_pipe_smem[];
 template <typename T>
+__device__ __forceinline__ T* smem_at(uint32_t off) { return reinterpret_cast<T*>(ccd_pipe_smem + off); }
+template <typename T>
 struct LdsRef {
     uint32_t off;
     __device__ __forceinline__ operator T*() const { return reinterpret_cast<T*>(ccd_pipe_smem + off); }
@@ -196,6 +198,41 @@ struct LdsRef {
         return *this;
     }
 };
+
+// Byte offsets of the LDS regions (all multiples of 16).  ONE definition for the kernel's carve-up (run-time shape), the
+// compile-time layout of a fixed-shape instantiation (ShapeFix) and the host's size (entropy_pipe_lds_bytes).
+struct PipeLayout { uint32_t ring, w, b, act, a, tab, meta, rcp, exp, ready, consumed, abort, end; int n_w_hidden; };
+__host__ __device__ constexpr PipeLayout pipe_layout(int dim, int n_layers, int in_pad, int ring_rows, int mf_tabs) {
+    PipeLayout L{};
+    L.ring = 0;  // LDS address 0: the decoder uses ring cells as addresses
+    L.w = static_cast<uint32_t>(ring_rows) * 64u;  // network next: its addresses stay below 64 KB, so the per-vector offsets fold into the ds_read immediates
+    L.n_w_hidden = (n_layers - 1) * dim * in_pad;
+    const int n_w_total = L.n_w_hidden + 4 * in_pad;  // + output layer (2 rows) + stabiliser (2 rows)
+    L.b = L.w + static_cast<uint32_t>((n_w_total + 3) & ~3) * 4u;
+    const int n_b_total = (n_layers - 1) * dim + 4;
+    L.act = L.b + static_cast<uint32_t>((n_b_total + 1) & ~1) * 8u;
+    L.a = L.act + static_cast<uint32_t>(kProducers * ((mf_tabs ? 16 : 8) * in_pad + 4)) * 4u;
+    L.tab = L.a + static_cast<uint32_t>(mf_tabs) * 1024u;
+    L.meta = L.tab + static_cast<uint32_t>(kRows + 1) * 64u * 8u;
+    L.rcp = L.meta + static_cast<uint32_t>(sizeof(RowMeta));
+    L.exp = L.rcp + static_cast<uint32_t>(kNumScale + 1) * 8u;
+    L.ready = L.exp + static_cast<uint32_t>(1 << CCD_EXP_LOG) * 8u;
+    L.consumed = L.ready + static_cast<uint32_t>(kSlots) * 4u;
+    L.abort = L.consumed + 8u;
+    L.end = (L.ready + static_cast<uint32_t>(kSlots + 8) * 4u + 15u) & ~15u;
+    return L;
+}
+
+// Shape of the ARM as the producers see it.  ShapeDyn: read from the parameter block (any network the kernel supports).
+// ShapeFix: compile-time inputs / layers / spatial contexts - every LDS region of the task loop sits at a constant address (no
+// scalar registers held for offsets, so no SGPR spill moves on the late path), the hidden-layer loop has a constant trip
+// count and the `n_layers` / `split` branches are gone.  Instantiated for the architecture the metric's sets use
+// (cfg/dec/intra/hop.cfg: 14 spatial contexts + 6 IFCE features, two hidden layers); the left neighbour (y, x - 1) is the
+// context of priority 0 (arm.py:501-509), i.e. input 0 of every network with a spatial context.
+struct ShapeDyn { static constexpr bool fixed = false; static constexpr int dim = 0, n_layers = 0, n_sp = 0; };
+template <int DIM, int NL, int NSP>
+struct ShapeFix { static constexpr bool fixed = true; static constexpr int dim = DIM, n_layers = NL, n_sp = NSP; };
+using ShapeHop = ShapeFix<20, 3, 14>;
 
 struct PipeCtx {
     const EntropyParams* P;
@@ -1242,9 +1279,20 @@ __device__ __forceinline__ ExactOut exact_pixel(const ExactArgs& A, int y, int x
 
 // MF: this grid's tasks run the ARM on the matrix cores; DYN_RING: the kernel's ring of decoded symbols has
 // EntropyParams::ring_rows rows instead of kRingRows (every grid of a matrix-core kernel, whichever producer serves it).
-template <int NV, int kLpp, bool MF, bool DYN_RING, bool DYN>
-__device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned long long* prof) {
+template <int NV, int kLpp, bool MF, bool DYN_RING, bool DYN, class SH>
+__device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned long long* prof) {
     constexpr int in_pad = 4 * NV;
+    static_assert(!SH::fixed || (!MF && SH::dim <= in_pad && SH::dim > in_pad - 4 && SH::n_sp >= 1 && SH::n_layers >= 2), "ShapeFix: vector-ALU path, matching width");
+    // fixed shape: every region at its compile-time address (the same pipe_layout the kernel carved the LDS with)
+    PipeCtx C_fix = C_run;
+    if constexpr (SH::fixed) {
+        constexpr PipeLayout L = pipe_layout(SH::dim, SH::n_layers, in_pad, kRingRows, 0);
+        C_fix.s_ring.off = L.ring; C_fix.s_w.off = L.w; C_fix.s_b.off = L.b; C_fix.s_act.off = L.act; C_fix.s_a.off = L.a; C_fix.s_tab.off = L.tab;
+        C_fix.s_meta.off = L.meta; C_fix.s_rcp.off = L.rcp; C_fix.s_exp.off = L.exp; C_fix.s_ready.off = L.ready; C_fix.s_consumed.off = L.consumed;
+        C_fix.s_abort.off = L.abort; C_fix.n_w_hidden = L.n_w_hidden; C_fix.ring_mask = kRingRows - 1;
+        C_fix.dim = SH::dim; C_fix.n_layers = SH::n_layers; C_fix.n_sp = SH::n_sp; C_fix.k_left = 0;
+    }
+    const PipeCtx& C = C_fix;
     constexpr int kTaskPix = 64 / kLpp;
     constexpr int kBpx = kTaskPix == 2 ? 8 : (kTaskPix == 8 ? kBpxWide : 16);   // pixels per decoder batch (see decoder_grid)
     constexpr int kHalves = kBpx / kTaskPix;
@@ -1255,8 +1303,9 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     // arithmetic and the task filter run on the scalar unit instead of as exec-masked vector code.
     const int pw = uni(static_cast<int>(threadIdx.x >> 6) - 1);
     const EntropyParams& P = *C.P;
-    const int dim = uni(C.dim), n_layers = uni(C.n_layers), n_sp = uni(C.n_sp), W = uni(C.W);
-    const int k_left = uni(C.k_left), fin = uni(C.fin), fw = uni(C.fw);
+    const int dim = SH::fixed ? SH::dim : uni(C.dim), n_layers = SH::fixed ? SH::n_layers : uni(C.n_layers), n_sp = SH::fixed ? SH::n_sp : uni(C.n_sp);
+    const int W = uni(C.W);
+    const int k_left = SH::fixed ? 0 : uni(C.k_left), fin = uni(C.fin), fw = uni(C.fw);
     const uint32_t seq_base = uni(C.seq_base);
     // this wave's activation tile [kTaskPix][in_pad] (MF: [16][in_pad], the exact redo) + 4 dummy words (stores of lanes that own
     // no activation go there by address select: no exec mask, no skip branch)
@@ -1309,12 +1358,11 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
     uint32_t seq = seq_base;
     // pixels of the stream in front of this step, the previous one, the one before; rows the step start moved down in between
     uint32_t pix0 = uni(C.px_base), prev_pix0 = pix0, prev2_pix0 = pix0, prev_moved = 0;
-    bool ok = true;
     // Task t of a step (pixels t kTaskPix ..) has the global index seq0 kHalves + t and belongs to producer index % kProducers:
     // a producer visits only its own tasks (first owned one of the step, then every kProducers-th).
     uint32_t phase = static_cast<uint32_t>((static_cast<unsigned long long>(seq_base) * kHalves) % kProducers);  // (seq0 kHalves) mod kProducers
     const bool split = k_left >= 0 && W > 9 && n_layers >= 2;  // (not in raster order)
-    while (ok && it.next()) {
+    while (it.next()) {
         const uint32_t nb = (it.n + kBpx - 1) >> kBpxShift;
         const uint32_t n_tasks = (it.n + kTaskPix - 1) >> kTaskShift;
         const uint32_t seq0 = seq;
@@ -1383,7 +1431,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 #endif
                     {
                         const unsigned long long t0 = PROF_T();
-                        if (!wait_ge2(C.s_consumed, need_slot, split ? need_early_px : need_px, C.s_abort)) { ok = false; break; }
+                        if (!wait_ge2(C.s_consumed, need_slot, split ? need_early_px : need_px, C.s_abort)) return seq;  // (abort / lost hand-over: the kernel stops behind this grid, the count is not used)
                         PROF_ADD(prof[0], t0);
                     }
                     lt_b = LPROF_T(pw == 0);
@@ -1455,7 +1503,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     lt_c = LPROF_T(pw == 0);
                     if (split) {
                         const unsigned long long t0 = PROF_T();
-                        if (!wait_ge(C.s_consumed + 1, need_px, C.s_abort)) { ok = false; break; }
+                        if (!wait_ge(C.s_consumed + 1, need_px, C.s_abort)) return seq;  // (abort / lost hand-over: the kernel stops behind this grid, the count is not used)
                         PROF_ADD(prof[0], t0);
                         PROF_SUB(prof[2], t0);  // the MLP's stamps bracket this wait: take it out of them
                         PROF_ADD(prof[5], t0);  // late wait
@@ -1547,7 +1595,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     const unsigned long long t0 = PROF_T();
                     // (the early wait includes "slot free again": true long ago whenever it is looked at - the slot was last used
                     // kNSlots batches back - and it lets the table rows' tails be cleared before the late wait, see below)
-                    if (!wait_ge2(C.s_consumed, need_slot, split ? need_early_px : need_px, C.s_abort)) { ok = false; break; }
+                    if (!wait_ge2(C.s_consumed, need_slot, split ? need_early_px : need_px, C.s_abort)) return seq;  // (abort / lost hand-over: the kernel stops behind this grid, the count is not used)
                     PROF_ADD(prof[0], t0);
                 }
                 lt_b = LPROF_T(pw == 0);
@@ -1569,13 +1617,27 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                 {   // every lane, branch-free: a lane of a pixel that does not exist fills its own (unused) row of the tile, a lane
                     // without an input stores to the dummy words; the ring read is unconditional (its offsets are 0 where there is no
                     // spatial context: the cell of the pixel itself, in bounds) and selected afterwards
+                    int32_t rr[NOUT];
+#pragma unroll
+                    for (int t = 0; t < NOUT; ++t) {
+                        const int yy = y - ctx_dy_l[t], xx = x + ctx_dx_l[t];
+                        rr[t] = C.s_ring[(yy & ring_mask) * 64 + ((xx + 10 * yy) & 63)];
+                    }
+                    // (a use the compiler cannot sink the reads behind: they stay unconditional - and ALL of them are on their way
+                    // before the first one is waited for; one statement per read made it wait for each in turn)
+                    if constexpr (NOUT == 1) asm volatile("" : "+v"(rr[0]));
+                    else if constexpr (NOUT == 2) asm volatile("" : "+v"(rr[0]), "+v"(rr[1]));
+                    else if constexpr (NOUT == 3) asm volatile("" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]));
+                    else if constexpr (NOUT == 4) asm volatile("" : "+v"(rr[0]), "+v"(rr[1]), "+v"(rr[2]), "+v"(rr[3]));
+                    else {
+#pragma unroll
+                        for (int t = 0; t < NOUT; ++t) asm volatile("" : "+v"(rr[t]));
+                    }
 #pragma unroll
                     for (int t = 0; t < NOUT; ++t) {
                         const int k = q + kLpp * t;
                         const int yy = y - ctx_dy_l[t], xx = x + ctx_dx_l[t];
-                        int32_t r = C.s_ring[(yy & ring_mask) * 64 + ((xx + 10 * yy) & 63)];
-                        asm volatile("" : "+v"(r));  // (a use the compiler cannot sink the read behind: it stays unconditional)
-                        const int32_t v = k < n_sp ? ((yy >= 0 && xx >= 0 && xx < W && !(split && k == k_left)) ? r : 0) : fv[t];
+                        const int32_t v = k < n_sp ? ((yy >= 0 && xx >= 0 && xx < W && !(split && k == k_left)) ? rr[t] : 0) : fv[t];
                         int32_t* const dst = k < in_pad ? act + px * in_pad + k : act_dummy;
                         *dst = v << 16;  // armint.py:193
                     }
@@ -1642,16 +1704,29 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
                     }
                     if constexpr (NOUT == 1) acc0[0] += acc0_b;
                 }
-                // ---- the left neighbour: wait for it (and for the slot), add its term to the first layer and the stabiliser
+                // ---- the left neighbour: wait for it, add its term to the first layer and the stabiliser.  The decoder's pixel count and
+                // the neighbour's ring cell are requested TOGETHER (one LDS round trip instead of two on the late path): LDS requests of a
+                // wave are served in order and the decoder writes the ring before it publishes the count, so a count that has
+                // reached `need_px` vouches for the cell read behind it; otherwise both are read again in the polling loop.
+                // Unconditional read (cell of column -1 for x = 0: in bounds, dropped by the select), no exec mask.
                 int32_t xleft = 0;
                 lt_c = LPROF_T(pw == 0);
                 if (split) {
                     const unsigned long long t0 = PROF_T();
-                    if (!wait_ge(C.s_consumed + 1, need_px, C.s_abort)) { ok = false; break; }
+                    const uint32_t want = uni(need_px);
+                    const uint32_t cell = static_cast<uint32_t>((y & ring_mask) * 64 + ((x - 1 + 10 * y) & 63));
+                    uint32_t seen_v;
+                    int32_t r;
+                    asm volatile("ds_read_b32 %0, %2 offset:4\n\tds_read_i8 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(seen_v), "=&v"(r) : "v"(C.s_consumed.off), "v"(C.s_ring.off + cell) : "memory");
+                    if (__builtin_expect(static_cast<int32_t>(uni(seen_v) - want) < 0, 0)) {
+                        if (!wait_ge(C.s_consumed + 1, need_px, C.s_abort)) return seq;
+                        r = C.s_ring[cell];
+                    }
                     PROF_ADD(prof[0], t0);
                     PROF_SUB(prof[2], t0);  // the MLP's stamps bracket this wait: take it out of them
                     PROF_SUB(prof[6], t0);
-                    if (px < cnt && x >= 1) xleft = static_cast<int32_t>(C.s_ring[(y & ring_mask) * 64 + ((x - 1 + 10 * y) & 63)]) << 16;
+                    xleft = (px < cnt && x >= 1) ? r << 16 : 0;
                 }
                 lt_d = LPROF_T(pw == 0);
                 mad64(so[0], xleft, wleft_stab);
@@ -1888,7 +1963,6 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 #endif
             }
         }
-        if (!ok) break;
         seq = seq0 + nb;
         phase = (phase + nb * kHalves) % kProducers;
         prev2_pix0 = prev_pix0;
@@ -1905,9 +1979,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C, unsigned lon
 // sentinels + the int32 side plane and the producers carry the check and the int64 redo (exact_pixel).  Networks whose worst
 // case provably fits run the DYN = false instantiation: the same kernel without that code (its mere presence in the task loop
 // costs ~2 %, profiles/r03/ab_entropy_dynamic_operand_check.txt).
-template <int NV, bool MF, bool DYN>
+template <int NV, bool MF, bool DYN, class SH>
 __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const EntropyParams* slots_desc) {
-    unsigned char* const smem = ccd_pipe_smem;
     const EntropyParams& P = slots_desc[blockIdx.x];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1920,30 +1993,19 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     // ---- LDS carve-up (all offsets multiples of 16) ----------------------------------------------
     PipeCtx C;
     C.P = &P;
-    // network first: its addresses stay below 64 KB, so the per-vector offsets fold into the ds_read immediates
     const int ring_rows = MF ? P.ring_rows : kRingRows;
-    C.s_ring = reinterpret_cast<int8_t*>(smem);  // LDS address 0: the decoder uses ring cells as addresses
+    {
+        const PipeLayout L = pipe_layout(dim, n_layers, in_pad, ring_rows, MF ? mf_tables(n_layers) : 0);
+        C.s_ring.off = L.ring; C.s_w.off = L.w; C.s_b.off = L.b; C.s_act.off = L.act; C.s_a.off = L.a; C.s_tab.off = L.tab;
+        C.s_meta.off = L.meta; C.s_rcp.off = L.rcp; C.s_exp.off = L.exp; C.s_ready.off = L.ready; C.s_consumed.off = L.consumed;
+        C.s_abort.off = L.abort; C.n_w_hidden = L.n_w_hidden;
+    }
     C.ring_mask = ring_rows - 1;
-    C.s_w = reinterpret_cast<int32_t*>(smem + ring_rows * 64);
-    C.n_w_hidden = (n_layers - 1) * dim * in_pad;
-    const int n_w_total = C.n_w_hidden + 4 * in_pad;  // + output layer (2 rows) + stabiliser (2 rows)
-    C.s_b = reinterpret_cast<int64_t*>(C.s_w + ((n_w_total + 3) & ~3));
-    const int n_b_total = (n_layers - 1) * dim + 4;
-    C.s_act = reinterpret_cast<int32_t*>(C.s_b + ((n_b_total + 1) & ~1));
     constexpr int kActRows = MF ? 16 : 8;
-    C.s_a = reinterpret_cast<uint32_t*>(C.s_act + kProducers * (kActRows * in_pad + 4));
-    C.s_tab = reinterpret_cast<uint2*>(static_cast<uint32_t*>(C.s_a) + (MF ? mf_tables(n_layers) * 256 : 0));
-    C.s_meta = reinterpret_cast<RowMeta*>(C.s_tab + (kRows + 1) * 64);
-    double* s_rcp = reinterpret_cast<double*>(C.s_meta + 1);
-    C.s_rcp = s_rcp;
-    double* s_exp = s_rcp + kNumScale + 1;
-    C.s_exp = s_exp;
-    uint32_t* s_sync = reinterpret_cast<uint32_t*>(s_exp + kExpN);
+    double* s_rcp = smem_at<double>(C.s_rcp.off);
+    double* s_exp = smem_at<double>(C.s_exp.off);
     for (int i = tid; i < kNumScale; i += kPipeThreads) s_rcp[i] = P.rcp_table[i];
     for (int i = tid; i < kExpN; i += kPipeThreads) s_exp[i] = kExpTab[i];
-    C.s_ready = s_sync;
-    C.s_consumed = s_sync + kSlots;
-    C.s_abort = C.s_consumed + 2;
     C.dim = dim; C.n_layers = n_layers; C.n_sp = P.n_spatial; C.n_if = n_if;
     C.k_left = -1;
     for (int k = 0; k < P.n_spatial; ++k) if (P.ctx_dy[k] == 0 && P.ctx_dx[k] == -1) C.k_left = k;
@@ -2168,7 +2230,8 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         } else {
             // the matrix-core evaluation only serves the 8-pixel tasks of wide grids: its chain has the same length whatever
             // the number of pixels, while the vector-ALU code of a 4- / 2-pixel task spreads a pixel over 16 / 32 lanes
-            seq_end = C.task_pix == 8 ? producer_grid<NV, 8, MF, MF, DYN>(C, prof) : (C.task_pix == 4 ? producer_grid<NV, 16, false, MF, DYN>(C, prof) : producer_grid<NV, 32, false, MF, DYN>(C, prof));
+            seq_end = C.task_pix == 8 ? producer_grid<NV, 8, MF, MF, DYN, SH>(C, prof)
+                                      : (C.task_pix == 4 ? producer_grid<NV, 16, false, MF, DYN, SH>(C, prof) : producer_grid<NV, 32, false, MF, DYN, SH>(C, prof));
         }
         const unsigned long long t_b = PROF_T();
         __syncthreads();  // also makes the decoder's global writes of this grid visible to every wave
@@ -2213,19 +2276,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
 }
 
 size_t entropy_pipe_lds_bytes(int dim, int n_layers, int ring_rows, int mfma) {
-    const int in_pad = (dim + 3) & ~3;
-    const int n_w_total = (n_layers - 1) * dim * in_pad + 4 * in_pad;
-    const int n_b_total = (n_layers - 1) * dim + 4;
-    size_t n = static_cast<size_t>(kRows + 1) * 64 * sizeof(uint2);
-    n += sizeof(RowMeta);
-    n += static_cast<size_t>((n_w_total + 3) & ~3) * 4;
-    n += static_cast<size_t>((n_b_total + 1) & ~1) * 8;
-    n += static_cast<size_t>(kProducers) * ((mfma ? 16 : 8) * in_pad + 4) * 4;
-    if (mfma) n += static_cast<size_t>(mf_tables(n_layers)) * 1024;
-    n += static_cast<size_t>(ring_rows) * 64;
-    n += static_cast<size_t>(kNumScale + 1) * 8 + static_cast<size_t>(kExpN) * 8;
-    n += (kSlots + 8) * 4;
-    return (n + 15) & ~size_t{15};
+    return pipe_layout(dim, n_layers, (dim + 3) & ~3, ring_rows, mfma ? mf_tables(n_layers) : 0).end;
 }
 
 // rows of the decoded-symbol ring for a stream whose widest grid is max_grid_w (0: too wide for the kernel)
@@ -2270,19 +2321,28 @@ hipError_t launch_laplace_sweep_pipe(const float* scale_table, const double* rcp
     return hipGetLastError();
 }
 
-template <int NV, bool MF, bool DYN>
+template <int NV, bool MF, bool DYN, class SH = ShapeDyn>
 static hipError_t launch_pipe_nv(const EntropyParams* d_slots, int n_slots, size_t lds_bytes, hipStream_t stream) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(entropy_pipe_kernel<NV, MF, DYN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(entropy_pipe_kernel<NV, MF, DYN, SH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((entropy_pipe_kernel<NV, MF, DYN>), dim3(n_slots), dim3(kPipeThreads), lds_bytes, stream, d_slots);
+    hipLaunchKernelGGL((entropy_pipe_kernel<NV, MF, DYN, SH>), dim3(n_slots), dim3(kPipeThreads), lds_bytes, stream, d_slots);
     return hipGetLastError();
 }
 
-// All `n_slots` descriptors must share nv = ceil(dim / 4), the mfma flag and the dyn flag (the host groups the slots of a batch by
-// all three).  The matrix-core variant's envelope implies dyn = 0.
-hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, int mfma, int dyn, size_t lds_bytes, hipStream_t stream) {
+// the shapes with a compile-time instantiation (launch_entropy_pipe's `shape`): 0 = none, 1 = ShapeHop
+int entropy_pipe_fixed_shape(int dim, int n_layers, int n_spatial) {
+    return (dim == ShapeHop::dim && n_layers == ShapeHop::n_layers && n_spatial == ShapeHop::n_sp) ? 1 : 0;
+}
+
+// All `n_slots` descriptors must share nv = ceil(dim / 4), the mfma flag, the dyn flag and the fixed shape (the host groups the
+// slots of a batch by all four).  The matrix-core variant's envelope implies dyn = 0 and shape = 0.
+hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv, int mfma, int dyn, int shape, size_t lds_bytes, hipStream_t stream) {
     if (n_slots <= 0) return hipSuccess;
+    if (shape == 1 && !mfma && nv == 5)
+        return dyn ? launch_pipe_nv<5, false, true, ShapeHop>(d_slots, n_slots, lds_bytes, stream)
+                   : launch_pipe_nv<5, false, false, ShapeHop>(d_slots, n_slots, lds_bytes, stream);
+    if (shape != 0) return hipErrorInvalidValue;
     if (mfma) {
         switch (nv) {
             case 1: return launch_pipe_nv<1, true, false>(d_slots, n_slots, lds_bytes, stream);

@@ -971,7 +971,7 @@ def _run_bench_two_ranks(extra):
 def test_bench_two_ranks_on_one_gpu_gloo():
     """bench.py --gpus 2 with its DEFAULTS (what the driver's scaling runs launch): BASELINE's kodak24 sharded round-robin over
     the ranks (strong), per-rank batch, gather of the planes to rank 0, max-over-ranks timing - and, beside the metric, the two
-    collective legs `clic41_sharded` (BASELINE configs[2] round-robin) and `throughput_regime` (264 streams per rank) - executed
+    collective legs `clic41_sharded` (BASELINE configs[2] round-robin) and `throughput_regime` (256 streams per rank) - executed
     with two ranks sharing this box's GPU and the host-staged "gloo" backend: every gathered set must hash to the oracle's
     planes.  (The RCCL transport itself needs one GPU per rank: the driver's scaling runs.)"""
     res = _run_bench_two_ranks([])
@@ -984,8 +984,8 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert c["scaling"] == "strong" and c["frames"] == 41 and c["frames_on_rank0"] == 21
     assert c["verified"]["ok"] is True and c["verified"]["frames_checked"] == 41, c["verified"]
     t = res["throughput_regime"]
-    assert t["scaling"] == "weak" and t["streams_per_gpu"] == 264
-    assert t["verified"]["ok"] is True and t["verified"]["frames_checked"] == 528, t["verified"]
+    assert t["scaling"] == "weak" and t["streams_per_gpu"] == 256
+    assert t["verified"]["ok"] is True and t["verified"]["frames_checked"] == 512, t["verified"]
 
 
 def test_bench_two_ranks_weak_scaling_gloo():
