@@ -40,7 +40,8 @@ class DecodeBatch:
         check(lib().ccd_batch_create(int(device), C.byref(self._h)), "ccd_batch_create")
         self.device = int(device)
         if fused_dec is not None:
-            check(lib().ccd_batch_set_option(self._h, self.OPT_FUSED_DEC, int(bool(fused_dec))), "ccd_batch_set_option")
+            # False / True, or 2: the fused kernel behind the batch's pyramid steps (level-1 stack pre-computed once per frame)
+            check(lib().ccd_batch_set_option(self._h, self.OPT_FUSED_DEC, int(fused_dec)), "ccd_batch_set_option")
         if keep_float is not None:
             check(lib().ccd_batch_set_option(self._h, self.OPT_KEEP_FLOAT, int(bool(keep_float))), "ccd_batch_set_option")
         if mfma_arm is not None:
@@ -98,7 +99,8 @@ class DecodeBatch:
     # ---- results -------------------------------------------------------------------------------
     def slot_kernels(self, slot: int) -> int:
         """bit 0: pipelined entropy kernel, bit 1: fused synthesis kernel, bit 2: fused upsampling + synthesis kernel,
-        bit 3: the ARM on the matrix cores, bit 4: the pipelined kernel's instantiation with the device check of IFCE features."""
+        bit 3: the ARM on the matrix cores, bit 4: the pipelined kernel's instantiation with the device check of IFCE features,
+        bit 5: its instantiation with a compile-time ARM shape (HOP), bit 6: the fused float kernel behind the pyramid launch."""
         return check(lib().ccd_batch_slot_kernels(self._h, slot), "ccd_batch_slot_kernels")
 
     def latent(self, slot: int, grid: int) -> np.ndarray:

@@ -38,7 +38,11 @@ hipError_t launch_syn_fused(const SynthFused* d_frames, int n_frames, int c_in, 
 bool fused_dec_supports(int c_in, int c);
 size_t fused_dec_lds_bytes(int n_lv, int c, int n_conv, int n_params);
 void fused_dec_param_shape(int c_in, int c, int* nwv, int* nws, int* nwc, int* nwo);
-hipError_t launch_fused_dec(const FusedDec* d_frames, const void* d_work, int n_work, int c_in, int c, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_fused_dec(const FusedDec* d_frames, const void* d_work, int n_work, int c_in, int c, int pre, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_fused_pyramid(const FusedDec* d_frames, const void* d_work, int n_work, int levels, size_t lds_bytes, hipStream_t stream);
+size_t fused_pyr_lds_bytes(int n_lv);
+bool fused_dec_cr_supports(int c_in, int c);
+hipError_t launch_fused_dec_cr(const FusedDec* d_frames, const void* d_work, int n_work, int c_in, int c, size_t lds_bytes, hipStream_t stream);
 int fused_dec_profile(unsigned long long* out16, int reset);
 hipError_t launch_resize_nearest(const float* in, float* out, int c, int h_in, int w_in, int h_out, int w_out,
                                  hipStream_t stream);
@@ -211,6 +215,8 @@ struct Slot {
     bool use_fused_syn = false;      // whole synthesis in one kernel (ccd_synth_fused.hip)
     SynthFused fused;
     bool use_fused_dec = false;      // upsampling + synthesis + integer samples in one kernel (ccd_fused.hip)
+    bool fdec_pre = false;           // ... whose level-1 stack comes from the batch's pyramid launch (CCD_OPT_FUSED_DEC = 2)
+    FusedDec fpyr;                   // ... descriptor of that launch: the same walk one level up (level 0 = this frame's level 1)
     FusedDec fdec;
     size_t fdec_lds = 0;
     std::vector<size_t> w_off, b_off;  // per main layer
@@ -273,11 +279,16 @@ struct ccd_batch {
     std::vector<FusedGroup> fused_groups;
     SynthFused* d_fused = nullptr;
     // fused float path (ccd_fused.hip): frames grouped by (latent levels, output channels); one workgroup per run of tiles
-    struct FdecGroup { int c_in, c, first_frame, first_work, n_work; size_t lds; };
+    struct FdecGroup { int c_in, c, pre, cr, first_frame, first_work, n_work; size_t lds; };
     std::vector<FdecGroup> fdec_groups;
     FusedDec* d_fdec = nullptr;
     void* d_fdec_work = nullptr;
-    int opt_fused_dec = 1;               // CCD_OPT_FUSED_DEC
+    // pyramid launches in front of the kFdPre groups (stage 1): descriptors grouped by their number of levels
+    struct PyrGroup { int levels, first_frame, first_work, n_work; size_t lds; };
+    std::vector<PyrGroup> pyr_groups;
+    FusedDec* d_pyr = nullptr;
+    void* d_pyr_work = nullptr;
+    int opt_fused_dec = 2;               // CCD_OPT_FUSED_DEC: 2 = fused kernel behind the pyramid launch, 1 = the whole pyramid per tile, 0 = unfused
     int opt_keep_float = 1;              // CCD_OPT_KEEP_FLOAT
     int opt_range_bits = 0;              // CCD_OPT_RANGE_BITS (tests: lowered feature limit of the dynamic operand check)
     int opt_mfma_arm = 0;                // CCD_OPT_MFMA_ARM (off: bit-exact but slower than the vector-ALU producers)
@@ -582,15 +593,20 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
         std::memset(&D, 0, sizeof(D));
         const auto& L = net.syn;
         const int C = h.out_channels;
-        bool ok = b->opt_fused_dec && !b->force_generic && !s.cr && n_levels == s.dense_c && n_levels >= 2 && n_levels <= kFdMaxLevels &&
-                  fused_dec_supports(n_levels, C) && net.ups_k == 8 && net.pre_k == 7 && L.size() >= 2 &&
+        // common randomness: n_levels noise planes behind the latent channels (the kFdPre instantiations with NZ = CIN; pictures only)
+        const int NZ = s.cr ? n_levels : 0;
+        bool ok = b->opt_fused_dec && !b->force_generic && n_levels + NZ == s.dense_c && n_levels >= 2 && n_levels <= kFdMaxLevels &&
+                  fused_dec_supports(n_levels, C) && (!s.cr || (b->opt_fused_dec == 2 && fused_dec_cr_supports(n_levels, C))) &&
+                  net.ups_k == 8 && net.pre_k == 7 && L.size() >= 2 &&
                   L.size() <= 2 + static_cast<size_t>(kFdMaxConv) && L[0].k == 1 && L[1].k == 1 && !L[0].residual && !L[1].residual &&
-                  L[0].c_in == n_levels && L[1].c_in == L[0].c_out && L[1].c_out == C && (!net.syn_stab.c_out || net.syn_stab.c_in <= n_levels);
+                  L[0].c_in == n_levels + NZ && L[1].c_in == L[0].c_out && L[1].c_out == C && (!net.syn_stab.c_out || net.syn_stab.c_in <= n_levels);
         for (size_t l = 2; ok && l < L.size(); ++l) ok = L[l].k == 3 && L[l].c_in == C && L[l].c_out == C;
         if (ok) {
             const int CIN = n_levels, N = L[0].c_out, CT = (C + 3) / 4, NT = (N + 3) / 4;
+            const int CI = CIN + NZ;  // inputs of the first 1x1 layer
             int nwv, nws, nwc, nwo;
             fused_dec_param_shape(CIN, C, &nwv, &nws, &nwc, &nwo);
+            nwv = (CI + 4 * CT + 15) / 16;
             while (syn_blob.size() % 4) syn_blob.push_back(0.0f);  // the kernel copies the block with 16-byte loads
             const size_t base = syn_blob.size();
             auto alloc = [&](size_t n) { const size_t off = syn_blob.size() - base; syn_blob.resize(syn_blob.size() + n, 0.0f); return static_cast<int32_t>(off); };
@@ -610,14 +626,14 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
                 for (int i = 0; i < 4; ++i) {
                     const int hu = 4 * n + i;  // hidden unit = row i of the tile
                     if (hu >= N) continue;
-                    for (int c = 0; c < CIN; ++c) quad(wq, c, i) = L[0].w[static_cast<size_t>(hu) * CIN + c];
+                    for (int c = 0; c < CI; ++c) quad(wq, c, i) = L[0].w[static_cast<size_t>(hu) * CI + c];
                     P[D.b0_off + 4 * n + i] = L[0].b[hu];
                 }
                 for (int t = 0; t < CT; ++t)
                     for (int r = 0; r < 4; ++r)
                         for (int i = 0; i < 4; ++i) {
                             const int oc = 4 * t + i, hu = 4 * n + r;
-                            if (oc < C && hu < N) quad(wq, CIN + t * 4 + r, i) = L[1].w[static_cast<size_t>(oc) * N + hu];
+                            if (oc < C && hu < N) quad(wq, CI + t * 4 + r, i) = L[1].w[static_cast<size_t>(oc) * N + hu];
                         }
             }
             for (int oc = 0; oc < C; ++oc) P[D.b1_off + oc] = L[1].b[oc];
@@ -676,10 +692,12 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     }
     const size_t plane_px = static_cast<size_t>(s.dense_h) * s.dense_w;
     // per-layer scratch of the generic synthesis path and the dense stacks of the unfused upsampling: only when that path runs
-    const bool need_dense = !s.use_fused_dec;
+    const bool need_dense = !s.use_fused_dec || s.cr;  // (the noise planes are channels [n_levels, 2 n_levels) of the dense stack)
     const bool need_layers = !s.use_fused_dec && !s.use_fused_syn;
+    // fused kernel behind the pyramid launch: the level-1 stack (channels 1 .. n_levels - 1 at level 1's size) is stack B
+    s.fdec_pre = s.use_fused_dec && b->opt_fused_dec == 2 && n_levels >= 5;
     const size_t o_stack_a = A.reserve(need_dense ? dense_elems * 4 : 16);
-    const size_t o_stack_b = A.reserve(need_dense ? stack_b_elems * 4 : 16);
+    const size_t o_stack_b = A.reserve((need_dense || s.fdec_pre) ? stack_b_elems * 4 : 16);
     const size_t o_tmp0 = A.reserve(need_layers ? plane_px * max_c * 4 : 16);
     const size_t o_tmp1 = A.reserve(need_layers ? plane_px * max_c * 4 : 16);
     const size_t o_stab = A.reserve(need_layers ? plane_px * std::max(h.out_channels, 1) * 4 : 16);
@@ -808,6 +826,24 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
         // float samples: always when nothing else is produced (or a later stage reads them); otherwise by CCD_OPT_KEEP_FLOAT
         D.out = (!D.write_planes || b->opt_keep_float) ? s.d_syn_out : nullptr;
         for (int p = 0; p < 3; ++p) D.plane[p] = s.d_plane[p];
+        D.l1 = nullptr;
+        D.noise = s.cr ? s.d_dense + static_cast<size_t>(n_levels) * s.dense_h * s.dense_w : nullptr;
+        if (s.fdec_pre) {
+            // the pyramid launch's descriptor: this frame's levels 1 .. n - 1 as levels 0 .. n - 2, 64 x 32 tiles without margin,
+            // output = the level-1 stack the main launch's tiles load
+            FusedDec& Y = s.fpyr;
+            std::memset(&Y, 0, sizeof(Y));
+            Y.n_lv = n_levels - 1;
+            for (int i = 0; i + 1 < n_levels; ++i) {
+                Y.lat[i] = D.lat[i + 1]; Y.lh[i] = D.lh[i + 1]; Y.lw[i] = D.lw[i + 1];
+                std::memcpy(Y.k2u[i], D.k2u[i + 1], sizeof(Y.k2u[i]));
+                std::memcpy(Y.k2p[i], D.k2p[i + 1], sizeof(Y.k2p[i]));
+            }
+            Y.h = Y.lh[0]; Y.w = Y.lw[0]; Y.c = 2; Y.bitdepth = 8;
+            Y.tiles_x = (Y.w + 63) / 64; Y.tiles_y = (Y.h + 31) / 32;
+            Y.out = stack_b;
+            D.l1 = stack_b;
+        }
         s.levels.clear();  // no unfused pyramid steps for this slot
         s.use_fused_syn = false;
     }
@@ -873,8 +909,8 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
             const Slot& s = *b->slots[i];
             if (!s.use_fused_dec) continue;
             bool placed = false;
-            for (auto& g : b->fdec_groups) placed = placed || (g.c_in == s.fdec.n_lv && g.c == s.fdec.c);
-            if (!placed) b->fdec_groups.push_back({s.fdec.n_lv, s.fdec.c, 0, 0, 0, 0});
+            for (auto& g : b->fdec_groups) placed = placed || (g.c_in == s.fdec.n_lv && g.c == s.fdec.c && g.pre == (s.fdec_pre ? 1 : 0) && g.cr == (s.cr ? 1 : 0));
+            if (!placed) b->fdec_groups.push_back({s.fdec.n_lv, s.fdec.c, s.fdec_pre ? 1 : 0, s.cr ? 1 : 0, 0, 0, 0, 0});
         }
         for (auto& g : b->fdec_groups) {
             g.first_frame = static_cast<int>(frames.size());
@@ -882,13 +918,13 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
             long total_tiles = 0;
             for (int i = 0; i < n; ++i) {
                 const Slot& s = *b->slots[i];
-                if (s.use_fused_dec && s.fdec.n_lv == g.c_in && s.fdec.c == g.c) total_tiles += static_cast<long>(s.fdec.tiles_x) * s.fdec.tiles_y;
+                if (s.use_fused_dec && s.fdec.n_lv == g.c_in && s.fdec.c == g.c && (s.fdec_pre ? 1 : 0) == g.pre && (s.cr ? 1 : 0) == g.cr) total_tiles += static_cast<long>(s.fdec.tiles_x) * s.fdec.tiles_y;
             }
             // ~8 workgroups per CU keep the tail short; a run of tiles amortises the parameter staging
             const int per_wg = static_cast<int>(std::min<long>(8, std::max<long>(1, (total_tiles + 2047) / 2048)));
             for (int i = 0; i < n; ++i) {
                 const Slot& s = *b->slots[i];
-                if (!s.use_fused_dec || s.fdec.n_lv != g.c_in || s.fdec.c != g.c) continue;
+                if (!s.use_fused_dec || s.fdec.n_lv != g.c_in || s.fdec.c != g.c || (s.fdec_pre ? 1 : 0) != g.pre || (s.cr ? 1 : 0) != g.cr) continue;
                 const int f = static_cast<int>(frames.size()) - g.first_frame;
                 frames.push_back(s.fdec);
                 g.lds = std::max(g.lds, s.fdec_lds);
@@ -897,6 +933,30 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
             }
             g.n_work = static_cast<int>(work.size()) - g.first_work;
         }
+    }
+    // pyramid launches of the kFdPre slots: one per number of levels; a workgroup takes a run of tiles of one frame
+    b->pyr_groups.clear();
+    std::vector<FusedDec> pyr_frames;
+    std::vector<Work> pyr_work;
+    for (int lv = 2; lv < kFdMaxLevels; ++lv) {
+        ccd_batch::PyrGroup g{lv, static_cast<int>(pyr_frames.size()), static_cast<int>(pyr_work.size()), 0, fused_pyr_lds_bytes(lv + 1)};
+        long total_tiles = 0;
+        for (int i = 0; i < n; ++i) {
+            const Slot& s = *b->slots[i];
+            if (s.fdec_pre && s.fpyr.n_lv == lv) total_tiles += static_cast<long>(s.fpyr.tiles_x) * s.fpyr.tiles_y;
+        }
+        if (!total_tiles) continue;
+        const int per_wg = static_cast<int>(std::min<long>(8, std::max<long>(1, (total_tiles + 2047) / 2048)));
+        for (int i = 0; i < n; ++i) {
+            const Slot& s = *b->slots[i];
+            if (!s.fdec_pre || s.fpyr.n_lv != lv) continue;
+            const int f = static_cast<int>(pyr_frames.size()) - g.first_frame;
+            pyr_frames.push_back(s.fpyr);
+            const int nt = s.fpyr.tiles_x * s.fpyr.tiles_y;
+            for (int t0 = 0; t0 < nt; t0 += per_wg) pyr_work.push_back({f, t0, std::min(per_wg, nt - t0), 0});
+        }
+        g.n_work = static_cast<int>(pyr_work.size()) - g.first_work;
+        b->pyr_groups.push_back(g);
     }
     // upsampling steps: step k (k-th from the coarsest level) of all slots together
     b->ups_steps.clear();
@@ -928,7 +988,9 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
     const size_t o_work = o_fdec + up256(sizeof(FusedDec) * std::max<size_t>(frames.size(), 1));
     const size_t o_levels = o_work + up256(sizeof(Work) * std::max<size_t>(work.size(), 1));
     const size_t o_zmap = o_levels + up256(sizeof(UpsampleLevel) * std::max<size_t>(levels.size(), 1));
-    const size_t o_stat = o_zmap + up256(sizeof(uint32_t) * std::max<size_t>(zmap.size(), 1));
+    const size_t o_pyr = o_zmap + up256(sizeof(uint32_t) * std::max<size_t>(zmap.size(), 1));
+    const size_t o_pyrw = o_pyr + up256(sizeof(FusedDec) * std::max<size_t>(pyr_frames.size(), 1));
+    const size_t o_stat = o_pyrw + up256(sizeof(Work) * std::max<size_t>(pyr_work.size(), 1));
     const size_t total = o_stat + up256(static_cast<size_t>(std::max(n, 1)) * 64 * sizeof(int32_t));
     // the previous tables may still be read by launches in flight on the caller's stream (a batch that grew between runs)
     if (b->tables.p && b->drain_streams() < 0) return CCD_ERR_HIP;
@@ -943,6 +1005,8 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
     b->d_fdec_work = dev + o_work;
     b->d_levels = reinterpret_cast<UpsampleLevel*>(dev + o_levels);
     b->d_zmap = reinterpret_cast<uint32_t*>(dev + o_zmap);
+    b->d_pyr = reinterpret_cast<FusedDec*>(dev + o_pyr);
+    b->d_pyr_work = dev + o_pyrw;
     b->d_status_all = reinterpret_cast<int32_t*>(dev + o_stat);
     for (int k = 0; k < n; ++k) {
         host[k].status = b->d_status_all + static_cast<size_t>(host_slot[k]) * 64;
@@ -954,6 +1018,8 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
     if (!work.empty()) std::memcpy(stg + o_work, work.data(), sizeof(Work) * work.size());
     if (!levels.empty()) std::memcpy(stg + o_levels, levels.data(), sizeof(UpsampleLevel) * levels.size());
     if (!zmap.empty()) std::memcpy(stg + o_zmap, zmap.data(), sizeof(uint32_t) * zmap.size());
+    if (!pyr_frames.empty()) std::memcpy(stg + o_pyr, pyr_frames.data(), sizeof(FusedDec) * pyr_frames.size());
+    if (!pyr_work.empty()) std::memcpy(stg + o_pyrw, pyr_work.data(), sizeof(Work) * pyr_work.size());
     std::memset(stg + o_stat, 0, total - o_stat);
     HIP_TRY(hipMemcpyAsync(dev, stg, total, hipMemcpyHostToDevice, st));
     b->n_params_uploaded = n;
@@ -1072,15 +1138,22 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
         }
         return CCD_OK;
     }
-    if (stage == 1)
+    if (stage == 1) {
         for (const auto& u : b->ups_steps)
             HIP_TRY(launch_upsample_step(b->d_levels, b->d_zmap + u.first_z, u.n_z, u.max_w, u.max_h, st));
+        for (const auto& g : b->pyr_groups)
+            HIP_TRY(launch_fused_pyramid(b->d_pyr + g.first_frame, static_cast<const char*>(b->d_pyr_work) + static_cast<size_t>(g.first_work) * 16,
+                                         g.n_work, g.levels, g.lds, st));
+    }
     if (stage == 2) {
         for (const auto& g : b->fused_groups)
             HIP_TRY(launch_syn_fused(b->d_fused + g.first, g.n, g.c_in, g.c, g.max_tx, g.max_ty, st));
-        for (const auto& g : b->fdec_groups)
-            HIP_TRY(launch_fused_dec(b->d_fdec + g.first_frame, static_cast<const char*>(b->d_fdec_work) + static_cast<size_t>(g.first_work) * 16,
-                                     g.n_work, g.c_in, g.c, g.lds, st));
+        for (const auto& g : b->fdec_groups) {
+            const FusedDec* fr = b->d_fdec + g.first_frame;
+            const char* wk = static_cast<const char*>(b->d_fdec_work) + static_cast<size_t>(g.first_work) * 16;
+            if (g.cr) HIP_TRY(launch_fused_dec_cr(fr, wk, g.n_work, g.c_in, g.c, g.lds, st));
+            else HIP_TRY(launch_fused_dec(fr, wk, g.n_work, g.c_in, g.c, g.pre, g.lds, st));
+        }
     }
     for (auto& sp : b->slots) {
         rc = (stage == 1) ? run_upsampling(*sp, st) : (stage == 2 ? run_synthesis(*sp, st) : CCD_ERR_ARG);
@@ -1138,7 +1211,7 @@ int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64) {
 int ccd_batch_slot_kernels(const ccd_batch* b, int slot) {
     if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
     const Slot& s = *b->slots[slot];
-    return (s.use_pipe ? 1 : 0) | (s.use_fused_syn ? 2 : 0) | (s.use_fused_dec ? 4 : 0) | (s.use_mfma ? 8 : 0) | (s.use_dyn ? 16 : 0) | (s.fixed_shape ? 32 : 0);
+    return (s.use_pipe ? 1 : 0) | (s.use_fused_syn ? 2 : 0) | (s.use_fused_dec ? 4 : 0) | (s.use_mfma ? 8 : 0) | (s.use_dyn ? 16 : 0) | (s.fixed_shape ? 32 : 0) | (s.fdec_pre ? 64 : 0);
 }
 
 const float* ccd_batch_output(const ccd_batch* b, int slot) {

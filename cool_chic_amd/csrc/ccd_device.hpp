@@ -111,6 +111,11 @@ struct FusedDec {
     float* out;                       // [c][h][w] f32 or null
     void* plane[3];
     int32_t bitdepth, write_planes;
+    // PRE = true instantiations: levels >= 1 evaluated once per frame by the batch's pyramid steps; channels 1 .. n_lv - 1 at the
+    // resolution of level 1, f32 [n_lv - 1][lh[1]][lw[1]] (channel 1 = level 1's own latent through the 7x7 filter first)
+    const float* l1;
+    // common randomness (NZ = n_lv instantiations): the noise planes at full resolution, f32 [n_lv][h][w]
+    const float* noise;
 };
 
 }  // namespace ccd

@@ -152,13 +152,19 @@ int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64);
  * bit 1 = fused synthesis kernel (else one launch per layer), bit 2 = the whole float path (upsampling +
  * synthesis + integer samples) in one kernel, ccd_fused.hip, bit 3 = the ARM's layers evaluated on the matrix cores
  * inside the pipelined entropy kernel (exact limb-split int8, ccd_entropy_pipe.hip), bit 4 = the pipelined kernel's
- * instantiation that checks the IFCE features on the device (networks whose worst-case feature does not fit 16 bits). */
+ * instantiation that checks the IFCE features on the device (networks whose worst-case feature does not fit 16 bits),
+ * bit 5 = the pipelined kernel's instantiation with a compile-time ARM shape (intra/hop.cfg: 14 + 6 inputs, two hidden layers),
+ * bit 6 = the fused float kernel runs behind the batch's pyramid launch (CCD_OPT_FUSED_DEC = 2). */
 int ccd_batch_slot_kernels(const ccd_batch* b, int slot);
 
 /* Batch options, to be set before the slots they concern are added:
- *   CCD_OPT_FUSED_DEC   1 (default): slots whose architecture the fused float kernel covers (every decoder preset of
- *                       the reference, cfg/dec) run it; 0: unfused path (per-level upsampling launches + synthesis
- *                       kernel), which materialises the dense stack ccd_batch_dense() returns.
+ *   CCD_OPT_FUSED_DEC   2 (default): slots whose architecture the fused float kernel covers (every decoder preset of
+ *                       the reference, cfg/dec) run it behind ONE pyramid launch per batch that evaluates the latent
+ *                       levels >= 1 once per frame (stage 1); the fused kernel's tiles load their level-1 footprint and do
+ *                       level 0 + synthesis + integer samples (stage 2).  1: the fused kernel alone, the whole pyramid per
+ *                       tile (one launch, nothing but the int8 latents read; ~20 % slower).  0: unfused path (per-level
+ *                       upsampling launches + synthesis kernel), which materialises the dense stack ccd_batch_dense()
+ *                       returns.  The three produce the same bits.
  *   CCD_OPT_KEEP_FLOAT  1 (default): the f32 synthesis output is always written (ccd_batch_output);
  *                       0: slots that produce integer planes directly (rgb / yuv444 intra frames) write only those.
  *   CCD_OPT_MFMA_ARM    0 (default): the integer ARM on the vector ALU; 1: streams inside the envelope (<= 20 ARM inputs,

@@ -33,18 +33,21 @@ def _decode(gpu, triples, bitdepth, fdt, **opts):
     return b
 
 
-@pytest.mark.parametrize("path", ["production", "mfma", "unfused"])
+@pytest.mark.parametrize("path", ["production", "mfma", "unfused", "fused_tile_pyramid", "fused_behind_pyramid_steps"])
 @pytest.mark.parametrize("name", IMAGE_STREAMS)
 def test_stream_parity(gpu, oracle, name, path):
     """path = "production": the library defaults - the pipelined entropy kernel with the ARM on the vector ALU, upsampling +
-    synthesis + integer samples in one kernel (ccd_fused.hip, every preset architecture); "mfma": the same with the ARM's
+    synthesis + integer samples in the fused kernel (ccd_fused*.hip, every preset architecture); "mfma": the same with the ARM's
     layers on the matrix cores where the stream allows (limb-split int8; the measured, slower alternative); "unfused":
-    per-level upsampling launches + synthesis kernel, which also exposes the dense stack."""
+    per-level upsampling launches + synthesis kernel, which also exposes the dense stack; the two fused variants by name:
+    "fused_tile_pyramid" (CCD_OPT_FUSED_DEC = 1: the whole pyramid per tile, one launch) and "fused_behind_pyramid_steps"
+    (= 2: levels >= 1 once per frame by the batch's pyramid steps, level 0 + synthesis + samples in the fused kernel)."""
     bs, z, j = load_golden(name)
     _, frames = oracle.split_stream(bs)
     fh, ccs = frames[0]
     ref = oracle.decode_coolchic(*ccs[0])
-    opts = {"production": {}, "mfma": {"mfma_arm": 1}, "unfused": {"fused_dec": False, "mfma_arm": 0}}[path]
+    opts = {"production": {}, "mfma": {"mfma_arm": 1}, "unfused": {"fused_dec": False, "mfma_arm": 0},
+            "fused_tile_pyramid": {"fused_dec": 1}, "fused_behind_pyramid_steps": {"fused_dec": 2}}[path]
     b = _decode(gpu, ccs[:1], fh.bitdepth, fh.frame_data_type, **opts)
     try:
         # every network the reference encoder produced runs the pipelined entropy kernel (the generic int64 kernel is the
@@ -57,14 +60,22 @@ def test_stream_parity(gpu, oracle, name, path):
             assert b.slot_stats(0)[37] > 0, "no batch was decoded part by part"
         if path != "mfma":  # networks whose WORST-CASE feature leaves 16 bits run the instantiation that checks features
             assert bool(b.slot_kernels(0) & 16) == (name in ("rgb192", "cr192", "yuv444_10b")), b.slot_kernels(0)
-        if path != "unfused" and name != "cr192":  # common randomness is outside the fused kernel's envelope
+        # common randomness: the noise planes are extra input channels of the fused kernel's instantiations behind the pyramid
+        # launch (CCD_OPT_FUSED_DEC = 2, the default); the one-launch variant (= 1) sends such a stream to the unfused path
+        if path != "unfused" and not (name == "cr192" and path == "fused_tile_pyramid"):
             assert b.slot_kernels(0) & 4, "the fused float kernel must serve this stream"
+        if name == "cr192" and path == "fused_tile_pyramid":
+            assert not b.slot_kernels(0) & 4
         if path == "mfma" and name == "kodim14":
             assert b.slot_kernels(0) & 8, "the ARM of the reference's sample stream must run on the matrix cores"
         if path == "production":
             assert not b.slot_kernels(0) & 8
         if path == "unfused":
             assert not b.slot_kernels(0) & 12
+        if path.startswith("fused_"):
+            assert bool(b.slot_kernels(0) & 64) == (path == "fused_behind_pyramid_steps"), b.slot_kernels(0)
+        if path == "production":
+            assert b.slot_kernels(0) & 64, "default: the fused kernel behind the pyramid launch"
         # integer stage: every latent grid bit-exact with the oracle AND the reference fixture
         for g in range(ref["n_grids"]):
             got = b.latent(0, g)

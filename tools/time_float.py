@@ -20,8 +20,10 @@ def main():
     sh = stream.cuda_stream
     for copies in copies_list:
         px = copies * sum(h * w for *_, (h, w) in items)
-        for label, opts in (("fused, planes only", dict(fused_dec=True, keep_float=False)),
-                            ("fused, planes + f32", dict(fused_dec=True, keep_float=True)),
+        for label, opts in (("fused, planes only", dict(fused_dec=1, keep_float=False)),
+                            ("fused, planes + f32", dict(fused_dec=1, keep_float=True)),
+                            ("pre+fused, planes only", dict(fused_dec=2, keep_float=False)),
+                            ("pre+fused, planes+f32", dict(fused_dec=2, keep_float=True)),
                             ("unfused (r01 path)", dict(fused_dec=False))):
             b = DecodeBatch(0, **opts)
             for _ in range(copies):
@@ -31,7 +33,7 @@ def main():
             b.wait(sh)
             reps = 20
             res = {}
-            for stages in ((1, 2),):
+            for stages in ((1, 2), (1,), (2,)):
                 for _ in range(3):
                     for st in stages:
                         b.run(sh, stage=st)
@@ -45,9 +47,10 @@ def main():
                 torch.cuda.synchronize(0)
                 res[stages] = e0.elapsed_time(e1) / reps
             ms = res[(1, 2)]
+            split = f"   [stage 1 alone {res[(1,)]:.4f} ms, stage 2 alone {res[(2,)]:.4f} ms]"
             flop = 1724.0 * px  # algorithmic: synthesis 2 x 672 + upsampling ~380 flop / px
             print(f"{copies * len(items):4d} frames  {label:22s} {ms:8.4f} ms  {px / ms / 1e3:9.1f} Mpx/s  {flop / ms / 1e9:7.1f} TFLOP/s algorithmic"
-                  f"  ({flop / ms / 1e9 / 157.3 * 100:5.1f} % of fp32 peak)", flush=True)
+                  f"  ({flop / ms / 1e9 / 157.3 * 100:5.1f} % of fp32 peak)" + split, flush=True)
             if opts.get("fused_dec"):
                 import ctypes as C
                 import numpy as np
