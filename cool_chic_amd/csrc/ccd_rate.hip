@@ -61,6 +61,7 @@ __device__ __forceinline__ float symbol_rate(float xi, float m, float s) {
 // (global_load_dwordx4 / global_store_dwordx4: one wave = 1 KB contiguous per array), two iterations' loads in flight
 // (8 symbols per lane) before the first use; the grid is a few workgroups per CU and strides over the arrays.
 // `n4` = number of whole 4-symbol groups; the (< 4) symbols behind them and unaligned arrays take rate_tail_kernel.
+template <bool TOTAL>
 __global__ __launch_bounds__(256) void rate_kernel_v4(const float* x_, const float* mu_, const float* scale_, float* rate_, double* total,
                                                       int64_t n4) {
     __shared__ double s_part[4];
@@ -75,19 +76,22 @@ __global__ __launch_bounds__(256) void rate_kernel_v4(const float* x_, const flo
         v4f ra, rb;
 #pragma unroll
         for (int k = 0; k < 4; ++k) { ra[k] = symbol_rate(xa[k], ma[k], sa[k]); rb[k] = symbol_rate(xb[k], mb[k], sb[k]); }
-        if (rate) { rate[i] = ra; rate[i + stride] = rb; }
-        acc += static_cast<double>(ra[0]) + static_cast<double>(ra[1]) + static_cast<double>(ra[2]) + static_cast<double>(ra[3]);
-        acc += static_cast<double>(rb[0]) + static_cast<double>(rb[1]) + static_cast<double>(rb[2]) + static_cast<double>(rb[3]);
+        // (streaming stores: the output is not read again by this kernel, it should not displace the inputs' lines)
+        if (rate) { __builtin_nontemporal_store(ra, &rate[i]); __builtin_nontemporal_store(rb, &rate[i + stride]); }
+        if constexpr (TOTAL) {
+            acc += static_cast<double>(ra[0]) + static_cast<double>(ra[1]) + static_cast<double>(ra[2]) + static_cast<double>(ra[3]);
+            acc += static_cast<double>(rb[0]) + static_cast<double>(rb[1]) + static_cast<double>(rb[2]) + static_cast<double>(rb[3]);
+        }
     }
     if (i < n4) {
         const v4f xa = x[i], ma = mu[i], sa = scale[i];
         v4f ra;
 #pragma unroll
         for (int k = 0; k < 4; ++k) ra[k] = symbol_rate(xa[k], ma[k], sa[k]);
-        if (rate) rate[i] = ra;
-        acc += static_cast<double>(ra[0]) + static_cast<double>(ra[1]) + static_cast<double>(ra[2]) + static_cast<double>(ra[3]);
+        if (rate) __builtin_nontemporal_store(ra, &rate[i]);
+        if constexpr (TOTAL) acc += static_cast<double>(ra[0]) + static_cast<double>(ra[1]) + static_cast<double>(ra[2]) + static_cast<double>(ra[3]);
     }
-    if (!total) return;
+    if (!TOTAL || !total) return;
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
     if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -129,7 +133,8 @@ extern "C" int ccd_compute_rate(int device, void* stream, const float* x, const 
         // 8 workgroups of 256 per CU (2048 of them) cover the chip; two 16-byte groups per lane and iteration
         const int64_t want = (n4 + 511) / 512;
         const unsigned blocks = static_cast<unsigned>(want < 2048 ? want : 2048);
-        hipLaunchKernelGGL(rate_kernel_v4, dim3(blocks), dim3(256), 0, st, x, mu, scale, rate, total_bits, n4);
+        if (total_bits) hipLaunchKernelGGL(rate_kernel_v4<true>, dim3(blocks), dim3(256), 0, st, x, mu, scale, rate, total_bits, n4);
+        else hipLaunchKernelGGL(rate_kernel_v4<false>, dim3(blocks), dim3(256), 0, st, x, mu, scale, rate, total_bits, n4);
     }
     if (4 * n4 < n) {
         const int64_t rest = n - 4 * n4;

@@ -1,21 +1,21 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): rocprofv3 summaries of the bench command, for the metric's workload (kodak24) and for the
-# chip-filling one (kodak24 x 8 = 192 frames in one batch: bench.py --scaling strong on one GPU).
+# chip-filling one (256 streams in one batch: bench.py --scaling throughput on one GPU), and for the rate model (tools/prof_rate.py).
 # clic41 / uhd4k (legs of bench.py) run through tools/prof_workload.py so that their kernels do not mix with kodak24's.
 #   pass 1: kernel trace + stats          -> gpurun_out/prof/<tag>/stats
 #   pass 2: PMC FETCH_SIZE (own run)      -> gpurun_out/prof/<tag>/fetch
 #   pass 3: PMC WRITE_SIZE (own run)      -> gpurun_out/prof/<tag>/write
 # (counters are never combined with sys/hip/hsa traces; see MI355X_MICROARCH.md, rocprofv3 PMC slots)
-# Afterwards (here or in the build container):  python tools/summarise_pmc.py gpurun_out/prof/<tag> profiles/r03 <tag>
+# Afterwards (here or in the build container):  python tools/summarise_pmc.py gpurun_out/prof/<tag> profiles/r04 <tag>
 set -u
 REPO=$(pwd)
 export TMPDIR=/tmp
-for TAG in kodak24 kodak192 clic41 uhd4k; do
+for TAG in kodak24 kodak256 clic41 uhd4k rate; do
   OUT=$REPO/gpurun_out/prof/$TAG
   rm -rf "$OUT"; mkdir -p "$OUT"
-  EXTRA=""; [ "$TAG" = kodak192 ] && EXTRA="--scaling strong"
+  EXTRA=""; [ "$TAG" = kodak256 ] && EXTRA="--scaling throughput"
   CMD="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --legs none $EXTRA"
-  case "$TAG" in clic41|uhd4k) CMD="python $REPO/tools/prof_workload.py $TAG 3";; esac
+  case "$TAG" in clic41|uhd4k) CMD="python $REPO/tools/prof_workload.py $TAG 3";; rate) CMD="python $REPO/tools/prof_rate.py";; esac
   cd /tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/bench_stats.log" 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/bench_fetch.log" 2>&1

@@ -18,7 +18,8 @@ KERNELS = {  # short name -> (substring of the kernel name, launches per bench s
     "entropy_pipe_kernel": ("entropy_pipe_kernel", None),
     "upsample_step_kernel": ("upsample_step_kernel", 6),
     "syn_fused_kernel": ("syn_fused_kernel", None),
-    "decode_fused_kernel": ("decode_fused_kernel", None),
+    "decode_fused_kernel": ("decode_fused_kernel", None),   # every instantiation of a step (pyramid launch + tiles): summed
+    "rate_kernel_v4": ("rate_kernel_v4", None),
     "png_filter_huff_kernel": ("png_filter_huff_kernel", None),
     "png_emit_kernel": ("png_emit_kernel", None),
     "png_crc_kernel": ("png_crc_kernel", None),
@@ -37,7 +38,7 @@ def read(dir_, counter):
 
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-    dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03"
+    dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r04"
     tag = sys.argv[3] if len(sys.argv) > 3 else "kodak24"
     fetch, write = read(os.path.join(src, "fetch"), "FETCH_SIZE"), read(os.path.join(src, "write"), "WRITE_SIZE")
     out = {}
@@ -45,19 +46,28 @@ def main():
         names = [n for n in fetch if sub in n]
         if not names:
             continue
-        name = names[0]
-        f, w = fetch[name][1:] or fetch[name], write.get(name, [0.0])[1:] or write.get(name, [0.0])
-        e = {"full_name": name, "launches": len(f)}
+        # one entry per short name: the mean over the launches of every kernel whose name holds `sub` (first launch dropped),
+        # summed over those kernels (the fused float path is two launches per step: the pyramid launch and the tiles)
+        e = {"full_names": names, "launches": 0}
+        tot_f = tot_w = 0.0
+        for name in names:
+            f, w = fetch[name][1:] or fetch[name], write.get(name, [0.0])[1:] or write.get(name, [0.0])
+            e["launches"] += len(f)
+            tot_f += sum(f) / len(f)
+            tot_w += sum(w) / len(w)
+            if len(names) > 1:
+                e.setdefault("per_kernel", {})[name[:120]] = {"fetch_bytes": sum(f) / len(f), "write_bytes": sum(w) / len(w)}
         if per_step:
             e["launches_per_step"] = per_step
-            e["fetch_bytes_per_step"] = sum(f) / len(f) * per_step
-            e["write_bytes_per_step"] = sum(w) / len(w) * per_step
+            e["fetch_bytes_per_step"] = tot_f * per_step
+            e["write_bytes_per_step"] = tot_w * per_step
         else:
-            e["fetch_bytes"] = sum(f) / len(f)
-            e["write_bytes"] = sum(w) / len(w)
+            e["fetch_bytes"] = tot_f
+            e["write_bytes"] = tot_w
         out[short] = e
     cmd = {"kodak24": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --legs none",
-           "kodak192": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --legs none --scaling strong"}.get(tag, f"python tools/prof_workload.py {tag} 3")
+           "kodak256": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --legs none --scaling throughput",
+           "rate": "python tools/prof_rate.py"}.get(tag, f"python tools/prof_workload.py {tag} 3")
     doc = {
         "command": cmd + " (tools/collect_profiles.sh; one rocprofv3 run per counter)",
         "unit": "bytes per launch: rocprofv3 FETCH_SIZE x 1024 x 2, WRITE_SIZE x 1024 x 1",
