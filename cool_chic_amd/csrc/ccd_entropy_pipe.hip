@@ -234,6 +234,13 @@ template <int DIM, int NL, int NSP>
 struct ShapeFix { static constexpr bool fixed = true; static constexpr int dim = DIM, n_layers = NL, n_sp = NSP; };
 using ShapeHop = ShapeFix<20, 3, 14>;
 
+// The IFCE features of one position of the previous grid sit NEXT to each other in the int16 scratch (stride = features rounded up
+// to a power of two: 16 bytes for the usual six): a task's feature reads touch one cache line per pixel instead of one per
+// pixel and feature, and eight neighbouring positions (eight wavefront steps) share that line.  r03 kept one plane per feature:
+// 6 x 52 lines per step of a Kodak grid 0 = 40 KB through a 16 KB L1, i.e. every read an L2 round trip, and 5.9 x the algorithmic
+// HBM traffic.  (The int32 side plane of the dynamic operand check stays planar: it is never read on real streams.)
+__host__ __device__ constexpr int feat_stride(int n_if) { int s = 1; while (s < n_if) s *= 2; return s; }
+
 struct PipeCtx {
     const EntropyParams* P;
     LdsRef<uint2> s_tab;          // [kRows][64] (L, P)
@@ -254,6 +261,7 @@ struct PipeCtx {
     int ring_mask;         // ring rows - 1
     // per grid
     int H, W, fin, fh, fw;
+    int fstride;           // feat_stride(n_if)
     int task_pix;          // pixels per producer task in this grid (8, 4 or 2)
     int k_left;            // index of the context (y, x - 1) among the spatial contexts, -1 if the mask has none
     int8_t* lat;
@@ -1170,7 +1178,7 @@ __device__ __forceinline__ void mf_exact_task(const PipeCtx& C, int32_t* tile, i
             const int yy = y - P.ctx_dy[k], xx = x + P.ctx_dx[k];
             if (yy >= 0 && xx >= 0 && xx < W) v = C.s_ring[(yy & ring_mask) * 64 + ((xx + 10 * yy) & 63)];
         } else if (fin > 0) {
-            v = reinterpret_cast<const int16_t*>(P.ifce_feat)[(k - n_sp) * feat_plane + (y >> 1) * fw + (x >> 1)];
+            v = reinterpret_cast<const int16_t*>(P.ifce_feat)[((y >> 1) * fw + (x >> 1)) * C.fstride + (k - n_sp)];
         }
         ain[k] = v << 16;
     }
@@ -1226,7 +1234,7 @@ struct ExactArgs {
     const EntropyParams* P;
     uint32_t s_w, s_b, s_ring;  // LDS byte offsets
     int n_w_hidden, dim, n_layers, n_sp, in_pad;
-    int W, fin, fw, feat_plane, ring_mask;
+    int W, fin, fw, feat_plane, ring_mask, fstride;
 };
 struct ExactOut { int64_t mu, ls; };
 __device__ __forceinline__ ExactOut exact_pixel(const ExactArgs& A, int y, int x) {
@@ -1243,10 +1251,10 @@ __device__ __forceinline__ ExactOut exact_pixel(const ExactArgs& A, int y, int x
             const int yy = y - P.ctx_dy[lane], xx = x + P.ctx_dx[lane];
             if (yy >= 0 && xx >= 0 && xx < A.W) v = s_ring[(yy & A.ring_mask) * 64 + ((xx + 10 * yy) & 63)];
         } else if (A.fin > 0) {
-            const int fo = (lane - n_sp) * A.feat_plane + (y >> 1) * A.fw + (x >> 1);
-            v = reinterpret_cast<const int16_t*>(P.ifce_feat)[fo];
-            // side plane: the raw Q8 sum; the reference sends it through float32 and back (coolchic.py:142-144)
-            if (v == kFeatSentinel) v = static_cast<int64_t>(static_cast<float>(P.ifce_wide[fo]));
+            const int pos = (y >> 1) * A.fw + (x >> 1);
+            v = reinterpret_cast<const int16_t*>(P.ifce_feat)[pos * A.fstride + (lane - n_sp)];
+            // side plane (planar): the raw Q8 sum; the reference sends it through float32 and back (coolchic.py:142-144)
+            if (v == kFeatSentinel) v = static_cast<int64_t>(static_cast<float>(P.ifce_wide[(lane - n_sp) * A.feat_plane + pos]));
         }
         xin = static_cast<uint64_t>(v) << 16;  // armint.py:193
     }
@@ -1331,6 +1339,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
     // this kernel keeps the features as int16 (|feature| < 2^15 under `narrow`): half the scratch traffic of the int32 planes
     const glb_ptr<const int16_t> ifce_feat = (glb_ptr<const int16_t>)reinterpret_cast<const int16_t*>(P.ifce_feat);
     const int feat_plane = uni(C.fh) * fw;
+    const int fstride = SH::fixed ? feat_stride(SH::dim - SH::n_sp) : uni(C.fstride);
     // MF: the lane's context offsets (k = q + 4 t, dy << 16 | dx) and the left neighbour's weights of the lane's rows
     // (neurons 4 q .. 4 q + 3 and 16 + q, then the two stabiliser outputs)
     int32_t mf_dxy[8], mf_wl[7];
@@ -1379,26 +1388,29 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                 const int i0 = static_cast<int>(task << kTaskShift);   // first pixel of the task within the step
                 const int cnt = min(kTaskPix, static_cast<int>(it.n) - i0);
                 const int y = static_cast<int>(it.y0) + i0 + px, x = static_cast<int>(it.x0) - 10 * (i0 + px);
-                // ---- IFCE features do not depend on this grid: fetch them before waiting on the decoder -------
-                int32_t fv[NOUT];
-#pragma unroll
-                for (int t = 0; t < NOUT; ++t) fv[t] = 0;
-                if (!MF && fin > 0) {  // (wave-uniform) every lane loads: a lane without a feature reads the plane's first sample and drops it
+                // ---- IFCE features do not depend on this grid: REQUEST them before waiting on the decoder, use them in the gather.
+                // (r04: the selects stood right behind the loads, so every task began with s_waitcnt vmcnt(0) - an L2 round trip of
+                // ~700 ticks on the path between two tasks.  The raw values now stay untouched until the gather, behind the early
+                // wait and the tail stores.)
+                uint32_t f_raw[NOUT];  // the 16 bits as loaded (sign-extended at the gather: any operation on them is a wait)
+                bool f_has[NOUT];
+                if constexpr (!MF) {
+                    // every lane loads, whatever the grid (no branch: at a join the compiler finishes the selects, i.e. waits): a lane
+                    // without a feature - or a grid without IFCE - reads the plane's first sample and drops it
                     const int fo = (y >> 1) * fw + (x >> 1);
 #pragma unroll
                     for (int t = 0; t < NOUT; ++t) {
                         const int k = q + kLpp * t;
-                        const bool has = px < cnt && k >= n_sp && k < dim;
-                        const int32_t f = ifce_feat[has ? (k - n_sp) * feat_plane + fo : 0];
-                        fv[t] = has ? f : 0;
+                        f_has[t] = fin > 0 && px < cnt && k >= n_sp && k < dim;
+                        f_raw[t] = reinterpret_cast<glb_ptr<const uint16_t>>(ifce_feat)[f_has[t] ? fo * fstride + (k - n_sp) : 0];
                     }
-                }
-                // dynamic operand check (see exact_pixel): a sentinel among the task's features.  Known BEFORE the waits, so the
-                // critical path only carries one scalar test of this mask.
-                bool feat_bad = false;
+                } else {
 #pragma unroll
-                for (int t = 0; t < NOUT; ++t) feat_bad |= DYN && fv[t] == kFeatSentinel;
-                const unsigned long long bad_lanes = (MF || !DYN) ? 0ull : __ballot(feat_bad);
+                    for (int t = 0; t < NOUT; ++t) { f_raw[t] = 0; f_has[t] = false; }
+                }
+                // dynamic operand check (see exact_pixel): a sentinel among the task's features - known at the gather, BEFORE the late
+                // wait, so the critical path only carries one scalar test of this mask.
+                unsigned long long bad_lanes = 0ull;
                 // ---- Two waits.  Of all contexts only the left neighbour (y, x - 1) lies in the previous step (pixel i of this
                 // step reads pixel i of that one, pixel i + 1 when the step start moved down a row in between); (y, x - 2) lies
                 // two steps back, everything else at least five.  So the task gathers every other input, runs the stabiliser and
@@ -1422,8 +1434,8 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                     int32_t f0 = 0, f1 = 0;
                     if (live && fin > 0) {
                         const int fo = (y >> 1) * fw + (x >> 1);
-                        if (g < n_if) f0 = ifce_feat[g * feat_plane + fo];
-                        if (g + 4 < n_if) f1 = ifce_feat[(g + 4) * feat_plane + fo];
+                        if (g < n_if) f0 = ifce_feat[fo * fstride + g];
+                        if (g + 4 < n_if) f1 = ifce_feat[fo * fstride + g + 4];
                     }
                     lt_a = LPROF_T(pw == 0);
 #if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
@@ -1633,6 +1645,15 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
 #pragma unroll
                         for (int t = 0; t < NOUT; ++t) asm volatile("" : "+v"(rr[t]));
                     }
+                    int32_t fv[NOUT];
+                    bool feat_bad = false;
+#pragma unroll
+                    for (int t = 0; t < NOUT; ++t) {
+                        asm volatile("" : "+v"(f_raw[t]));  // (first use of the loaded value: here, not at the load)
+                        fv[t] = f_has[t] ? static_cast<int32_t>(static_cast<int16_t>(f_raw[t])) : 0;
+                        feat_bad |= DYN && fv[t] == kFeatSentinel;
+                    }
+                    if constexpr (DYN) bad_lanes = __ballot(feat_bad);
 #pragma unroll
                     for (int t = 0; t < NOUT; ++t) {
                         const int k = q + kLpp * t;
@@ -1815,9 +1836,9 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                         ExactArgs A;
                         A.P = C.P; A.s_w = uni(C.s_w.off); A.s_b = uni(C.s_b.off); A.s_ring = uni(C.s_ring.off);
                         A.n_w_hidden = uni(C.n_w_hidden); A.dim = dim; A.n_layers = n_layers; A.n_sp = n_sp; A.in_pad = in_pad;
-                        A.W = W; A.fin = fin; A.fw = fw; A.feat_plane = feat_plane; A.ring_mask = ring_mask;
+                        A.W = W; A.fin = fin; A.fw = fw; A.feat_plane = feat_plane; A.ring_mask = ring_mask; A.fstride = fstride;
                         asm volatile("" : "+s"(A.P), "+s"(A.s_w), "+s"(A.s_b), "+s"(A.s_ring), "+s"(A.n_w_hidden), "+s"(A.dim), "+s"(A.n_layers));
-                        asm volatile("" : "+s"(A.n_sp), "+s"(A.W), "+s"(A.fin), "+s"(A.fw), "+s"(A.feat_plane), "+s"(A.ring_mask));
+                        asm volatile("" : "+s"(A.n_sp), "+s"(A.W), "+s"(A.fin), "+s"(A.fw), "+s"(A.feat_plane), "+s"(A.ring_mask), "+s"(A.fstride));
                         const ExactOut r = exact_pixel(A, static_cast<int>(it.y0) + i0 + p, static_cast<int>(it.x0) - 10 * (i0 + p));
                         if (px == p && q < 2) {
                             const int64_t off = ((q == 0 ? r.mu : r.ls) >> 24) + (q == 0 ? kMuOffset : kScaleOffset);
@@ -2007,6 +2028,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     for (int i = tid; i < kNumScale; i += kPipeThreads) s_rcp[i] = P.rcp_table[i];
     for (int i = tid; i < kExpN; i += kPipeThreads) s_exp[i] = kExpTab[i];
     C.dim = dim; C.n_layers = n_layers; C.n_sp = P.n_spatial; C.n_if = n_if;
+    C.fstride = feat_stride(n_if);
     C.k_left = -1;
     for (int k = 0; k < P.n_spatial; ++k) if (P.ctx_dy[k] == 0 && P.ctx_dx[k] == -1) C.k_left = k;
 
@@ -2118,6 +2140,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                 const glb_ptr<int16_t> featg = (glb_ptr<int16_t>)feat;
                 const glb_ptr<int32_t> wideg = (glb_ptr<int32_t>)P.ifce_wide;
                 const int plane = fh * fw;
+                const int fstride_g = C.fstride;
                 // source descriptors: wave-uniform, read from LDS once (inside the loop each costs an LDS round trip per position)
                 glb_ptr<const int8_t> srcp[kIfceFastIn];
                 int gwr[kIfceFastIn], shr[kIfceFastIn];
@@ -2164,9 +2187,8 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                         // 32-bit tests: q8 = acc >> 24 lies in [-2^b, 2^b) iff the bits of acc from 24 + b up are all equal.
                         const int32_t hi = static_cast<int32_t>(acc[j] >> 32), q32 = static_cast<int32_t>(acc[j] >> 24);
                         const bool big = static_cast<uint32_t>((hi >> feat_hi_shift) + 1) > 1u || (q32 & 0xffff) == 0x8000;
-                        const int fo = min(j, n_if - 1) * plane + p;
-                        if (j < n_if_lane) featg[fo] = (DYN && big) ? kFeatSentinel : static_cast<int16_t>(q32);
-                        if (DYN && j < n_if_lane && big) wideg[fo] = q32;
+                        if (j < n_if_lane) featg[p * fstride_g + min(j, n_if - 1)] = (DYN && big) ? kFeatSentinel : static_cast<int16_t>(q32);
+                        if (DYN && j < n_if_lane && big) wideg[min(j, n_if - 1) * plane + p] = q32;
                     }
                 }
             } else
@@ -2190,7 +2212,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                         if (o0 + j < n_if) {
                             const int64_t q8 = static_cast<int64_t>(acc[j]) >> 24;
                             const bool big = static_cast<uint64_t>(q8 + feat_lim - 1) >= static_cast<uint64_t>(2 * feat_lim - 1);
-                            feat[(o0 + j) * fh * fw + p] = (DYN && big) ? kFeatSentinel : static_cast<int16_t>(q8);
+                            feat[p * C.fstride + (o0 + j)] = (DYN && big) ? kFeatSentinel : static_cast<int16_t>(q8);
                             if (DYN && big) P.ifce_wide[(o0 + j) * fh * fw + p] = static_cast<int32_t>(q8);
                         }
                     }
