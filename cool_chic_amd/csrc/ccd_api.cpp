@@ -78,7 +78,7 @@ namespace {
 // per image set, and hipMalloc / hipFree / hipHostMalloc of its arenas were a fifth of the time from bytes to planes
 // (24 hipFree = 4.4 ms per Kodak set; 64 arenas of 50-100 MB per 1080p GOP).  Blocks are handed out in size classes
 // (power of two up to 1 MB, then eighths of a power of two: <= 12.5 % slack) and come back on destroy; the cache is capped
-// (CCD_POOL_MAX_MB, default 8192; CCD_PINNED_POOL_MAX_MB, default 2048: the cache is invisible to PyTorch's allocator, so it
+// (CCD_POOL_MAX_MB, default 16384; CCD_PINNED_POOL_MAX_MB, default 2048: the cache is invisible to PyTorch's allocator, so it
 // stays a few percent of the device) - beyond the cap a block is really freed.
 // ccd_pool_trim() empties the caches.  The current device must be the block's device (callers hipSetDevice first).
 class BlockPool {
@@ -142,7 +142,7 @@ public:
 private:
     static int key(int device, Kind kind) { return device * 2 + kind; }
     static size_t cap(Kind kind) {
-        static const size_t caps[2] = {env_mb("CCD_POOL_MAX_MB", 8192), env_mb("CCD_PINNED_POOL_MAX_MB", 2048)};
+        static const size_t caps[2] = {env_mb("CCD_POOL_MAX_MB", 16384), env_mb("CCD_PINNED_POOL_MAX_MB", 2048)};
         return caps[kind];
     }
     static size_t env_mb(const char* name, size_t dflt) {

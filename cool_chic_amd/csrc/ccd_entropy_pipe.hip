@@ -234,12 +234,13 @@ template <int DIM, int NL, int NSP>
 struct ShapeFix { static constexpr bool fixed = true; static constexpr int dim = DIM, n_layers = NL, n_sp = NSP; };
 using ShapeHop = ShapeFix<20, 3, 14>;
 
-// The IFCE features of one position of the previous grid sit NEXT to each other in the int16 scratch (stride = features rounded up
-// to a power of two: 16 bytes for the usual six): a task's feature reads touch one cache line per pixel instead of one per
-// pixel and feature, and eight neighbouring positions (eight wavefront steps) share that line.  r03 kept one plane per feature:
-// 6 x 52 lines per step of a Kodak grid 0 = 40 KB through a 16 KB L1, i.e. every read an L2 round trip, and 5.9 x the algorithmic
-// HBM traffic.  (The int32 side plane of the dynamic operand check stays planar: it is never read on real streams.)
-__host__ __device__ constexpr int feat_stride(int n_if) { int s = 1; while (s < n_if) s *= 2; return s; }
+// The IFCE features of one position of the previous grid sit NEXT to each other in the int16 scratch (position-major, stride =
+// the number of features: 12 bytes for the usual six): a task's feature reads touch one cache line per pixel instead of one per
+// pixel and feature, and ten neighbouring positions (ten wavefront steps) share that line.  r03 kept one plane per feature:
+// 6 x 52 lines per step of a Kodak grid 0 = 40 KB through a 16 KB L1, every read an L2 round trip.  Same bytes written either
+// way (a power-of-two stride was tried: + 27 % HBM traffic for nothing).  The int32 side plane of the dynamic operand check stays
+// planar: it is never read on real streams.
+__host__ __device__ constexpr int feat_stride(int n_if) { return n_if > 0 ? n_if : 1; }
 
 struct PipeCtx {
     const EntropyParams* P;

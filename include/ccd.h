@@ -203,7 +203,7 @@ int ccd_batch_planes_layout(const ccd_batch* b, int slot, size_t* total_bytes, s
 int ccd_batch_copy_planes_async(ccd_batch* b, int first_slot, int n_slots, void* const* host_blocks, void* stream);
 /* Device and pinned-host blocks of destroyed batches are cached per device for the next batch (a batch per image set is the
  * normal use); this returns them to the runtime.  The environment variables CCD_POOL_MAX_MB / CCD_PINNED_POOL_MAX_MB cap the
- * caches (defaults 8192 / 2048 MB: the cache is invisible to other allocators of the process, e.g. PyTorch's; a block beyond
+ * caches (defaults 16384 / 2048 MB = 5.5 % of the device: the cache is invisible to other allocators of the process, e.g. PyTorch's; a block beyond
  * the cap is freed at once, and an allocation that fails trims the cache and retries).
  *
  * Threading and global state.  Per device and for the life of the process the library keeps: that block cache, the two
