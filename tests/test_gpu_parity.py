@@ -1068,3 +1068,82 @@ def test_pooled_blocks_are_recycled_and_results_stay_exact(gpu, oracle):
     finally:
         b.close()
     lib().ccd_pool_trim(0)
+
+
+def test_two_host_threads_two_batches_one_gpu(gpu, oracle):
+    """Different batches may be driven by different host threads on one GPU (include/ccd.h, "Threading and global state"): the
+    fork / join events of the entropy launches belong to the batch (r03 kept one set per device, so that thread A's side stream
+    could wait on thread B's record).  Two threads, each on its own torch stream, run batches that need SEVERAL kernel
+    instantiations (streams with 8, 14, 20 and 26 ARM inputs: the launches fork over the shared side streams) 12 times each,
+    create / add / run / all_planes / destroy; every result must hash to the single-threaded one."""
+    import hashlib
+    import threading
+
+    import torch
+
+    names = ["rgb192", "mop192", "vhop192", "yuv444_10b", "kodim14"]
+    triples = []
+    for n in names:
+        bs, _, _ = load_golden(n)
+        fh, ccs = oracle.split_stream(bs)[1][0]
+        triples.append((ccs[0], fh.bitdepth, fh.frame_data_type))
+
+    def run_once(stream_handle):
+        b = gpu(0)
+        try:
+            for (hdr, nn, lat), bd, fdt in triples:
+                b.add(hdr, nn, lat, bd, fdt)
+            b.run(stream_handle)
+            planes = b.all_planes(stream_handle)
+            h = hashlib.sha256()
+            for fr in planes:
+                for p in fr:
+                    h.update(np.ascontiguousarray(p).tobytes())
+            return h.hexdigest()
+        finally:
+            b.close()
+
+    want = run_once(0)
+    results, errors = {0: [], 1: []}, []
+
+    def worker(k):
+        try:
+            st = torch.cuda.Stream(device=0)
+            with torch.cuda.stream(st):
+                for _ in range(12):
+                    results[k].append(run_once(st.cuda_stream))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(len(v) == 12 for v in results.values())
+    assert all(x == want for v in results.values() for x in v), "a concurrent batch decoded differently"
+
+
+def test_pool_trim_returns_the_cache(gpu, oracle):
+    """cool_chic_amd.pool_trim (ccd_pool_trim): the blocks destroyed batches left in the per-device cache go back to the runtime -
+    free device memory grows by about what the batches used - and decoding afterwards still works."""
+    import torch
+
+    import cool_chic_amd
+
+    bs, z, _ = load_golden("kodim14")
+    fh, ccs = oracle.split_stream(bs)[1][0]
+    for _ in range(2):
+        b = _decode(gpu, [ccs[0]] * 8, fh.bitdepth, fh.frame_data_type)
+        b.close()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    cool_chic_amd.pool_trim(0)
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free1 - free0 > 30 * 2 ** 20, (free0, free1)  # eight Kodak arenas of ~10 MB
+    b = _decode(gpu, ccs[:1], fh.bitdepth, fh.frame_data_type)
+    try:
+        assert np.array_equal(b.latent(0, 0), z["cc0.latent0"])
+    finally:
+        b.close()
