@@ -1751,6 +1751,10 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                     xleft = (px < cnt && x >= 1) ? r << 16 : 0;
                 }
                 lt_d = LPROF_T(pw == 0);
+                // the late path is on the chain "symbol decoded -> table ready": it goes ahead of a SIMD neighbour's early work (the
+                // decoder runs at priority 3).  41.03 -> 40.84 ms on kodak24 (profiles/r04/ab_entropy_late_prio.txt)
+                // (priority 2 for the first task of a step, the head of its chain: no further gain)
+                __builtin_amdgcn_s_setprio(1);
                 mad64(so[0], xleft, wleft_stab);
                 const int64_t stab = so[0] + so[1];
                 if (n_layers >= 2) {
@@ -1974,6 +1978,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                 // decoder (a release would first wait for every outstanding LDS and global access of the wave)
                 asm volatile("" ::: "memory");
                 if (lane == 0) __hip_atomic_fetch_or(&C.s_ready[slot], 1u << half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __builtin_amdgcn_s_setprio(0);
                 asm volatile("" ::: "memory");
                 PROF_ADD(prof[3], t_t);
 #if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
