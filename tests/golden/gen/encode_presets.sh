@@ -7,6 +7,8 @@
 #   tests/golden/gen/encode_presets.sh <name> <input under /root/reference/test/data> <n_frames> <intra cfg> [<residue cfg> <motion cfg>]
 set -e
 NAME=$1; IN=$2; NF=$3; INTRA=$4; RES=${5:-lop}; MOT=${6:-lop}
+# <input>: a file name under /root/reference/test/data, or an absolute path (crops of the reference's test picture made by the caller)
+case "$IN" in /*) INP=$IN;; *) INP=/root/reference/test/data/$IN;; esac
 HERE=$(cd "$(dirname "$0")" && pwd)
 export PYTHONDONTWRITEBYTECODE=1
 export PYTHONPATH=$HERE/shims:/root/reference
@@ -17,7 +19,7 @@ PPOS=""
 if [ "$NF" -gt 1 ]; then PPOS="--p_pos=-1"; fi
 for ((k = 0; k < NF; k++)); do
     if [ $k -eq 0 ]; then R=/root/reference/cfg/dec/intra/$INTRA.cfg; else R=/root/reference/cfg/dec/residue/$RES.cfg; fi
-    python3 cc_encode.py --input=/root/reference/test/data/$IN --workdir=$W/ --intra_pos=0 $PPOS --n_frames=$NF \
+    python3 cc_encode.py --input=$INP --workdir=$W/ --intra_pos=0 $PPOS --n_frames=$NF \
         --output=$W/$NAME.cool --coding_idx=$k --debug \
         --dec_cfg_residue=$R --dec_cfg_motion=/root/reference/cfg/dec/motion/$MOT.cfg > $W/enc$k.log 2>&1
 done

@@ -28,7 +28,9 @@ def test_integer_stages_bit_exact(oracle, name):
     assert np.array_equal(r["arm_bs"], z["cc0.fp.arm.bs"])
     for g in range(r["n_grids"]):
         assert np.array_equal(r["latent"][g], z[f"cc0.latent{g}"]), f"latent grid {g}"
-        head = z[f"cc0.mu_scale_idx{g}.head"]
+        # the fixture holds the indices as the ARM produced them; RangeCoder.decode clips them into the tables
+        # (`take(..., mode="clip")`, rangecoder.py:98-99: odd18x65 has a log-scale index of -128), the oracle reports them clipped
+        head = np.clip(z[f"cc0.mu_scale_idx{g}.head"], 0, [32767, 2560])
         assert np.array_equal(r["mu_scale_idx"][g][: len(head)], head), f"(mu, scale) indices grid {g}"
         key = f"cc0.ctx_ifce{g}"
         if key in z.files:
