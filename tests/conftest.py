@@ -10,8 +10,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-IMAGE_STREAMS = ["kodim14", "rgb192", "yuv420_8b", "yuv420_10b", "yuv444_10b", "cr192", "bicubic190", "bilinear190", "mop192", "vhop192", "odd191x127", "odd100x37", "odd18x65"]
-SMALL_STREAMS = ["rgb192", "yuv420_8b", "yuv420_10b", "yuv444_10b", "cr192", "bicubic190", "bilinear190", "mop192", "vhop192", "odd191x127", "odd100x37", "odd18x65"]
+IMAGE_STREAMS = ["kodim14", "rgb192", "yuv420_8b", "yuv420_10b", "yuv444_10b", "cr192", "bicubic190", "bilinear190", "mop192", "vhop192", "odd191x127", "odd100x37", "odd18x65", "hq192"]
+SMALL_STREAMS = ["rgb192", "yuv420_8b", "yuv420_10b", "yuv444_10b", "cr192", "bicubic190", "bilinear190", "mop192", "vhop192", "odd191x127", "odd100x37", "odd18x65", "hq192"]
 # I / P / B videos encoded by the reference encoder: vid5 = lop presets (+ its two warp-filter variants); vid3_* = the other
 # decoder presets of cfg/dec (tests/golden/gen/encode_presets.sh): intra vhop + residue hop + motion mop, intra mop + residue
 # mop + motion lop, intra lop + residue vlop + motion mop

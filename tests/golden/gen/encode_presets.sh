@@ -7,6 +7,9 @@
 #   tests/golden/gen/encode_presets.sh <name> <input under /root/reference/test/data> <n_frames> <intra cfg> [<residue cfg> <motion cfg>]
 set -e
 NAME=$1; IN=$2; NF=$3; INTRA=$4; RES=${5:-lop}; MOT=${6:-lop}
+# LMBDA (environment): the rate constraint, default the encoder's 1e-3; hq192 = LMBDA=0.00001 encode_presets.sh hq192 192x128_kodim15.png 1 lop
+# (2.5 bpp: 12-15 % of the symbols take the wide 62-symbol windows, scale indices up to 2433 of 2560)
+LMBDA_ARG=${LMBDA:+--lmbda=$LMBDA}
 # <input>: a file name under /root/reference/test/data, or an absolute path (crops of the reference's test picture made by the caller)
 case "$IN" in /*) INP=$IN;; *) INP=/root/reference/test/data/$IN;; esac
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -20,7 +23,7 @@ if [ "$NF" -gt 1 ]; then PPOS="--p_pos=-1"; fi
 for ((k = 0; k < NF; k++)); do
     if [ $k -eq 0 ]; then R=/root/reference/cfg/dec/intra/$INTRA.cfg; else R=/root/reference/cfg/dec/residue/$RES.cfg; fi
     python3 cc_encode.py --input=$INP --workdir=$W/ --intra_pos=0 $PPOS --n_frames=$NF \
-        --output=$W/$NAME.cool --coding_idx=$k --debug \
+        --output=$W/$NAME.cool --coding_idx=$k --debug $LMBDA_ARG \
         --dec_cfg_residue=$R --dec_cfg_motion=/root/reference/cfg/dec/motion/$MOT.cfg > $W/enc$k.log 2>&1
 done
 ls -la $W/$NAME.cool
