@@ -10,12 +10,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-IMAGE_STREAMS = ["kodim14", "rgb192", "yuv420_8b", "yuv420_10b", "yuv444_10b", "cr192", "bicubic190", "bilinear190", "mop192", "vhop192", "odd191x127", "odd100x37", "odd18x65", "hq192"]
-SMALL_STREAMS = ["rgb192", "yuv420_8b", "yuv420_10b", "yuv444_10b", "cr192", "bicubic190", "bilinear190", "mop192", "vhop192", "odd191x127", "odd100x37", "odd18x65", "hq192"]
+IMAGE_STREAMS = ["kodim14", "rgb192", "yuv420_8b", "yuv420_10b", "yuv444_10b", "cr192", "bicubic190", "bilinear190", "mop192", "vhop192", "odd191x127", "odd100x37", "odd18x65", "hq192", "yuv444_8b"]
+SMALL_STREAMS = ["rgb192", "yuv420_8b", "yuv420_10b", "yuv444_10b", "cr192", "bicubic190", "bilinear190", "mop192", "vhop192", "odd191x127", "odd100x37", "odd18x65", "hq192", "yuv444_8b"]
 # I / P / B videos encoded by the reference encoder: vid5 = lop presets (+ its two warp-filter variants); vid3_* = the other
 # decoder presets of cfg/dec (tests/golden/gen/encode_presets.sh): intra vhop + residue hop + motion mop, intra mop + residue
-# mop + motion lop, intra lop + residue vlop + motion mop
-VIDEO_STREAMS = ["vid5", "vid5_w2", "vid5_w4", "vid3_hop", "vid3_mop", "vid3_vlop"]
+# mop + motion lop, intra lop + residue vlop + motion mop; vid3_ldp = low-delay I P P (a P frame predicted from a P frame)
+VIDEO_STREAMS = ["vid5", "vid5_w2", "vid5_w4", "vid3_hop", "vid3_mop", "vid3_vlop", "vid3_ldp"]
 
 
 def pytest_configure(config):

@@ -18,8 +18,9 @@ export PYTHONPATH=$HERE/shims:/root/reference
 W=/tmp/ccgen/$NAME
 rm -rf $W; mkdir -p $W
 cd /root/reference
-PPOS=""
-if [ "$NF" -gt 1 ]; then PPOS="--p_pos=-1"; fi
+# PPOS (environment): display indices of the P frames (cc_encode.py --p_pos), default: the last frame (hierarchical B in between);
+# vid3_ldp = PPOS=1-2 encode_presets.sh vid3_ldp D-BQSquare-3frames_224x128_60p_yuv420_8b.yuv 3 lop lop lop   (I P P: a P frame predicted from a P frame)
+if [ "$NF" -gt 1 ]; then PPOS="--p_pos=${PPOS:--1}"; else PPOS=""; fi
 for ((k = 0; k < NF; k++)); do
     if [ $k -eq 0 ]; then R=/root/reference/cfg/dec/intra/$INTRA.cfg; else R=/root/reference/cfg/dec/residue/$RES.cfg; fi
     python3 cc_encode.py --input=$INP --workdir=$W/ --intra_pos=0 $PPOS --n_frames=$NF \

@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported():
     assert b"gfx950" in L.ccd_version()
 
 
-@pytest.mark.parametrize("name", IMAGE_STREAMS + ["vid5", "vid3_hop", "vid3_mop", "vid3_vlop"])
+@pytest.mark.parametrize("name", IMAGE_STREAMS + ["vid5", "vid3_hop", "vid3_mop", "vid3_vlop", "vid3_ldp"])
 def test_headers_match_reference(name):
     from cool_chic_amd.bitstream.header import CoolChicHeader, FrameHeader, VideoHeader
 
@@ -272,6 +272,7 @@ def test_fixtures_reach_every_entropy_instantiation(oracle):
     assert [c[:2] for c in ref_encoded["vid3_mop"]] == [(4, 3), (3, 3), (2, 2), (3, 3), (2, 2)]
     # vid3_vlop: I = lop (8), residue vlop (6 inputs, one hidden layer) + motion mop (8)
     assert [c[:2] for c in ref_encoded["vid3_vlop"]] == [(2, 3), (2, 2), (2, 3), (2, 2), (2, 3)]
+    assert [c[:2] for c in ref_encoded["vid3_ldp"]] == [(2, 3), (2, 3), (2, 2), (2, 3), (2, 2)]
     nv_ref = {c[0] for v in ref_encoded.values() for c in v}
     assert nv_ref == {2, 3, 4, 5, 7}
     sweep = {n: classes(s)[0] for n, (s, _) in load_arm_sweep().items()}
