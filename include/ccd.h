@@ -212,7 +212,8 @@ int ccd_batch_copy_planes_async(ccd_batch* b, int first_slot, int n_slots, void*
  * events belong to the batch.  Different batches may be driven from different host threads on one device; ONE batch is not
  * thread-safe.  ccd_batch_destroy drains every stream the caller passed to ccd_batch_run[_stage], ccd_batch_wait and
  * ccd_batch_copy_* before the batch's blocks return to the cache; work the caller enqueued on OTHER streams that reads
- * pointers obtained from ccd_batch_plane / _output / _latent must be finished by the caller before the destroy. */
+ * pointers obtained from ccd_batch_plane / _output / _latent must be finished by the caller before the destroy.  A stream
+ * handed to any ccd_batch_* call must stay alive until the batch is destroyed (the destroy synchronises it). */
 void ccd_pool_trim(int device);
 
 /* ---- whole file: decode_video(), decode.py:26-91 ----------------------------------------- */
