@@ -49,10 +49,20 @@ namespace ccd {
 #define PROF_SUB(var, t0) (void)(t0)
 #endif
 // level 2 only: stamps per task of producer 0 (idle before the early wait, early work, late wait, late work)
-#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
+#if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2 && defined(CCD_PIPE_TRACE)
+#define LPROF_T(cond) __builtin_amdgcn_s_memtime()
+#elif defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
 #define LPROF_T(cond) ((cond) ? __builtin_amdgcn_s_memtime() : 0ull)
 #else
 #define LPROF_T(cond) 0ull
+#endif
+// -DCCD_PIPE_PROFILE=2 -DCCD_PIPE_TRACE: EVERY producer stamps its tasks, and the tasks of the grid whose width is g_trace_cfg[0],
+// 512 steps from "g_trace_cfg[1] steps left" on, are written out as records of 8 words (tools/trace_tasks.py draws the
+// time line of a few steps from them: which hand-over a step of a chain-bound grid waits for).  One stream per launch.
+#if defined(CCD_PIPE_TRACE)
+constexpr int kTraceTasks = 4096;
+__device__ unsigned long long g_trace[kTraceTasks * 8];
+__device__ unsigned int g_trace_cfg[2];
 #endif
 
 // widest step of a grid >= CCD_T8 pixels: 8-pixel tasks; >= CCD_T4: 4-pixel tasks; else 2-pixel tasks (tunable at build time)
@@ -466,7 +476,6 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_min_u32 s54, s54, %[n]\n\t"
                 "s_and_b32 s55, %[seq], %[smask]\n\t"
                 "v_lshl_add_u32 v51, s55, 2, %[rdy]\n\t"
-                "ds_read_b32 v52, v51\n\t"
                 "s_lshl_b32 s56, s55, %[bshift]\n\t"
                 "s_sub_u32 s57, s54, %[i]\n\t"
                 "s_add_u32 s57, s57, s70\n\t"
@@ -475,16 +484,22 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "v_lshl_add_u32 v50, s56, 9, %[tabl]\n\t"
                 "v_lshl_add_u32 v53, s56, 2, %[l4]\n\t"
                 "s_mov_b32 s68, 0\n\t"
-                "s_branch 12f\n\t"
+                "s_branch 18f\n\t"
                 // bounded spin on the slot's counter (short waits are the rule on short steps); a long wait goes back to the
-                // compiled code, which also watches the abort flag
+                // compiled code, which also watches the abort flag.  Every look asks for the counter AND, behind it, for what the
+                // first symbols need (top symbols, first two rows): LDS answers a wave in order and a producer stores its rows
+                // before it counts its part in, so a counter that reads "there" vouches for the answers behind it - the look that
+                // succeeds costs ONE LDS round trip, not two (r04: ~150 ticks per part where the producers are the limit)
                 "11:\n\t"
                 "s_add_u32 s68, s68, 1\n\t"
                 "s_cmp_lt_u32 s68, 1024\n\t"
                 "s_cbranch_scc0 7f\n\t"
+                "18:\n\t"
                 "ds_read_b32 v52, v51\n\t"
-                "12:\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
+                "ds_read_b32 %[top], v53\n\t"
+                "ds_read_b64 v[40:41], v50\n\t"
+                "ds_read_b64 v[42:43], v50 offset:512\n\t"
+                "s_waitcnt lgkmcnt(3)\n\t"
                 "v_readfirstlane_b32 s58, v52\n\t"
                 "s_cmp_eq_u32 s58, s57\n\t"
                 "s_cbranch_scc1 13f\n\t"
@@ -498,13 +513,22 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_add_u32 %[npart], %[npart], 1\n\t"
                 "s_mov_b32 s65, 1\n\t"
                 "s_mov_b32 s66, s54\n\t"
-                "s_branch 27f\n\t"
-                "13:\n\t"
-                "s_add_u32 %[spins], %[spins], s68\n\t"
-                "ds_read_b32 %[top], v53\n\t"
+                "s_mov_b32 s67, %[i]\n\t"           // (what 27: sets for a part that starts at symbol i; its rows are the batch's first)
+                "s_add_u32 s54, %[i], s70\n\t"
+                "s_add_u32 s54, s54, 1\n\t"
+                "s_min_u32 s54, s54, s66\n\t"
+#if CCD_BPX_WIDE == 16 && !defined(CCD_NO_PART_BLOCKS)
+                "s_sub_u32 s58, s54, %[i]\n\t"     // a full 8-symbol part (8-pixel tasks): its unrolled block (ccd_dec_parts8.inc)
+                "s_cmp_eq_u32 s58, 8\n\t"
+                "s_cbranch_scc1 400f\n\t"
+#endif
+                "s_branch 1f\n\t"
                 "8:\n\t"
                 "ds_read_b64 v[40:41], v50\n\t"
                 "ds_read_b64 v[42:43], v50 offset:512\n\t"
+                "s_branch 19f\n\t"
+                "13:\n\t"
+                "s_add_u32 %[spins], %[spins], s68\n\t"
                 // a full batch of 16 symbols takes the unrolled copy of the loop (80:): no loop control on the chain
                 "19:\n\t"
                 "s_sub_u32 s58, s54, %[i]\n\t"
@@ -639,13 +663,23 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "ds_write_b32 %[rdy], v52 offset:68\n\t"
                 "s_cmp_lt_u32 %[i], s66\n\t"
                 "s_cbranch_scc0 29f\n\t"
-                // the next part of the batch: wait for its bit
+                // the next part of the batch starts at symbol i: it runs through the loop above like a short batch.  Wait for its bit -
+                // each look with the part's top symbols and first two rows behind it, as at 11:
                 "s_and_b32 s59, %[i], s62\n\t"
+                "s_add_u32 s58, s59, s56\n\t"
+                "v_lshl_add_u32 v50, s58, 9, %[tabl]\n\t"
                 "s_lshr_b32 s59, s59, %[tshift]\n\t"
+                "s_mov_b32 s67, %[i]\n\t"
+                "s_add_u32 s54, %[i], s70\n\t"
+                "s_add_u32 s54, s54, 1\n\t"
+                "s_min_u32 s54, s54, s66\n\t"
                 "s_mov_b32 s68, 0\n\t"
                 "28:\n\t"
                 "ds_read_b32 v52, v51\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
+                "ds_read_b32 %[top], v53\n\t"
+                "ds_read_b64 v[40:41], v50\n\t"
+                "ds_read_b64 v[42:43], v50 offset:512\n\t"
+                "s_waitcnt lgkmcnt(3)\n\t"
                 "v_readfirstlane_b32 s58, v52\n\t"
                 "s_bitcmp1_b32 s58, s59\n\t"
                 "s_cbranch_scc1 27f\n\t"
@@ -653,19 +687,13 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_cmp_lt_u32 s68, 1024\n\t"
                 "s_cbranch_scc1 28b\n\t"
                 "s_branch 7f\n\t"
-                // a part starts at symbol i (its tables are there): it runs through the loop above like a short batch
                 "27:\n\t"
                 "s_add_u32 %[spins], %[spins], s68\n\t"
-                "s_mov_b32 s67, %[i]\n\t"
-                "s_add_u32 s54, %[i], s70\n\t"
-                "s_add_u32 s54, s54, 1\n\t"
-                "s_min_u32 s54, s54, s66\n\t"
-                "s_and_b32 s58, %[i], s62\n\t"
-                "s_add_u32 s58, s58, s56\n\t"
-                "v_lshl_add_u32 v50, s58, 9, %[tabl]\n\t"
-                "ds_read_b32 %[top], v53\n\t"
-                "ds_read_b64 v[40:41], v50\n\t"
-                "ds_read_b64 v[42:43], v50 offset:512\n\t"
+#if CCD_BPX_WIDE == 16 && !defined(CCD_NO_PART_BLOCKS)
+                "s_sub_u32 s58, s54, %[i]\n\t"     // the second 8-symbol part of a 16-pixel batch: its unrolled block
+                "s_cmp_eq_u32 s58, 8\n\t"
+                "s_cbranch_scc1 420f\n\t"
+#endif
                 "s_branch 1b\n\t"
                 // the batch is finished (its last part is published): slot handed back, batch counted
                 "29:\n\t"
@@ -788,6 +816,8 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "80:\n\t"
 #ifdef CCD_BLOCK_TEST_EVERY_SYMBOL
 #include "ccd_dec_block16.inc"
+#elif defined(CCD_MID_PUBLISH)
+#include "ccd_dec_block16pm.inc"  // + the first 8 symbols published half-way
 #else
 #include "ccd_dec_block16p.inc"   // one renormalisation / sentinel test per two symbols (tools/gen_decoder_block.py: block_paired)
 #endif
@@ -932,6 +962,11 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
 #endif
 #if CCD_BPX_WIDE == 32
 #include "ccd_dec_tramp32.inc"
+#endif
+#if CCD_BPX_WIDE == 16 && !defined(CCD_NO_PART_BLOCKS)
+                // ---- the two 8-symbol parts of a batch that is decoded part by part (the producers are the limit: every short-step
+                // grid, grid 0 of a portrait picture): the paired block above cut in two, each half ending in the part-end handler 2:
+#include "ccd_dec_parts8.inc"
 #endif
                 "15:\n\t"
                 "s_mov_b32 %[st], 3\n\t"
@@ -1742,8 +1777,17 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                     asm volatile("ds_read_b32 %0, %2 offset:4\n\tds_read_i8 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                                  : "=&v"(seen_v), "=&v"(r) : "v"(C.s_consumed.off), "v"(C.s_ring.off + cell) : "memory");
                     if (__builtin_expect(static_cast<int32_t>(uni(seen_v) - want) < 0, 0)) {
-                        if (!wait_ge(C.s_consumed + 1, need_px, C.s_abort)) return seq;
-                        r = C.s_ring[cell];
+                        // every look of the polling loop is the same pair: the look that succeeds brings the cell along (one LDS
+                        // round trip less between "published" and the late work: on the chain of every short-step grid)
+                        unsigned spins = 0;
+                        do {
+                            if ((++spins & 1023u) == 0) {
+                                if (lds_load_acquire(C.s_abort) != 0) return seq;  // (abort / lost hand-over: the kernel stops behind this grid, the count is not used)
+                                if (spins > kSpinLimit) { lds_store_release(C.s_abort, static_cast<uint32_t>(-CCD_ERR_HIP)); return seq; }
+                            }
+                            asm volatile("ds_read_b32 %0, %2 offset:4\n\tds_read_i8 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                                         : "=&v"(seen_v), "=&v"(r) : "v"(C.s_consumed.off), "v"(C.s_ring.off + cell) : "memory");
+                        } while (static_cast<int32_t>(uni(seen_v) - want) < 0);
                     }
                     PROF_ADD(prof[0], t0);
                     PROF_SUB(prof[2], t0);  // the MLP's stamps bracket this wait: take it out of them
@@ -1982,6 +2026,17 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                 asm volatile("" ::: "memory");
                 PROF_ADD(prof[3], t_t);
 #if defined(CCD_PIPE_PROFILE) && CCD_PIPE_PROFILE == 2
+#if defined(CCD_PIPE_TRACE)
+                {
+                    const unsigned long long lt_e = __builtin_amdgcn_s_memtime();
+                    const uint32_t gidx = seq0 * kHalves + task;
+                    if (lane == 0 && static_cast<uint32_t>(W) == g_trace_cfg[0] && g_trace_cfg[1] - it.left < 512u) {
+                        unsigned long long* r = g_trace + static_cast<size_t>(gidx % kTraceTasks) * 8;
+                        r[0] = (static_cast<unsigned long long>(it.left) << 32) | (static_cast<unsigned long long>(task) << 16) | (static_cast<unsigned long long>(pw) << 8) | static_cast<unsigned long long>(cnt);
+                        r[1] = lt_a; r[2] = lt_b; r[3] = lt_c; r[4] = lt_d; r[5] = lt_e; r[6] = (static_cast<unsigned long long>(need_px) << 32) | seq0; r[7] = pix0;
+                    }
+                }
+#endif
                 if (pw == 0) {
                     const unsigned long long lt_e = __builtin_amdgcn_s_memtime();
                     prof[0] += lt_b - lt_a; prof[1] += lt_c - lt_b; prof[2] += lt_d - lt_c; prof[3] += lt_e - lt_d; prof[8] += 1;
@@ -2408,3 +2463,14 @@ hipError_t launch_entropy_pipe(const EntropyParams* d_slots, int n_slots, int nv
 }
 
 }  // namespace ccd
+
+#if defined(CCD_PIPE_TRACE)
+// trace builds only (tools/trace_tasks.py): which grid / first task to record, and the records back
+extern "C" int ccd_debug_trace_config(unsigned int grid_w, unsigned int steps_left) {
+    const unsigned int cfg[2] = {grid_w, steps_left};
+    return hipMemcpyToSymbol(HIP_SYMBOL(ccd::g_trace_cfg), cfg, sizeof(cfg)) == hipSuccess ? 0 : -1;
+}
+extern "C" int ccd_debug_trace_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ccd::g_trace), sizeof(unsigned long long) * ccd::kTraceTasks * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -82,7 +82,12 @@ def pair(p):
     return "s[%s:%s]" % (p[0][1:], p[1][1:])
 
 
-def block_paired(n, tramp0):
+def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False):
+    """mid_publish: behind the test of symbols n/2 - 2 and n/2 - 1 the first n/2 symbols go to the ring and the stream's pixel count
+    is published - the first task of the NEXT step (8 pixels: it waits for its left neighbours, the first 8 or 9 symbols of this
+    step) starts its late part half a batch earlier (measured: no gain on the chain-bound grids, + 2 ticks per symbol on grid 0).
+    part: the block of ONE 8-pixel part of a batch that is decoded part by part (symbols lane0 .. lane0 + 7 of the batch; v50 = the
+    part's first row); it ends in the loop's part-end handler (2:) like a part that ran through the 3-copy loop."""
     assert n % 2 == 0
     out = []
     for j in range(n):
@@ -90,17 +95,22 @@ def block_paired(n, tramp0):
         rcur, rnew = RP[j % 3], RP[(j + 1) % 3]
         dcur, dnew = DP[j % 2], DP[(j + 1) % 2]
         lp_lo, lp_hi, lane = HS[j % 2]
-        out += [q("%d:" % (300 + j)),
-                q("s_lshr_b64 s[40:41], %s, 24" % pair(rcur)),
+        out.append(q("%d:" % (label0 + j)))
+        if mid_publish and j == n // 2:
+            out += [q("s_mov_b64 exec, 0x%x" % ((1 << (n // 2)) - 1)), q("v_sub_u32 v52, %[top], %[raw]"), q("v_add_u32 v52, 1, v52"),
+                    q("ds_write_b8 %[ring], v52"), q("s_mov_b64 exec, -1"), q("s_add_u32 s58, %[pix0], %[i]"), q("s_add_u32 s58, s58, %d" % (n // 2)),
+                    q("v_mov_b32 v56, s58"), q("ds_write_b32 %[rdy], v56 offset:68")]
+        wait = "s_waitcnt lgkmcnt(4)" if (mid_publish and j in (n // 2, n // 2 + 1)) else "s_waitcnt lgkmcnt(2)"
+        out += [q("s_lshr_b64 s[40:41], %s, 24" % pair(rcur)),
                 q("ds_read_b64 %s, v50 offset:%d" % (nxt, 512 * (j + 2))),
-                q("s_waitcnt lgkmcnt(2)"),
+                q(wait),
                 q("v_mad_u64_u32 v[44:45], s[42:43], s40, %s, 0" % cur_l),
                 q("v_mad_u32_u24 v45, %s, s41, v45" % cur_l),
                 q("v_cmpx_ge_u64 vcc, %s, v[44:45]" % pair(dcur)),
                 q("v_mad_u64_u32 v[48:49], s[42:43], s40, %s, 0" % cur_p),
                 q("v_mad_u32_u24 v49, %s, s41, v49" % cur_p),
                 q("s_ff1_i32_b64 %s, vcc" % lane),
-                q("v_writelane_b32 %%[raw], %s, %d" % (lane, j)),
+                q("v_writelane_b32 %%[raw], %s, %d" % (lane, lane0 + j)),
                 q("v_readfirstlane_b32 %s, v48" % rnew[0]),
                 q("v_readfirstlane_b32 %s, v49" % rnew[1]),
                 q("v_readfirstlane_b32 %s, v44" % lp_lo),
@@ -112,10 +122,12 @@ def block_paired(n, tramp0):
                     q("s_cbranch_scc1 %df" % (tramp0 + j // 2))]
         out += [q("s_sub_u32 %s, %s, %s" % (dnew[0], dcur[0], lp_lo)),
                 q("s_subb_u32 %s, %s, %s" % (dnew[1], dcur[1], lp_hi))]
-    out.append(q("%d:" % (300 + n)))
+    out.append(q("%d:" % (label0 + n)))
     if n % 3:  # the loop and the epilogue expect the range in s[52:53]
         out.append(q("s_mov_b64 s[52:53], %s" % pair(RP[n % 3])))
     out.append(q("s_add_u32 %%[i], %%[i], %d" % n))
+    if part:
+        out.append(q("s_branch 2b"))
     return out
 
 
@@ -142,7 +154,7 @@ def loop_conventions(e):
     return out
 
 
-def renorm_in_block(x, odd, lbl_slow):
+def renorm_in_block(x, odd, lbl_slow, label0=300):
     """Symbol x left with a new range below 2^32.  Not zero (a sentinel goes to the loop's handler): an ordinary renormalisation,
     done here in the block's own registers - commit the symbol, shift the next payload word in - and the block goes on with
     symbol x + 1 (an even x: the odd symbol behind it ran on a useless scale and runs again)."""
@@ -162,7 +174,7 @@ def renorm_in_block(x, odd, lbl_slow):
             q("s_mov_b32 %s, 0" % rn[0]),
             q("s_add_u32 %[wpos], %[wpos], 1"),
             q("s_cmp_eq_u32 s58, 63"),
-            q("s_cbranch_scc0 %db" % (300 + x + 1))]
+            q("s_cbranch_scc0 %db" % (label0 + x + 1))]
     # the 64-word payload buffer is used up: leave for the refill with the loop's conventions, symbol x committed
     if dn != DP[0]:
         out.append(q("s_mov_b64 s[50:51], %s" % pair(dn)))
@@ -172,18 +184,18 @@ def renorm_in_block(x, odd, lbl_slow):
     return out
 
 
-def trampolines_paired(n, tramp0):
+def trampolines_paired(n, tramp0, label0=300):
     out = []
     for k in range(n // 2):
         e, o = 2 * k, 2 * k + 1
         out.append(q("%d:" % (tramp0 + k)))
         out += [q("s_cmp_eq_u32 %s, 0" % RP[(e + 1) % 3][1]),   # the even symbol's new range
                 q("s_cbranch_scc0 %df" % (tramp0 + 50 + k))]
-        out += renorm_in_block(e, False, tramp0 + 200 + k)
+        out += renorm_in_block(e, False, tramp0 + 200 + k, label0)
         out.append(q("%d:" % (tramp0 + 200 + k)))
         out += loop_conventions(e)
         out.append(q("%d:" % (tramp0 + 50 + k)))
-        out += renorm_in_block(o, True, tramp0 + 250 + k)
+        out += renorm_in_block(o, True, tramp0 + 250 + k, label0)
         out.append(q("%d:" % (tramp0 + 250 + k)))
         out += loop_conventions(o)
     return out
@@ -196,6 +208,12 @@ def main():
         (root / ("ccd_dec_block%d.inc" % n)).write_text(head + "\n".join(block(n, tramp0, mid)) + "\n")
         (root / ("ccd_dec_tramp%d.inc" % n)).write_text(head + "\n".join(trampolines(n, tramp0)) + "\n")
     (root / "ccd_dec_block16p.inc").write_text(head + "\n".join(block_paired(16, 201)) + "\n")
+    (root / "ccd_dec_block16pm.inc").write_text(head + "\n".join(block_paired(16, 201, mid_publish=True)) + "\n")
+    # the two 8-symbol parts of a 16-pixel batch that is decoded part by part (each with its trampolines behind it)
+    parts = []
+    for label0, lane0, tramp0 in ((400, 0, 1001), (420, 8, 1401)):
+        parts += [q(".p2align 6")] + block_paired(8, tramp0, label0=label0, lane0=lane0, part=True) + trampolines_paired(8, tramp0, label0)
+    (root / "ccd_dec_parts8.inc").write_text(head + "\n".join(parts) + "\n")
     (root / "ccd_dec_tramp16p.inc").write_text(head + "\n".join(trampolines_paired(16, 201)) + "\n")
 
 
