@@ -59,9 +59,12 @@ namespace ccd {
 // -DCCD_PIPE_PROFILE=2 -DCCD_PIPE_TRACE: EVERY producer stamps its tasks, and the tasks of the grid whose width is g_trace_cfg[0],
 // 512 steps from "g_trace_cfg[1] steps left" on, are written out as records of 8 words (tools/trace_tasks.py draws the
 // time line of a few steps from them: which hand-over a step of a chain-bound grid waits for).  One stream per launch.
+// The records are collected in LDS (32 bytes each, behind the kernel's own regions) and copied out when the kernel ends: a global
+// store per task put every producer behind a vmcnt wait of ~2 k ticks.
 #if defined(CCD_PIPE_TRACE)
-constexpr int kTraceTasks = 4096;
-__device__ unsigned long long g_trace[kTraceTasks * 8];
+constexpr int kTraceTasks = 1024;
+constexpr uint32_t kTraceLdsBytes = kTraceTasks * 32u;
+__device__ unsigned int g_trace[kTraceTasks * 8];
 __device__ unsigned int g_trace_cfg[2];
 #endif
 
@@ -270,6 +273,9 @@ struct PipeCtx {
     LdsRef<uint32_t> s_abort;
     int dim, n_layers, n_sp, n_if, n_w_hidden;
     int ring_mask;         // ring rows - 1
+#if defined(CCD_PIPE_TRACE)
+    uint32_t trace_off;    // LDS offset of the trace records
+#endif
     // per grid
     int H, W, fin, fh, fw;
     int fstride;           // feat_stride(n_if)
@@ -661,6 +667,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_add_u32 s58, %[pix0], %[i]\n\t"
                 "v_mov_b32 v52, s58\n\t"
                 "ds_write_b32 %[rdy], v52 offset:68\n\t"
+                "126:\n\t"
                 "s_cmp_lt_u32 %[i], s66\n\t"
                 "s_cbranch_scc0 29f\n\t"
                 // the next part of the batch starts at symbol i: it runs through the loop above like a short batch.  Wait for its bit -
@@ -1334,6 +1341,9 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
         C_fix.s_ring.off = L.ring; C_fix.s_w.off = L.w; C_fix.s_b.off = L.b; C_fix.s_act.off = L.act; C_fix.s_a.off = L.a; C_fix.s_tab.off = L.tab;
         C_fix.s_meta.off = L.meta; C_fix.s_rcp.off = L.rcp; C_fix.s_exp.off = L.exp; C_fix.s_ready.off = L.ready; C_fix.s_consumed.off = L.consumed;
         C_fix.s_abort.off = L.abort; C_fix.n_w_hidden = L.n_w_hidden; C_fix.ring_mask = kRingRows - 1;
+#if defined(CCD_PIPE_TRACE)
+        C_fix.trace_off = L.end;
+#endif
         C_fix.dim = SH::dim; C_fix.n_layers = SH::n_layers; C_fix.n_sp = SH::n_sp; C_fix.k_left = 0;
     }
     const PipeCtx& C = C_fix;
@@ -2030,10 +2040,13 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                 {
                     const unsigned long long lt_e = __builtin_amdgcn_s_memtime();
                     const uint32_t gidx = seq0 * kHalves + task;
-                    if (lane == 0 && static_cast<uint32_t>(W) == g_trace_cfg[0] && g_trace_cfg[1] - it.left < 512u) {
-                        unsigned long long* r = g_trace + static_cast<size_t>(gidx % kTraceTasks) * 8;
-                        r[0] = (static_cast<unsigned long long>(it.left) << 32) | (static_cast<unsigned long long>(task) << 16) | (static_cast<unsigned long long>(pw) << 8) | static_cast<unsigned long long>(cnt);
-                        r[1] = lt_a; r[2] = lt_b; r[3] = lt_c; r[4] = lt_d; r[5] = lt_e; r[6] = (static_cast<unsigned long long>(need_px) << 32) | seq0; r[7] = pix0;
+                    if (lane == 0 && static_cast<uint32_t>(W) == uni(g_trace_cfg[0]) && uni(g_trace_cfg[1]) - it.left < 256u) {
+                        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                                                u32x4* r = reinterpret_cast<u32x4*>(ccd_pipe_smem + C.trace_off + (gidx % kTraceTasks) * 32u);
+                        const u32x4 r0 = {(it.left << 12) | (task << 8) | (static_cast<uint32_t>(pw) << 4) | static_cast<uint32_t>(cnt), static_cast<uint32_t>(lt_a),
+                                          static_cast<uint32_t>(lt_b), static_cast<uint32_t>(lt_c)};
+                        const u32x4 r1 = {static_cast<uint32_t>(lt_d), static_cast<uint32_t>(lt_e), need_px - pix0, static_cast<uint32_t>(lt_a >> 32)};
+                        r[0] = r0; r[1] = r1;
                     }
                 }
 #endif
@@ -2081,6 +2094,9 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         C.s_ring.off = L.ring; C.s_w.off = L.w; C.s_b.off = L.b; C.s_act.off = L.act; C.s_a.off = L.a; C.s_tab.off = L.tab;
         C.s_meta.off = L.meta; C.s_rcp.off = L.rcp; C.s_exp.off = L.exp; C.s_ready.off = L.ready; C.s_consumed.off = L.consumed;
         C.s_abort.off = L.abort; C.n_w_hidden = L.n_w_hidden;
+#if defined(CCD_PIPE_TRACE)
+        C.trace_off = L.end;
+#endif
     }
     C.ring_mask = ring_rows - 1;
     constexpr int kActRows = MF ? 16 : 8;
@@ -2121,6 +2137,9 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
     }
     if (tid < kSlots) C.s_ready[tid] = 0;
     if (tid == 0) { C.s_consumed[0] = 0; C.s_consumed[1] = 0; *C.s_abort = 0; P.status[39] = 0; }
+#if defined(CCD_PIPE_TRACE)
+    for (int i = tid; i < kTraceTasks * 8; i += kPipeThreads) reinterpret_cast<unsigned int*>(ccd_pipe_smem + C.trace_off)[i] = 0u;
+#endif
 
     DecState S;
     S.range = ~uint64_t{0}; S.dist = 0; S.word_pos = 2; S.wbase = 2; S.wbuf = 0; S.n_decoded = 0;
@@ -2323,6 +2342,12 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         C.seq_base = seq_end;  // every wave walked the same batches
         C.px_base += static_cast<uint32_t>(C.H) * static_cast<uint32_t>(C.W);
     }
+#if defined(CCD_PIPE_TRACE)
+    {
+                const unsigned int* t = reinterpret_cast<const unsigned int*>(ccd_pipe_smem + C.trace_off);
+        for (int i = tid; i < kTraceTasks * 8; i += kPipeThreads) g_trace[i] = t[i];
+    }
+#endif
     if (tid == 0) {
         const uint32_t ab = *C.s_abort;
         P.status[0] = ab ? -static_cast<int32_t>(ab) : 0;
@@ -2359,7 +2384,11 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
 }
 
 size_t entropy_pipe_lds_bytes(int dim, int n_layers, int ring_rows, int mfma) {
-    return pipe_layout(dim, n_layers, (dim + 3) & ~3, ring_rows, mfma ? mf_tables(n_layers) : 0).end;
+    size_t n = pipe_layout(dim, n_layers, (dim + 3) & ~3, ring_rows, mfma ? mf_tables(n_layers) : 0).end;
+#if defined(CCD_PIPE_TRACE)
+    n += kTraceLdsBytes;
+#endif
+    return n;
 }
 
 // rows of the decoded-symbol ring for a stream whose widest grid is max_grid_w (0: too wide for the kernel)
@@ -2470,7 +2499,7 @@ extern "C" int ccd_debug_trace_config(unsigned int grid_w, unsigned int steps_le
     const unsigned int cfg[2] = {grid_w, steps_left};
     return hipMemcpyToSymbol(HIP_SYMBOL(ccd::g_trace_cfg), cfg, sizeof(cfg)) == hipSuccess ? 0 : -1;
 }
-extern "C" int ccd_debug_trace_read(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ccd::g_trace), sizeof(unsigned long long) * ccd::kTraceTasks * 8) == hipSuccess ? 0 : -1;
+extern "C" int ccd_debug_trace_read(unsigned int* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(ccd::g_trace), sizeof(unsigned int) * ccd::kTraceTasks * 8) == hipSuccess ? 0 : -1;
 }
 #endif

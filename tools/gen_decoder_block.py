@@ -96,11 +96,16 @@ def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False):
         dcur, dnew = DP[j % 2], DP[(j + 1) % 2]
         lp_lo, lp_hi, lane = HS[j % 2]
         out.append(q("%d:" % (label0 + j)))
+        if part and lane0 == 0 and j == n - 2:
+            # first part of a batch: ask for the slot's ready word now - behind the block it says whether the second part is there
+            out.append(q("ds_read_b32 v54, v51"))
         if mid_publish and j == n // 2:
             out += [q("s_mov_b64 exec, 0x%x" % ((1 << (n // 2)) - 1)), q("v_sub_u32 v52, %[top], %[raw]"), q("v_add_u32 v52, 1, v52"),
                     q("ds_write_b8 %[ring], v52"), q("s_mov_b64 exec, -1"), q("s_add_u32 s58, %[pix0], %[i]"), q("s_add_u32 s58, s58, %d" % (n // 2)),
                     q("v_mov_b32 v56, s58"), q("ds_write_b32 %[rdy], v56 offset:68")]
         wait = "s_waitcnt lgkmcnt(4)" if (mid_publish and j in (n // 2, n // 2 + 1)) else "s_waitcnt lgkmcnt(2)"
+        if part and lane0 == 0 and j >= n - 2:
+            wait = "s_waitcnt lgkmcnt(3)"
         out += [q("s_lshr_b64 s[40:41], %s, 24" % pair(rcur)),
                 q("ds_read_b64 %s, v50 offset:%d" % (nxt, 512 * (j + 2))),
                 q(wait),
@@ -123,6 +128,25 @@ def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False):
         out += [q("s_sub_u32 %s, %s, %s" % (dnew[0], dcur[0], lp_lo)),
                 q("s_subb_u32 %s, %s, %s" % (dnew[1], dcur[1], lp_hi))]
     out.append(q("%d:" % (label0 + n)))
+    if part and lane0 == 0:
+        # The first 8 symbols of a 16-pixel batch are decoded: publish them (ring cells + pixel count: the first task of the next step
+        # waits for exactly these), then - if the ready word read two symbols ago shows the second part - go on in the SECOND HALF of the
+        # full batch's block (its symbol 8 finds rows 8 / 9, the range and the distance where this block leaves them; i still
+        # points at the batch's first symbol, as that block expects) and leave through the full batch's epilogue: a batch taken in
+        # two parts then costs ~15 instructions more than one taken whole, not a polling round trip and two part hand-overs.
+        assert n == 8 and RP[n % 3] == RP[8 % 3] and DP[n % 2] == DP[0]
+        out += [q("s_mov_b64 exec, 0xff"), q("v_sub_u32 v52, %[top], %[raw]"), q("v_add_u32 v52, 1, v52"), q("ds_write_b8 %[ring], v52"),
+                q("global_store_byte %[goff], v52, %[lat]"), q("s_mov_b64 exec, -1"),
+                q("s_add_u32 s58, %[pix0], %[i]"), q("s_add_u32 s58, s58, 8"), q("v_mov_b32 v56, s58"), q("ds_write_b32 %[rdy], v56 offset:68"),
+                q("s_sub_u32 s59, s66, %[i]"),
+                q("s_waitcnt lgkmcnt(4)"),          # (the ready word: in front of rows 8 and 9 and the two stores)
+                q("v_readfirstlane_b32 s58, v54"),
+                q("s_cmp_eq_u32 s59, 16"), q("s_cbranch_scc0 %df" % (label0 + n + 1)),
+                q("s_bitcmp1_b32 s58, 1"), q("s_cbranch_scc0 %df" % (label0 + n + 1)),
+                q("ds_read_b32 %[top], v53"), q("s_mov_b32 s65, 0"), q("s_mov_b32 s54, s66"), q("s_branch 308b"),
+                q("%d:" % (label0 + n + 1)),
+                q("s_mov_b64 s[52:53], %s" % pair(RP[n % 3])), q("s_add_u32 %%[i], %%[i], %d" % n), q("s_mov_b32 s67, %[i]"), q("s_branch 126b")]
+        return out
     if n % 3:  # the loop and the epilogue expect the range in s[52:53]
         out.append(q("s_mov_b64 s[52:53], %s" % pair(RP[n % 3])))
     out.append(q("s_add_u32 %%[i], %%[i], %d" % n))

@@ -33,15 +33,20 @@ tp = 8 if n_max >= 25 else (4 if n_max >= 9 else 2)
 total_steps = w + 10 * (h - 1)
 assert L.ccd_debug_trace_config(w, total_steps - 1 - step0) == 0
 b.run(stage=0); b.wait()
-buf = np.zeros(4096 * 8, np.uint64)
+buf = np.zeros(1024 * 8, np.uint32)
 assert L.ccd_debug_trace_read(buf.ctypes.data) == 0
 rec = buf.reshape(-1, 8)
 rows = []
 for r in rec:
     if r[5] == 0: continue
-    left = int(r[0] >> 32); task = int((r[0] >> 16) & 0xffff); pw = int((r[0] >> 8) & 0xff); cnt = int(r[0] & 0xff)
+    left = int(r[0] >> 12); task = int((r[0] >> 8) & 0xf); pw = int((r[0] >> 4) & 0xf); cnt = int(r[0] & 0xf)
     step = total_steps - 1 - left
-    rows.append((step, task, pw, cnt, [int(x) for x in r[1:6]], int(r[6] >> 32), int(r[7])))
+    base = int(r[7]) << 32
+    ts = [base | int(x) for x in (r[1], r[2], r[3], r[4], r[5])]
+    for k in range(1, 5):  # the low words may wrap once within a task
+        while ts[k] < ts[k - 1]: ts[k] += 1 << 32
+    need = int(np.int32(r[6]))
+    rows.append((step, task, pw, cnt, ts, need, 0))
 rows.sort()
 t0 = rows[0][4][0]
 print(f"stream {idx} grid {grid} {h}x{w}: {tp}-pixel tasks; times in ticks relative to the first record")
@@ -64,3 +69,19 @@ for k in range(4):
     if line: print(f"  task {k}: late work / ready->next seen: " + "  ".join(line))
 per = [seen[(s + 1, 0)][0] - seen[(s, 0)][0] for s in steps if (s, 0) in seen and (s + 1, 0) in seen]
 if per: print("  step period (task 0 seen -> next task 0 seen): mean %.0f" % (sum(per) / len(per)), per)
+# per producer: the phases of its tasks in the window, and the time between the ready bit of one task and the start of the next
+import collections
+by_prod = collections.defaultdict(list)
+for step, task, pw, cnt, t, need, _ in rows:
+    by_prod[pw].append((t[0], t, cnt))
+ph = collections.defaultdict(list)
+for pw, lst in by_prod.items():
+    lst.sort()
+    for k, (_, t, cnt) in enumerate(lst):
+        ph["early wait"].append(t[1] - t[0]); ph["early work"].append(t[2] - t[1]); ph["late wait"].append(t[3] - t[2]); ph["late work"].append(t[4] - t[3])
+        if k: ph["between"].append(t[0] - lst[k - 1][1][4])
+print("all producers, %d tasks: " % len(rows) + "  ".join("%s %.0f" % (k, sum(v) / len(v)) for k, v in ph.items()))
+span = max(r[4][4] for r in rows) - min(r[4][0] for r in rows)
+nst = len({r[0] for r in rows})
+print("window: %d steps in %d ticks = %.0f per step; producers busy (early work + late work + between) %.0f %% of 7 waves" %
+      (nst, span, span / nst, 100.0 * (sum(ph["early work"]) + sum(ph["late work"]) + sum(ph["between"])) / (7.0 * span)))
