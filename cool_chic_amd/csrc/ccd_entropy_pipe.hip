@@ -527,6 +527,8 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_sub_u32 s58, s54, %[i]\n\t"     // a full 8-symbol part (8-pixel tasks): its unrolled block (ccd_dec_parts8.inc)
                 "s_cmp_eq_u32 s58, 8\n\t"
                 "s_cbranch_scc1 400f\n\t"
+                "s_cmp_eq_u32 s58, 4\n\t"          // a 4-symbol part (4-pixel tasks): ccd_dec_parts4.inc
+                "s_cbranch_scc1 440f\n\t"
 #endif
                 "s_branch 1f\n\t"
                 "8:\n\t"
@@ -700,6 +702,15 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_sub_u32 s58, s54, %[i]\n\t"     // the second 8-symbol part of a 16-pixel batch: its unrolled block
                 "s_cmp_eq_u32 s58, 8\n\t"
                 "s_cbranch_scc1 420f\n\t"
+                "s_cmp_eq_u32 s58, 4\n\t"          // a 4-symbol part at pixel 4, 8 or 12 of the batch
+                "s_cbranch_scc0 1b\n\t"
+                "s_and_b32 s58, %[i], s62\n\t"
+                "s_cmp_eq_u32 s58, 4\n\t"
+                "s_cbranch_scc1 450f\n\t"
+                "s_cmp_eq_u32 s58, 8\n\t"
+                "s_cbranch_scc1 460f\n\t"
+                "s_cmp_eq_u32 s58, 12\n\t"
+                "s_cbranch_scc1 470f\n\t"
 #endif
                 "s_branch 1b\n\t"
                 // the batch is finished (its last part is published): slot handed back, batch counted
@@ -974,6 +985,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 // ---- the two 8-symbol parts of a batch that is decoded part by part (the producers are the limit: every short-step
                 // grid, grid 0 of a portrait picture): the paired block above cut in two, each half ending in the part-end handler 2:
 #include "ccd_dec_parts8.inc"
+#include "ccd_dec_parts4.inc"
 #endif
                 "15:\n\t"
                 "s_mov_b32 %[st], 3\n\t"

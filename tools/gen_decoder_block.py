@@ -82,7 +82,7 @@ def pair(p):
     return "s[%s:%s]" % (p[0][1:], p[1][1:])
 
 
-def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False):
+def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False, cont=False):
     """mid_publish: behind the test of symbols n/2 - 2 and n/2 - 1 the first n/2 symbols go to the ring and the stream's pixel count
     is published - the first task of the NEXT step (8 pixels: it waits for its left neighbours, the first 8 or 9 symbols of this
     step) starts its late part half a batch earlier (measured: no gain on the chain-bound grids, + 2 ticks per symbol on grid 0).
@@ -96,7 +96,7 @@ def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False):
         dcur, dnew = DP[j % 2], DP[(j + 1) % 2]
         lp_lo, lp_hi, lane = HS[j % 2]
         out.append(q("%d:" % (label0 + j)))
-        if part and lane0 == 0 and j == n - 2:
+        if part and cont and j == n - 2:
             # first part of a batch: ask for the slot's ready word now - behind the block it says whether the second part is there
             out.append(q("ds_read_b32 v54, v51"))
         if mid_publish and j == n // 2:
@@ -104,7 +104,7 @@ def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False):
                     q("ds_write_b8 %[ring], v52"), q("s_mov_b64 exec, -1"), q("s_add_u32 s58, %[pix0], %[i]"), q("s_add_u32 s58, s58, %d" % (n // 2)),
                     q("v_mov_b32 v56, s58"), q("ds_write_b32 %[rdy], v56 offset:68")]
         wait = "s_waitcnt lgkmcnt(4)" if (mid_publish and j in (n // 2, n // 2 + 1)) else "s_waitcnt lgkmcnt(2)"
-        if part and lane0 == 0 and j >= n - 2:
+        if part and cont and j >= n - 2:
             wait = "s_waitcnt lgkmcnt(3)"
         out += [q("s_lshr_b64 s[40:41], %s, 24" % pair(rcur)),
                 q("ds_read_b64 %s, v50 offset:%d" % (nxt, 512 * (j + 2))),
@@ -128,7 +128,7 @@ def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False):
         out += [q("s_sub_u32 %s, %s, %s" % (dnew[0], dcur[0], lp_lo)),
                 q("s_subb_u32 %s, %s, %s" % (dnew[1], dcur[1], lp_hi))]
     out.append(q("%d:" % (label0 + n)))
-    if part and lane0 == 0:
+    if part and cont:
         # The first 8 symbols of a 16-pixel batch are decoded: publish them (ring cells + pixel count: the first task of the next step
         # waits for exactly these), then - if the ready word read two symbols ago shows the second part - go on in the SECOND HALF of the
         # full batch's block (its symbol 8 finds rows 8 / 9, the range and the distance where this block leaves them; i still
@@ -236,8 +236,14 @@ def main():
     # the two 8-symbol parts of a 16-pixel batch that is decoded part by part (each with its trampolines behind it)
     parts = []
     for label0, lane0, tramp0 in ((400, 0, 1001), (420, 8, 1401)):
-        parts += [q(".p2align 6")] + block_paired(8, tramp0, label0=label0, lane0=lane0, part=True) + trampolines_paired(8, tramp0, label0)
+        parts += [q(".p2align 6")] + block_paired(8, tramp0, label0=label0, lane0=lane0, part=True, cont=lane0 == 0) + trampolines_paired(8, tramp0, label0)
     (root / "ccd_dec_parts8.inc").write_text(head + "\n".join(parts) + "\n")
+    # the four 4-symbol parts of a 16-pixel batch of 4-pixel tasks (grids whose widest step has 9 .. 24 pixels)
+    parts = []
+    for k in range(4):
+        label0, tramp0 = 440 + 10 * k, 1801 + 400 * k
+        parts += [q(".p2align 6")] + block_paired(4, tramp0, label0=label0, lane0=4 * k, part=True) + trampolines_paired(4, tramp0, label0)
+    (root / "ccd_dec_parts4.inc").write_text(head + "\n".join(parts) + "\n")
     (root / "ccd_dec_tramp16p.inc").write_text(head + "\n".join(trampolines_paired(16, 201)) + "\n")
 
 
