@@ -80,7 +80,11 @@ __device__ unsigned int g_trace_cfg[2];
 #endif
 constexpr int kPipeThreads = CCD_PIPE_THREADS;  // 8 waves: 1 decoder + 7 producers
 constexpr int kPipeWaves = kPipeThreads / 64;
+#ifdef CCD_IDLE_WAVE  // experiment: wave CCD_IDLE_WAVE builds nothing (the decoder's SIMD neighbour is wave 4)
+constexpr int kProducers = kPipeWaves - 2;
+#else
 constexpr int kProducers = kPipeWaves - 1;
+#endif
 // pixels per decoder batch: 16 (two 8-pixel or four 4-pixel tasks), 8 with 2-pixel tasks (bpx / kBpx below)
 #ifndef CCD_BPX_WIDE
 #define CCD_BPX_WIDE 16
@@ -1367,7 +1371,14 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
     const int lane = threadIdx.x & 63;
     // Everything that steers the task loop is wave-uniform; stated with readfirstlane, the loop control, the dependency
     // arithmetic and the task filter run on the scalar unit instead of as exec-masked vector code.
+#ifdef CCD_IDLE_WAVE
+    const int wave_id = uni(static_cast<int>(threadIdx.x >> 6));
+    const bool idle_wave = wave_id == CCD_IDLE_WAVE;
+    const int pw = wave_id - 1 - (wave_id > CCD_IDLE_WAVE ? 1 : 0);
+#else
+    constexpr bool idle_wave = false;
     const int pw = uni(static_cast<int>(threadIdx.x >> 6) - 1);
+#endif
     const EntropyParams& P = *C.P;
     const int dim = SH::fixed ? SH::dim : uni(C.dim), n_layers = SH::fixed ? SH::n_layers : uni(C.n_layers), n_sp = SH::fixed ? SH::n_sp : uni(C.n_sp);
     const int W = uni(C.W);
@@ -1438,7 +1449,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
         uint32_t t_first = static_cast<uint32_t>(pw) - phase;
         t_first += static_cast<int32_t>(t_first) < 0 ? kProducers : 0;
         {
-            for (uint32_t task = t_first; task < n_tasks; task += kProducers) {
+            for (uint32_t task = t_first; task < n_tasks && !idle_wave; task += kProducers) {
                 const uint32_t j = task >> kHalvesShift;
                 const int half = static_cast<int>(task & (kHalves - 1));
                 seq = seq0 + j;
