@@ -198,7 +198,14 @@ struct alignas(16) RowMeta {  // per table row (= pixel of a batch in flight)
     double rcp[kRows + 2];      // RN(1 / b)
     int32_t mu_idx[kRows + 2];
     int32_t top[kRows + 2];     // symbol of window lane 1
+    // where the decoder's epilogue puts the pixel's symbol: LDS address of its ring cell, byte offset in the latent grid.  Written
+    // by the task's producer (early part: position only), read by the decoder with the top symbols - the decoder then needs no
+    // geometry of its own, and a batch may hold pixels of any steps.
+    uint32_t cell[kRows + 2];
+    uint32_t goff[kRows + 2];
 };
+static_assert(offsetof(RowMeta, cell) - offsetof(RowMeta, top) == 520 && offsetof(RowMeta, goff) - offsetof(RowMeta, top) == 1040,
+              "the decoder's asm region reads cell / goff at these immediate offsets from a top symbol's address");
 
 // The workgroup's dynamic LDS.  Regions are referred to by 32-bit byte offsets (LdsRef): a generic 64-bit pointer per
 // region would pin two SGPRs each for the whole kernel (eleven regions), and the compiler could no longer see that the
@@ -428,15 +435,10 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     const int task_shift = task_pix == 8 ? 3 : (task_pix == 4 ? 2 : 1);
     // LDS byte addresses (the dynamic LDS starts at 0) and per-lane constants of the step loop below
     const uint32_t ready_base = C.s_ready.off;  // s_consumed sits kSlots words behind it, the ring at LDS address 0 (kernel set-up)
-    // the ring has kRingRows rows unless the matrix-core variant needs the LDS (then EntropyParams::ring_rows): a constant
-    // here keeps one more SGPR out of the step loop
-    const int ring_mask = MF ? uni(C.ring_mask) : kRingRows - 1;
-    const uint32_t ring_cells_mask = static_cast<uint32_t>(ring_mask) * 64u + 63u;
     const uint32_t top_base = C.s_meta.off + static_cast<uint32_t>(offsetof(RowMeta, top));
     const uint32_t tab_lane = C.s_tab.off + static_cast<uint32_t>(lane) * 8u;
     const uint32_t lane_top_off = top_base + static_cast<uint32_t>(lane & (bpx - 1)) * 4u;
     const uint64_t lat_addr = uni(reinterpret_cast<uint64_t>(C.lat));
-    const uint32_t glo_stride = static_cast<uint32_t>(bpx * (grid_w - 10));
     const RowMeta& meta = *C.s_meta;
     bool ok = true;
     int raw = 0, top_l = 0;  // lane p: window lane chosen for / top symbol of pixel p of the current batch
@@ -453,10 +455,9 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
         uint32_t n_step = static_cast<uint32_t>(it.n), step_x0 = static_cast<uint32_t>(it.x0), step_hy = static_cast<uint32_t>(it.H - it.y0);
         uint32_t steps_left = it.raster ? 1u : static_cast<uint32_t>(it.n_steps - it.c);
         uint32_t i = 0, mode = 0;
-        // lane p <-> pixel p of the step's first batch (v_rbase, v_gbase); the working copies advance by one batch in the epilogue
-        uint32_t v_rbase = static_cast<uint32_t>((((it.y0 + lane) & ring_mask) << 6) | ((it.x0 + 10 * it.y0) & 63));
-        uint32_t v_gbase = static_cast<uint32_t>((it.y0 + lane) * grid_w + (it.x0 - 10 * lane));
-        uint32_t v_ring = v_rbase, v_goff = v_gbase;
+        // lane p <-> pixel p of the current batch: LDS address of its ring cell, its byte in the latent grid (RowMeta::cell / goff,
+        // read with the batch's top symbols)
+        uint32_t v_ring = 0, v_goff = 0;
         while (true) {
             uint32_t status, k_rare;
             i = uni(i); seq = uni(seq); mode = uni(mode); n_spins = uni(n_spins);  // scalar operands of the region below
@@ -469,8 +470,6 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_sub_u32 s62, s69, 1\n\t"
                 "s_lshl_b32 s70, 1, %[tshift]\n\t"
                 "s_sub_u32 s70, s70, 1\n\t"           // pixels per task - 1
-                "s_lshl_b32 s71, s69, 6\n\t"          // ring cells per batch
-                "s_sub_u32 s63, %[gw], 9\n\t"
                 "s_sub_u32 s64, %[gw], 10\n\t"
                 "s_mov_b32 s65, 0\n\t"               // 1: the batch is decoded part by part (see 27:)
                 "s_cmp_eq_u32 s69, 16\n\t"
@@ -507,9 +506,11 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "18:\n\t"
                 "ds_read_b32 v52, v51\n\t"
                 "ds_read_b32 %[top], v53\n\t"
+                "ds_read_b32 %[ring], v53 offset:520\n\t"
+                "ds_read_b32 %[goff], v53 offset:1040\n\t"
                 "ds_read_b64 v[40:41], v50\n\t"
                 "ds_read_b64 v[42:43], v50 offset:512\n\t"
-                "s_waitcnt lgkmcnt(3)\n\t"
+                "s_waitcnt lgkmcnt(5)\n\t"
                 "v_readfirstlane_b32 s58, v52\n\t"
                 "s_cmp_eq_u32 s58, s57\n\t"
                 "s_cbranch_scc1 13f\n\t"
@@ -690,9 +691,11 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "28:\n\t"
                 "ds_read_b32 v52, v51\n\t"
                 "ds_read_b32 %[top], v53\n\t"
+                "ds_read_b32 %[ring], v53 offset:520\n\t"
+                "ds_read_b32 %[goff], v53 offset:1040\n\t"
                 "ds_read_b64 v[40:41], v50\n\t"
                 "ds_read_b64 v[42:43], v50 offset:512\n\t"
-                "s_waitcnt lgkmcnt(3)\n\t"
+                "s_waitcnt lgkmcnt(5)\n\t"
                 "v_readfirstlane_b32 s58, v52\n\t"
                 "s_bitcmp1_b32 s58, s59\n\t"
                 "s_cbranch_scc1 27f\n\t"
@@ -889,6 +892,8 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_lshl_b32 s56, s55, %[bshift]\n\t"
                 "v_lshl_add_u32 v53, s56, 2, %[l4]\n\t"
                 "ds_read_b32 %[top], v53\n\t"
+                "ds_read_b32 %[ring], v53 offset:520\n\t"
+                "ds_read_b32 %[goff], v53 offset:1040\n\t"
                 "v_lshl_add_u32 v50, s56, 9, %[tabl]\n\t"
                 "ds_read_b64 v[40:41], v50\n\t"
                 "ds_read_b64 v[42:43], v50 offset:512\n\t"
@@ -899,10 +904,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_add_u32 s54, %[i], s69\n\t"
                 "s_cmp_le_u32 s54, s72\n\t"
                 "s_cbranch_scc0 25f\n\t"
-                "v_add_u32 %[ring], s71, %[ring]\n\t"
-                "v_and_b32 %[ring], %[rmask], %[ring]\n\t"
-                "v_add_u32 %[goff], %[gstride], %[goff]\n\t"
-                "s_waitcnt lgkmcnt(3)\n\t"          // the counter (the first of the four answers)
+                "s_waitcnt lgkmcnt(5)\n\t"          // the counter (the first of the six answers)
                 "v_readfirstlane_b32 s59, v54\n\t"
                 "s_cmp_eq_u32 s59, s73\n\t"
                 "s_cbranch_scc1 80b\n\t"
@@ -914,15 +916,12 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_cbranch_scc0 30f\n\t"
                 "s_add_u32 s54, %[i], s69\n\t"
                 "s_min_u32 s54, s54, %[n]\n\t"
-                "v_add_u32 %[ring], s71, %[ring]\n\t"
-                "v_and_b32 %[ring], %[rmask], %[ring]\n\t"
-                "v_add_u32 %[goff], %[gstride], %[goff]\n\t"
                 "24:\n\t"
                 "s_sub_u32 s58, s54, %[i]\n\t"
                 "s_add_u32 s57, s58, s70\n\t"
                 "s_lshr_b32 s57, s57, %[tshift]\n\t"
                 "s_bfm_b32 s57, s57, 0\n\t"
-                "s_waitcnt lgkmcnt(3)\n\t"          // the counter (the first of the four answers)
+                "s_waitcnt lgkmcnt(5)\n\t"          // the counter (the first of the six answers)
                 "v_readfirstlane_b32 s59, v54\n\t"
                 "s_cmp_eq_u32 s59, s57\n\t"
                 "s_cbranch_scc0 23f\n\t"
@@ -954,8 +953,6 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_cbranch_scc1 10f\n\t"
                 "s_add_u32 %[x0], %[x0], 1\n\t"
                 "s_cmp_eq_u32 %[x0], %[gw]\n\t"
-                "s_cselect_b32 s58, 64, 0\n\t"        // ring: one row down
-                "s_cselect_b32 s59, s63, 1\n\t"       // latent grid: + 1, past the edge + 1 + (W - 10)
                 "s_cselect_b32 %[x0], s64, %[x0]\n\t"
                 "s_cselect_b32 s60, 1, 0\n\t"
                 "s_sub_u32 %[hy], %[hy], s60\n\t"     // rows left below the step's first
@@ -966,13 +963,6 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_mul_i32 s72, %[n], s61\n\t"
                 "s_mov_b32 %[i], 0\n\t"
                 "s_min_u32 s54, s69, %[n]\n\t"
-                "v_add_u32 v52, 1, %[rbase]\n\t"
-                "v_bfi_b32 %[rbase], 63, v52, %[rbase]\n\t"   // column (c & 63) + 1
-                "v_add_u32 %[rbase], s58, %[rbase]\n\t"
-                "v_and_b32 %[rbase], %[rmask], %[rbase]\n\t"
-                "v_mov_b32 %[ring], %[rbase]\n\t"
-                "v_add_u32 %[gbase], s59, %[gbase]\n\t"
-                "v_mov_b32 %[goff], %[gbase]\n\t"
                 "s_branch 24b\n\t"
                 "10:\n\t"
                 "s_mov_b32 %[st], 0\n\t"
@@ -1003,12 +993,12 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 "s_waitcnt lgkmcnt(0)\n\t"
                 : [dst] "+s"(rc_dist), [rng] "+s"(rc_range), [i] "+s"(i), [seq] "+s"(seq), [raw] "+v"(raw), [top] "+v"(top_l),
                   [ring] "+v"(v_ring), [goff] "+v"(v_goff), [spins] "+s"(n_spins), [wpos] "+s"(word_pos), [st] "=s"(status), [kr] "=s"(k_rare),
-                  [n] "+s"(n_step), [x0] "+s"(step_x0), [hy] "+s"(step_hy), [cleft] "+s"(steps_left), [rbase] "+v"(v_rbase), [gbase] "+v"(v_gbase),
+                  [n] "+s"(n_step), [x0] "+s"(step_x0), [hy] "+s"(step_hy), [cleft] "+s"(steps_left),
                   [pix0] "+s"(pix0), [npart] "+s"(n_part)
                 : [mode] "s"(mode), [gw] "s"(static_cast<uint32_t>(grid_w)), [smask] "s"(static_cast<uint32_t>(slot_mask)),
                   [bshift] "s"(bpx_shift), [tshift] "s"(static_cast<uint32_t>(task_shift)),
-                  [rdy] "v"(ready_base), [zero] "v"(0u), [rmask] "s"(ring_cells_mask),
-                  [gstride] "s"(glo_stride), [wbuf] "v"(wbuf), [wbase] "s"(wbase), [tabl] "v"(tab_lane), [lane] "v"(static_cast<uint32_t>(lane)),
+                  [rdy] "v"(ready_base), [zero] "v"(0u),
+                  [wbuf] "v"(wbuf), [wbase] "s"(wbase), [tabl] "v"(tab_lane), [lane] "v"(static_cast<uint32_t>(lane)),
                   [l4] "v"(lane_top_off), [lat] "s"(lat_addr)
                 : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
                   "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60");
@@ -1517,6 +1507,11 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                     }
                     lt_b = LPROF_T(pw == 0);
                     const unsigned long long t_g = PROF_T();
+                    {   // where the decoder puts the pixel's symbol (RowMeta::cell / goff)
+                        const int mi = (g == 0 && live) ? slot * kBpx + half * kTaskPix + n : kRows;
+                        meta.cell[mi] = static_cast<uint32_t>(((y & ring_mask) << 6) | ((x + 10 * y) & 63));
+                        meta.goff[mi] = static_cast<uint32_t>(y * W + x);
+                    }
                     // ---- B operand of the first layer: context k = g + 4 t at byte t, the two features at bytes 8..11
                     uint32_t w0 = 0, w1 = 0;
 #pragma unroll
@@ -1681,6 +1676,11 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                 }
                 lt_b = LPROF_T(pw == 0);
                 const unsigned long long t_g = PROF_T();
+                {   // where the decoder puts the pixel's symbol (RowMeta::cell / goff): position only, so it is written here
+                    const int mi = (q == 0 && px < cnt) ? slot * kBpx + half * kTaskPix + px : kRows;
+                    meta.cell[mi] = static_cast<uint32_t>(((y & ring_mask) << 6) | ((x + 10 * y) & 63));
+                    meta.goff[mi] = static_cast<uint32_t>(y * W + x);
+                }
                 // ---- entries 16..63 of the task's table rows: lower sentinels of a narrow window (P = 0).  Written now, off the
                 // late path: a row that turns out wide overwrites all 64 entries later.  cnt rows x 24 16-byte stores.
                 {

@@ -143,7 +143,7 @@ def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False, 
                 q("v_readfirstlane_b32 s58, v54"),
                 q("s_cmp_eq_u32 s59, 16"), q("s_cbranch_scc0 %df" % (label0 + n + 1)),
                 q("s_bitcmp1_b32 s58, 1"), q("s_cbranch_scc0 %df" % (label0 + n + 1)),
-                q("ds_read_b32 %[top], v53"), q("s_mov_b32 s65, 0"), q("s_mov_b32 s54, s66"), q("s_branch 308b"),
+                q("ds_read_b32 %[top], v53"), q("ds_read_b32 %[ring], v53 offset:520"), q("ds_read_b32 %[goff], v53 offset:1040"), q("s_mov_b32 s65, 0"), q("s_mov_b32 s54, s66"), q("s_branch 308b"),
                 q("%d:" % (label0 + n + 1)),
                 q("s_mov_b64 s[52:53], %s" % pair(RP[n % 3])), q("s_add_u32 %%[i], %%[i], %d" % n), q("s_mov_b32 s67, %[i]"), q("s_branch 126b")]
         return out
