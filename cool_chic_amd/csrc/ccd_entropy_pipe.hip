@@ -396,6 +396,7 @@ struct StepIter {
     int H, W, raster, n_steps;
     int c, y0, x0, n;
     __device__ void init(int h, int w) { H = h; W = w; raster = w <= 9; n_steps = raster ? h * w : w + 10 * (h - 1); c = -1; }
+    __device__ bool seek(int step) { c = step - 1; return next(); }
     __device__ bool next() {
         if (++c >= n_steps) return false;
         if (raster) { y0 = c / W; x0 = c - y0 * W; n = 1; }
@@ -405,6 +406,37 @@ struct StepIter {
             n = min(H - y0, x0 / 10 + 1);
         }
         return true;
+    }
+};
+
+// ---- The BODY of a wide grid as one stream of pixels (r04).  Steps of the wavefront order are independent of batch boundaries as
+// soon as a pixel's left neighbour (same index in the previous step) lies at least a task + a batch behind it in decoding order,
+// i.e. for steps of >= 18 pixels.  So the steps [first, end) whose length is >= kStreamMinStep - 1 - all of a grid but the ramps at
+// its two corners - are cut into 16-pixel batches / 8-pixel tasks WITHOUT regard to step ends: every batch but the last is full
+// (the unrolled block), no 3-pixel tail batch and no step hand-over per step, 6.4 instead of 7 tasks per step of a portrait
+// Kodak picture.  A task then holds pixels of up to two steps (per-lane position select), the decoder sees ONE step of n_body
+// symbols (it takes each pixel's ring cell and latent offset from the row meta the producers write).
+//   ramp-up:  steps c < first = 10 (T - 1): y0 = 0, n = c / 10 + 1 < T, together 5 T (T - 1) pixels;
+//   ramp-down: steps c >= end = W + 10 (H - T): fewer than T rows left, again 5 T (T - 1) pixels (the mirror image);
+//   in between n = min(H - y0, x0 / 10 + 1) >= T - 1 (x0 >= W - 10 >= 10 (T - 1) - 9 behind the first row).
+#ifndef CCD_STREAM_MIN_STEP
+#define CCD_STREAM_MIN_STEP 24
+#endif
+constexpr uint32_t kStreamMinStep = CCD_STREAM_MIN_STEP;
+struct StreamBody {
+    uint32_t first, end, n_pix, pix_before;  // steps [first, end), pixels of the body, pixels of the grid in front of it
+    bool on;
+    __device__ void init(uint32_t H, uint32_t W, int task_pix) {
+        const uint32_t T = kStreamMinStep;
+#if CCD_BPX_WIDE == 16 && !defined(CCD_NO_STREAM_BODY)
+        on = task_pix == 8 && W > 10u * (T - 1u) && H >= T;
+#else
+        on = false;
+#endif
+        first = 10u * (T - 1u);
+        end = on ? W + 10u * (H - T) : 0u;
+        pix_before = 5u * T * (T - 1u);
+        n_pix = on ? H * W - 2u * pix_before : 0u;
     }
 };
 
@@ -445,15 +477,29 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     uint32_t n_spins = 0;    // polls of a ready counter inside the asm region (profile builds report them)
     uint32_t pix0 = uni(C.px_base);  // pixels of the stream decoded before the current step (the asm region counts on)
     uint32_t n_part = 0;             // batches decoded part by part
-    while (ok && it.next()) {
+    StreamBody body;
+    body.init(static_cast<uint32_t>(it.H), static_cast<uint32_t>(it.W), task_pix);
+    // segments of the grid: a step of a raster-order grid; else all steps - or, around a streamed body (StreamBody), the steps in
+    // front of it, the body as ONE step of n_pix symbols, the steps behind it
+    int seg_c = 0;
+    while (ok && seg_c < it.n_steps) {
+        int seg_steps = it.raster ? 1 : it.n_steps;
+        bool seg_body = false;
+        if (body.on) {
+            if (seg_c < static_cast<int>(body.first)) seg_steps = static_cast<int>(body.first) - seg_c;
+            else if (seg_c == static_cast<int>(body.first)) { seg_body = true; seg_steps = static_cast<int>(body.end - body.first); }
+            else seg_steps = it.n_steps - seg_c;
+        }
+        it.seek(seg_c);
+        seg_c += seg_steps;
         // ---- one wavefront step = one asm region: per batch the ready check, the symbol loop (hand-scheduled recurrence, see
         // the file header) and the epilogue (symbols -> LDS ring + latent grid, slot handed back, progress published) without
         // returning to compiled code.  It leaves early for a symbol whose new range has a zero high word (renormalisation,
         // window miss, invalid data: status 1, handled below, then re-entered) and for a batch that is not ready (status 2).
         // The region walks the remaining steps of a wavefront-ordered grid itself (label 30); `it` only sets it up.  A grid
         // narrower than 10 (raster order, one pixel per step) comes back after every step.
-        uint32_t n_step = static_cast<uint32_t>(it.n), step_x0 = static_cast<uint32_t>(it.x0), step_hy = static_cast<uint32_t>(it.H - it.y0);
-        uint32_t steps_left = it.raster ? 1u : static_cast<uint32_t>(it.n_steps - it.c);
+        uint32_t n_step = seg_body ? uni(body.n_pix) : static_cast<uint32_t>(it.n), step_x0 = static_cast<uint32_t>(it.x0), step_hy = static_cast<uint32_t>(it.H - it.y0);
+        uint32_t steps_left = (it.raster || seg_body) ? 1u : static_cast<uint32_t>(seg_steps);
         uint32_t i = 0, mode = 0;
         // lane p <-> pixel p of the current batch: LDS address of its ring cell, its byte in the latent grid (RowMeta::cell / goff,
         // read with the batch's top symbols)
@@ -1002,10 +1048,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                   [l4] "v"(lane_top_off), [lat] "s"(lat_addr)
                 : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
                   "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60");
-            if (status == 0) {
-                if (!it.raster) it.c = it.n_steps;  // every step of the grid is done
-                break;
-            }
+            if (status == 0) break;  // every step of the segment is done
             if (status == 3) {  // the region renormalised with the last buffered payload word: refill, resume inside the batch
                 wbase = word_pos;
                 wbuf = (wbase + lane < n_words) ? words_g[wbase + lane] : 0u;
@@ -1430,12 +1473,20 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
     // a producer visits only its own tasks (first owned one of the step, then every kProducers-th).
     uint32_t phase = static_cast<uint32_t>((static_cast<unsigned long long>(seq_base) * kHalves) % kProducers);  // (seq0 kHalves) mod kProducers
     const bool split = k_left >= 0 && W > 9 && n_layers >= 2;  // (not in raster order)
+    StreamBody body;
+    body.init(it.H, it.W, kTaskPix);
+    const uint32_t n_steps_total = it.left;
+    // leaves step `it` for the next one (the bookkeeping of the dependencies: where the previous two steps begin in the stream)
+    const auto walk_on = [&]() { prev2_pix0 = prev_pix0; prev_pix0 = pix0; pix0 += it.n; prev_moved = it.moved; it.next(); };
     while (it.next()) {
-        const uint32_t nb = (it.n + kBpx - 1) >> kBpxShift;
-        const uint32_t n_tasks = (it.n + kTaskPix - 1) >> kTaskShift;
+        // a SEGMENT of the grid: one step - or the streamed body (StreamBody: the steps [first, end) cut into tasks without regard to
+        // step ends) as one "step" of body.n_pix pixels, during which `it` follows the tasks through the body's steps
+        const bool seg_body = body.on && n_steps_total - 1u - it.left == body.first;
+        const uint32_t seg_n = seg_body ? body.n_pix : it.n;
+        const uint32_t seg_pix0 = pix0;
+        const uint32_t nb = (seg_n + kBpx - 1) >> kBpxShift;
+        const uint32_t n_tasks = (seg_n + kTaskPix - 1) >> kTaskShift;
         const uint32_t seq0 = seq;
-        const uint32_t dy1 = it.moved, dy2 = it.moved + prev_moved;
-        const uint32_t prev_n = pix0 - prev_pix0, prev2_n = prev_pix0 - prev2_pix0;
         uint32_t t_first = static_cast<uint32_t>(pw) - phase;
         t_first += static_cast<int32_t>(t_first) < 0 ? kProducers : 0;
         {
@@ -1444,9 +1495,23 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                 const int half = static_cast<int>(task & (kHalves - 1));
                 seq = seq0 + j;
                 const int slot = static_cast<int>(seq & (kNSlots - 1));
-                const int i0 = static_cast<int>(task << kTaskShift);   // first pixel of the task within the step
-                const int cnt = min(kTaskPix, static_cast<int>(it.n) - i0);
-                const int y = static_cast<int>(it.y0) + i0 + px, x = static_cast<int>(it.x0) - 10 * (i0 + px);
+                const int i0 = static_cast<int>(task << kTaskShift);   // first pixel of the task within the segment
+                const int cnt = min(kTaskPix, static_cast<int>(seg_n) - i0);
+                // Where the task's pixels are: `n_a` of them in step `it` from index `ia` on, the others (streamed body only) at the
+                // head of the step behind it.
+                if (seg_body) {
+                    while (seg_pix0 + static_cast<uint32_t>(i0) >= pix0 + it.n) walk_on();
+                }
+                const uint32_t ia = seg_body ? seg_pix0 + static_cast<uint32_t>(i0) - pix0 : static_cast<uint32_t>(i0);
+                const uint32_t n_a = seg_body ? min(static_cast<uint32_t>(cnt), it.n - ia) : static_cast<uint32_t>(kTaskPix);
+                uint32_t bx0 = it.x0 + 1u, by0 = it.y0;
+                const uint32_t b_moved = bx0 == static_cast<uint32_t>(W) ? 1u : 0u;
+                if (b_moved) { bx0 = static_cast<uint32_t>(W) - 10u; ++by0; }
+                const bool in_b = seg_body && static_cast<uint32_t>(px) >= n_a;
+                const int ii = in_b ? px - static_cast<int>(n_a) : static_cast<int>(ia) + px;
+                const int y = static_cast<int>(in_b ? by0 : it.y0) + ii, x = static_cast<int>(in_b ? bx0 : it.x0) - 10 * ii;
+                const uint32_t dy1 = it.moved, dy2 = it.moved + prev_moved;
+                const uint32_t prev_n = pix0 - prev_pix0, prev2_n = prev_pix0 - prev2_pix0;
                 // ---- IFCE features do not depend on this grid: REQUEST them before waiting on the decoder, use them in the gather.
                 // (r04: the selects stood right behind the loads, so every task began with s_waitcnt vmcnt(0) - an L2 round trip of
                 // ~700 ticks on the path between two tasks.  The raw values now stay untouched until the gather, behind the early
@@ -1478,9 +1543,12 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                 // Both waits are in pixels of the stream (the decoder publishes in decoding order: a published pixel vouches
                 // for every earlier step); the first one also wants the slot's previous batch gone (table / meta rows free again).
                 const uint32_t need_slot = seq >= static_cast<uint32_t>(kNSlots) ? seq - kNSlots + 1 : 0;
-                const uint32_t last1 = static_cast<uint32_t>(i0 + cnt);  // pixels of the step up to the task's last one
-                const uint32_t need_px = prev_pix0 + min(last1 + dy1, prev_n);         // ... the left neighbours
-                const uint32_t need_early_px = prev2_pix0 + min(last1 + dy2, prev2_n);  // ... the pixels two to the left
+                // (the task's LAST pixel decides: index `last1 - 1` of step `it`, or - a task that reaches into the next step - of that one)
+                const bool ends_in_b = seg_body && n_a < static_cast<uint32_t>(cnt);
+                const uint32_t last1 = ends_in_b ? static_cast<uint32_t>(cnt) - n_a : ia + static_cast<uint32_t>(cnt);
+                const uint32_t need_px = ends_in_b ? pix0 + min(last1 + b_moved, it.n) : prev_pix0 + min(last1 + dy1, prev_n);  // ... the left neighbours
+                const uint32_t need_early_px = ends_in_b ? prev_pix0 + min(last1 + b_moved + dy1, prev_n)
+                                                         : prev2_pix0 + min(last1 + dy2, prev2_n);                        // ... the pixels two to the left
                 unsigned long long lt_a = 0, lt_b = 0, lt_c = 0, lt_d = 0;  // level-2 profile stamps
                 (void)lt_a; (void)lt_b; (void)lt_c; (void)lt_d;
                 unsigned narrow_mask = 0;  // matrix-core path: bit i: pixel i of the task is narrow (wave-uniform)
@@ -1921,7 +1989,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                         A.W = W; A.fin = fin; A.fw = fw; A.feat_plane = feat_plane; A.ring_mask = ring_mask; A.fstride = fstride;
                         asm volatile("" : "+s"(A.P), "+s"(A.s_w), "+s"(A.s_b), "+s"(A.s_ring), "+s"(A.n_w_hidden), "+s"(A.dim), "+s"(A.n_layers));
                         asm volatile("" : "+s"(A.n_sp), "+s"(A.W), "+s"(A.fin), "+s"(A.fw), "+s"(A.feat_plane), "+s"(A.ring_mask), "+s"(A.fstride));
-                        const ExactOut r = exact_pixel(A, static_cast<int>(it.y0) + i0 + p, static_cast<int>(it.x0) - 10 * (i0 + p));
+                        const ExactOut r = exact_pixel(A, __builtin_amdgcn_readlane(y, MF ? p : p * kLpp), __builtin_amdgcn_readlane(x, MF ? p : p * kLpp));
                         if (px == p && q < 2) {
                             const int64_t off = ((q == 0 ? r.mu : r.ls) >> 24) + (q == 0 ? kMuOffset : kScaleOffset);
                             const int64_t hi = q == 0 ? kNumMu - 1 : kNumScale - 1;
@@ -2083,6 +2151,9 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
         }
         seq = seq0 + nb;
         phase = (phase + nb * kHalves) % kProducers;
+        if (seg_body) {  // on to the body's last step: the lines below leave it like any step
+            while (n_steps_total - it.left < body.end) walk_on();
+        }
         prev2_pix0 = prev_pix0;
         prev_pix0 = pix0;
         pix0 += it.n;
