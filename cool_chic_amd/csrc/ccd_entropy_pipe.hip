@@ -430,6 +430,14 @@ struct StreamBody {
         const uint32_t T = kStreamMinStep;
 #if CCD_BPX_WIDE == 16 && !defined(CCD_NO_STREAM_BODY)
         on = task_pix == 8 && W > 10u * (T - 1u) && H >= T;
+#ifndef CCD_STREAM_EVERY_WIDE_GRID
+        {   // where it pays: long steps (the decoder is the limit: its per-step costs go away) or steps whose last task is mostly empty.
+            // Elsewhere - 39-pixel steps = 8 + 8 + 8 + 8 + 7 - the tasks of step-aligned batches wait for ONE earlier task each instead
+            // of two (profiles/r04/ab_entropy_stream.txt: grid 1 of a landscape Kodak picture 16.8 -> 17.3 M ticks when streamed).
+            const uint32_t n_pl = (W - 1u) / 10u + 1u, tail = n_pl & 7u;
+            on = on && (n_pl >= 48u || (tail >= 1u && tail <= 4u));
+        }
+#endif
 #else
         on = false;
 #endif
@@ -2448,6 +2456,17 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         P.status[1] = static_cast<int32_t>(S.word_pos);
 #ifndef CCD_PIPE_PROFILE
         P.status[37] = static_cast<int32_t>(S.n_part_batches);  // batches the decoder took part by part (tests)
+        {   // grids whose body ran as one stream of pixels (StreamBody; tests)
+            int n_streamed = 0;
+            for (int g2 = 0; g2 < P.n_grids; ++g2) {
+                const int gh = P.grid_h[g2], gw = P.grid_w[g2];
+                const int n_max = gw <= 9 ? 1 : min(gh, (gw - 1) / 10 + 1);
+                StreamBody sb;
+                sb.init(static_cast<uint32_t>(gh), static_cast<uint32_t>(gw), n_max >= CCD_T8 ? 8 : (n_max >= CCD_T4 ? 4 : 2));
+                n_streamed += sb.on ? 1 : 0;
+            }
+            P.status[36] = n_streamed;
+        }
 #endif
         {   // symbols decoded = all grids unless aborted
             uint64_t n_sym = 0;

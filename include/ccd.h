@@ -143,9 +143,10 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage);
 int ccd_batch_wait(ccd_batch* b, void* stream);
 int ccd_batch_slot_status(const ccd_batch* b, int slot);
 /* Raw per-slot counters of the entropy kernel after ccd_batch_wait: [0] status, [1] payload words read,
- * [2..3] symbols decoded (lo, hi); [37] batches the pipelined kernel's decoder took part by part; [39] pixels the pipelined
- * kernel redid in int64 (dynamic operand check); the other words [4..63] are profiling cycle counters when built with
- * -DCCD_PIPE_PROFILE (which also reuses [37]).
+ * [2..3] symbols decoded (lo, hi); [36] latent grids whose body the pipelined kernel decoded as one stream of pixels
+ * (batches cut without regard to wavefront steps: DESIGN.md 4.1); [37] batches its decoder took part by part; [39] pixels it
+ * redid in int64 (dynamic operand check); the other words [4..63] are profiling cycle counters when built with
+ * -DCCD_PIPE_PROFILE (which also reuses [36] and [37]).
  * `out64` receives 64 words. */
 int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64);
 /* Which kernels serve this slot: bit 0 = pipelined entropy kernel (else the generic int64 one),

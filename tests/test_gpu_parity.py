@@ -570,6 +570,51 @@ def test_ragged_picture_sizes(gpu, oracle, donor_name, sizes):
         b.close()
 
 
+@pytest.mark.parametrize("donor_name,sizes", [
+    # grid 0 = the picture: streamed when its longest step ((W - 1) // 10 + 1 pixels) has >= 48 pixels or ends in a task of 1..4
+    # pixels, W > 230, H >= 25 (8-pixel tasks).  The body then is steps [230, W + 10 (H - 24)):
+    ("kodim14", [(25, 241), (25, 250), (40, 271), (33, 480), (64, 521), (300, 241), (57, 332)]),
+    # ... and grid 1 (half size) as well: 40 x 250 / 45 x 261
+    ("kodim14", [(80, 500), (90, 522)]),
+    ("yuv420_8b", [(48, 482)]),
+])
+def test_streamed_body_geometry(gpu, oracle, donor_name, sizes):
+    """The body of a wide grid runs as ONE stream of pixels (ccd_entropy_pipe.hip: StreamBody - batches and tasks cut without
+    regard to wavefront steps, a task may hold pixels of two steps): sizes around every bound of that rule - the smallest width
+    and height, bodies of a few steps, step lengths whose tail is 1, 2, 4 pixels, both the picture's and the half-size grid.
+    Streams: the donor's trained networks, seeded random latents, written with the bitstream writer; latents and integer planes
+    bit-exact against the oracle; stats word 36 says how many grids were streamed."""
+    from cool_chic_amd import writer
+
+    bs, z, j = load_golden(donor_name)
+    (fh, ccs), = oracle.split_stream(bs)[1]
+    hdr, nn, _ = ccs[0]
+    donor = writer.parse_cc_header(hdr)
+    rng = np.random.default_rng(20240927)
+    streams, lat_in = [], []
+    for (h, w) in sizes:
+        arch = writer.derive_arch(donor, img_size=(h, w))
+        assert writer.network_layout(arch) == writer.network_layout(donor)
+        lat = [np.clip(np.rint(rng.laplace(0.0, 1.0 + 0.3 * g, size=(arch.grid_h[g], arch.grid_w[g]))), -30, 30).astype(np.int8)
+               for g in range(arch.n_grids)]
+        streams.append(writer.encode_stream(writer.cc_header_bytes(arch), nn, lat, bitdepth=fh.bitdepth, frame_data_type=fh.frame_data_type))
+        lat_in.append(lat)
+    triples = [oracle.split_stream(s)[1][0][1][0] for s in streams]
+    b = _decode(gpu, triples, fh.bitdepth, fh.frame_data_type)
+    try:
+        for i, (s, lat) in enumerate(zip(streams, lat_in)):
+            assert b.slot_status(i) == 0
+            assert b.slot_kernels(i) & 1
+            assert b.slot_stats(i)[36] >= 1, f"size {sizes[i]}: no grid was streamed"
+            for g, a in enumerate(lat):
+                assert np.array_equal(b.latent(i, g), a), f"size {sizes[i]} grid {g}"
+            want = oracle.decode_video(s)[0]["planes"]
+            for p_, (got, w_) in enumerate(zip(b.planes(i), want)):
+                assert got.shape == w_.shape and np.array_equal(got.astype(np.uint16), w_), f"size {sizes[i]} plane {p_}"
+    finally:
+        b.close()
+
+
 def test_repeated_runs_are_identical(gpu, oracle):
     """The pipelined entropy kernel hands work between waves through LDS flags; a lost or early hand-over would show as a
     run-to-run difference.  One batch (kodim14 twice + the small fixtures), twenty runs, every latent and plane equal."""
