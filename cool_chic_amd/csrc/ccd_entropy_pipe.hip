@@ -57,12 +57,12 @@ namespace ccd {
 #define LPROF_T(cond) 0ull
 #endif
 // -DCCD_PIPE_PROFILE=2 -DCCD_PIPE_TRACE: EVERY producer stamps its tasks, and the tasks of the grid whose width is g_trace_cfg[0],
-// 512 steps from "g_trace_cfg[1] steps left" on, are written out as records of 8 words (tools/trace_tasks.py draws the
+// 64 steps from "g_trace_cfg[1] steps left" on, are written out as records of 8 words (tools/trace_tasks.py draws the
 // time line of a few steps from them: which hand-over a step of a chain-bound grid waits for).  One stream per launch.
 // The records are collected in LDS (32 bytes each, behind the kernel's own regions) and copied out when the kernel ends: a global
 // store per task put every producer behind a vmcnt wait of ~2 k ticks.
 #if defined(CCD_PIPE_TRACE)
-constexpr int kTraceTasks = 1024;
+constexpr int kTraceTasks = 512;  // (16 KB: the kernel's own regions take ~128 KB of the 160)
 constexpr uint32_t kTraceLdsBytes = kTraceTasks * 32u;
 __device__ unsigned int g_trace[kTraceTasks * 8];
 __device__ unsigned int g_trace_cfg[2];
@@ -429,7 +429,7 @@ struct StreamBody {
     __device__ void init(uint32_t H, uint32_t W, int task_pix) {
         const uint32_t T = kStreamMinStep;
 #if CCD_BPX_WIDE == 16 && !defined(CCD_NO_STREAM_BODY)
-        on = task_pix == 8 && W > 10u * (T - 1u) && H >= T;
+        on = task_pix == 8 && W > 10u * (T - 1u) && H >= T;  // (4-pixel tasks streamed: measured slower, profiles/r04/ab_entropy_stream.txt)
 #ifndef CCD_STREAM_EVERY_WIDE_GRID
         {   // where it pays: long steps (the decoder is the limit: its per-step costs go away) or steps whose last task is mostly empty.
             // Elsewhere - 39-pixel steps = 8 + 8 + 8 + 8 + 7 - the tasks of step-aligned batches wait for ONE earlier task each instead
@@ -2139,10 +2139,10 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                 {
                     const unsigned long long lt_e = __builtin_amdgcn_s_memtime();
                     const uint32_t gidx = seq0 * kHalves + task;
-                    if (lane == 0 && static_cast<uint32_t>(W) == uni(g_trace_cfg[0]) && uni(g_trace_cfg[1]) - it.left < 256u) {
+                    if (lane == 0 && static_cast<uint32_t>(W) == uni(g_trace_cfg[0]) && uni(g_trace_cfg[1]) - it.left < 64u) {
                         typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                                                 u32x4* r = reinterpret_cast<u32x4*>(ccd_pipe_smem + C.trace_off + (gidx % kTraceTasks) * 32u);
-                        const u32x4 r0 = {(it.left << 12) | (task << 8) | (static_cast<uint32_t>(pw) << 4) | static_cast<uint32_t>(cnt), static_cast<uint32_t>(lt_a),
+                        const u32x4 r0 = {(it.left << 12) | ((task & 15u) << 8) | (static_cast<uint32_t>(pw) << 4) | static_cast<uint32_t>(cnt), static_cast<uint32_t>(lt_a),
                                           static_cast<uint32_t>(lt_b), static_cast<uint32_t>(lt_c)};
                         const u32x4 r1 = {static_cast<uint32_t>(lt_d), static_cast<uint32_t>(lt_e), need_px - pix0, static_cast<uint32_t>(lt_a >> 32)};
                         r[0] = r0; r[1] = r1;
@@ -2414,7 +2414,7 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         if (wave == 0) {
             __builtin_amdgcn_s_setprio(3);
 #ifdef CCD_PIPE_PROFILE
-            const unsigned long long w0 = S.prof_wait, k0 = S.prof_work;
+            const unsigned long long k0 = S.prof_work;
             const unsigned long long g_t0 = __builtin_amdgcn_s_memtime(), sp0 = S.n_spins, se0 = S.stall_events;
 #endif
             seq_end = decoder_grid<MF>(C, S);

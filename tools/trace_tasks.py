@@ -33,9 +33,10 @@ tp = 8 if n_max >= 25 else (4 if n_max >= 9 else 2)
 total_steps = w + 10 * (h - 1)
 assert L.ccd_debug_trace_config(w, total_steps - 1 - step0) == 0
 b.run(stage=0); b.wait()
-buf = np.zeros(1024 * 8, np.uint32)
+buf = np.zeros(512 * 8, np.uint32)
 assert L.ccd_debug_trace_read(buf.ctypes.data) == 0
 rec = buf.reshape(-1, 8)
+assert b.slot_kernels(0) & 1, 'the pipelined kernel did not serve the stream'
 rows = []
 for r in rec:
     if r[5] == 0: continue
