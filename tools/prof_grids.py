@@ -19,7 +19,7 @@ hdr = b.header(0)
 st = np.zeros(64, np.int32)
 lib().ccd_batch_slot_stats(b._h, 0, st.ctypes.data)
 u = st[4:24].view(np.uint64)
-print(f"stream {idx}: decoder total {int(u[0]) / 1e6:.1f} Mticks; rare-path symbols {st[62]}, full searches {st[63]}")
+print(f"stream {idx}: rare-path symbols {st[62]}, full searches {st[63]}")
 tot = 0
 for g in range(min(4, hdr.n_grids)):
     h, w = b.latent(0, g).shape[-2:]
