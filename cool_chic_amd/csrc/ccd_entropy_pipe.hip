@@ -22,6 +22,12 @@
 //   * a lone wave issues in order, so every instruction between two symbols lengthens the chain: a full
 //     16-symbol batch runs an unrolled copy of the symbol loop without index arithmetic, bound test or branch,
 //     and the decoder stays inside ONE asm region for a whole grid (batch hand-over, step advance, renormalisation);
+//   * batches are not tied to wavefront steps: the body of a wide grid (all steps of >= 23 pixels) is cut into 16-pixel batches /
+//     8-pixel tasks as ONE stream of pixels (StreamBody), so every batch is full, there is no short tail batch and no step
+//     hand-over; a task may hold pixels of two steps, and the decoder takes each pixel's ring cell and latent-grid offset
+//     from the row meta its producer wrote (RowMeta::cell / goff) instead of keeping a geometry of its own;
+//   * a batch whose parts arrive one by one is decoded part by part through unrolled 8- / 4-symbol blocks (ccd_dec_parts*.inc),
+//     and every look at a ready word brings the part's top symbols and first rows along;
 //   * between grids the whole workgroup computes the IFCE features of the next grid (loads requested a
 //     position ahead through explicit global pointers, straight-line body: see the notes there);
 //   * optionally (EntropyParams::mfma, off by default: measured slower) the ARM's layers of 8-pixel tasks run
