@@ -1490,8 +1490,14 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
     StreamBody body;
     body.init(it.H, it.W, kTaskPix);
     const uint32_t n_steps_total = it.left;
-    // leaves step `it` for the next one (the bookkeeping of the dependencies: where the previous two steps begin in the stream)
-    const auto walk_on = [&]() { prev2_pix0 = prev_pix0; prev_pix0 = pix0; pix0 += it.n; prev_moved = it.moved; it.next(); };
+    // leaves step `it` for the next one INSIDE a streamed body (wavefront order, not the last step: straight-line code, no test of
+    // the grid's kind or end), with the bookkeeping of the dependencies: where the previous two steps begin in the stream
+    const auto walk_on = [&]() {
+        prev2_pix0 = prev_pix0; prev_pix0 = pix0; pix0 += it.n; prev_moved = it.moved;
+        const uint32_t nx = it.x0 + 1u, mv = nx == it.W ? 1u : 0u;
+        it.x0 = mv ? it.W - 10u : nx; it.y0 += mv; it.moved = mv; --it.left;
+        it.n = min(it.H - it.y0, ((it.x0 * 0xcccdu) >> 19) + 1u);
+    };
     while (it.next()) {
         // a SEGMENT of the grid: one step - or the streamed body (StreamBody: the steps [first, end) cut into tasks without regard to
         // step ends) as one "step" of body.n_pix pixels, during which `it` follows the tasks through the body's steps
@@ -1512,16 +1518,14 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                 const int i0 = static_cast<int>(task << kTaskShift);   // first pixel of the task within the segment
                 const int cnt = min(kTaskPix, static_cast<int>(seg_n) - i0);
                 // Where the task's pixels are: `n_a` of them in step `it` from index `ia` on, the others (streamed body only) at the
-                // head of the step behind it.
-                if (seg_body) {
-                    while (seg_pix0 + static_cast<uint32_t>(i0) >= pix0 + it.n) walk_on();
-                }
-                const uint32_t ia = seg_body ? seg_pix0 + static_cast<uint32_t>(i0) - pix0 : static_cast<uint32_t>(i0);
-                const uint32_t n_a = seg_body ? min(static_cast<uint32_t>(cnt), it.n - ia) : static_cast<uint32_t>(kTaskPix);
-                uint32_t bx0 = it.x0 + 1u, by0 = it.y0;
-                const uint32_t b_moved = bx0 == static_cast<uint32_t>(W) ? 1u : 0u;
-                if (b_moved) { bx0 = static_cast<uint32_t>(W) - 10u; ++by0; }
-                const bool in_b = seg_body && static_cast<uint32_t>(px) >= n_a;
+                // head of the step behind it.  The same lines serve a step-aligned segment: there `it` is the segment, the loop never
+                // runs, ia = i0 and n_a = cnt - no test of the segment's kind on the path between two tasks.
+                while (seg_pix0 + static_cast<uint32_t>(i0) >= pix0 + it.n) walk_on();
+                const uint32_t ia = seg_pix0 + static_cast<uint32_t>(i0) - pix0;
+                const uint32_t n_a = min(static_cast<uint32_t>(cnt), it.n - ia);
+                const uint32_t bx1 = it.x0 + 1u, b_moved = bx1 == static_cast<uint32_t>(W) ? 1u : 0u;
+                const uint32_t bx0 = b_moved ? static_cast<uint32_t>(W) - 10u : bx1, by0 = it.y0 + b_moved;
+                const bool in_b = static_cast<uint32_t>(px) >= n_a;  // (also the lanes behind the task's last pixel: unused)
                 const int ii = in_b ? px - static_cast<int>(n_a) : static_cast<int>(ia) + px;
                 const int y = static_cast<int>(in_b ? by0 : it.y0) + ii, x = static_cast<int>(in_b ? bx0 : it.x0) - 10 * ii;
                 const uint32_t dy1 = it.moved, dy2 = it.moved + prev_moved;
@@ -1558,7 +1562,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
                 // for every earlier step); the first one also wants the slot's previous batch gone (table / meta rows free again).
                 const uint32_t need_slot = seq >= static_cast<uint32_t>(kNSlots) ? seq - kNSlots + 1 : 0;
                 // (the task's LAST pixel decides: index `last1 - 1` of step `it`, or - a task that reaches into the next step - of that one)
-                const bool ends_in_b = seg_body && n_a < static_cast<uint32_t>(cnt);
+                const bool ends_in_b = n_a < static_cast<uint32_t>(cnt);
                 const uint32_t last1 = ends_in_b ? static_cast<uint32_t>(cnt) - n_a : ia + static_cast<uint32_t>(cnt);
                 const uint32_t need_px = ends_in_b ? pix0 + min(last1 + b_moved, it.n) : prev_pix0 + min(last1 + dy1, prev_n);  // ... the left neighbours
                 const uint32_t need_early_px = ends_in_b ? prev_pix0 + min(last1 + b_moved + dy1, prev_n)
