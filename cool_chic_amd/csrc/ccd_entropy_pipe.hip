@@ -429,6 +429,7 @@ struct StepIter {
 #define CCD_STREAM_MIN_STEP 24
 #endif
 constexpr uint32_t kStreamMinStep = CCD_STREAM_MIN_STEP;
+static_assert(kStreamMinStep >= 19, "a streamed task must find its left neighbours in an EARLIER batch: steps of >= 18 pixels");
 struct StreamBody {
     uint32_t first, end, n_pix, pix_before;  // steps [first, end), pixels of the body, pixels of the grid in front of it
     bool on;
