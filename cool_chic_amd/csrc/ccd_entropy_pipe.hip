@@ -395,6 +395,20 @@ struct StepWalk {
         n = raster ? 1u : min(H - y0, ((x0 * 0xcccdu) >> 19) + 1u);  // x0 / 10 + 1 (exact below 43699)
         return true;
     }
+    // length of step c / whether its start lies a row below step c - 1's (wavefront order)
+    __device__ uint32_t len_of(uint32_t c) const {
+        const uint32_t yy = c < W ? 0u : (c - W) / 10u + 1u, xx = c < W ? c : W - 10u + (c - W) % 10u;
+        return min(H - yy, xx / 10u + 1u);
+    }
+    __device__ uint32_t moved_at(uint32_t c) const { return (c >= W && (c - W) % 10u == 0u) ? 1u : 0u; }
+    // the state of step c - 1 (c >= 1, wavefront order): next() then arrives at step c
+    __device__ void seek_before(uint32_t c) {
+        const uint32_t p = c - 1u;
+        y0 = p < W ? 0u : (p - W) / 10u + 1u;
+        x0 = p < W ? p : W - 10u + (p - W) % 10u;
+        n = len_of(p); moved = moved_at(p);
+        left = W + 10u * (H - 1u) - c;
+    }
 };
 
 // Iterates the wavefront steps of one grid (latent.py:66-140).
@@ -455,6 +469,25 @@ struct StreamBody {
     }
 };
 
+// Segments of a grid, the same list for the decoder and for every producer: all steps - or, around a streamed body, the ramp in
+// front of it, the body (ONE step of n_pix symbols for the decoder), the ramp behind it.  The ramps of a streamed grid - 230 steps
+// of 1 .. 23 pixels at each of two corners, every one a full "late work + hand-overs + one part" chain - run 4-pixel tasks
+// (shorter late path, 4 symbols instead of 8 between "ready" and "published"); same batches of 16, so nothing drains in between.
+#ifndef CCD_RAMP_TASK_PIX
+#define CCD_RAMP_TASK_PIX 4
+#endif
+struct GridSeg { uint32_t first, steps, pix_before, n_pix; int task_pix; bool body; };  // steps [first, first + steps), pixels in front of / in them
+__device__ __forceinline__ int grid_segments(uint32_t H, uint32_t W, int task_pix, GridSeg* out) {
+    StreamBody b;
+    b.init(H, W, task_pix);
+    const uint32_t total = W <= 9u ? H * W : W + 10u * (H - 1u);
+    if (!b.on) { out[0] = GridSeg{0u, total, 0u, H * W, task_pix, false}; return 1; }
+    out[0] = GridSeg{0u, b.first, 0u, b.pix_before, CCD_RAMP_TASK_PIX, false};
+    out[1] = GridSeg{b.first, b.end - b.first, b.pix_before, b.n_pix, task_pix, true};
+    out[2] = GridSeg{b.end, total - b.end, H * W - b.pix_before, b.pix_before, CCD_RAMP_TASK_PIX, false};
+    return 3;
+}
+
 // =================================================================================================
 // DECODER (wave 0): one grid.  Returns the batch sequence number after the grid.
 // =================================================================================================
@@ -472,14 +505,14 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     uint32_t word_pos = uni(S.word_pos), wbase = uni(S.wbase), wbuf = S.wbuf;
     const uint32_t n_words = uni(P.n_words);
     const glb_ptr<const uint32_t> words_g = (glb_ptr<const uint32_t>)P.words;
-    const int task_pix = uni(C.task_pix);
+    int task_pix = uni(C.task_pix);  // (of the grid; the ramps around a streamed body run smaller tasks: per segment below)
     const int grid_w = uni(C.W);
     // pixels per batch: 16 (two 8-pixel or four 4-pixel tasks) or 8 (four 2-pixel tasks).  32-pixel batches were tried twice
     // (r01; r03 with the first half published half-way, kBpxWide above): fewer hand-overs for the decoder, but slower overall.
     const int bpx = task_pix == 2 ? 8 : (task_pix == 8 ? kBpxWide : 16);
     const uint32_t bpx_shift = task_pix == 2 ? 3u : (task_pix == 8 && kBpxWide == 32 ? 5u : 4u);
     const int slot_mask = kRows / bpx - 1;       // 8 / 16 slots share the 128 table rows
-    const int task_shift = task_pix == 8 ? 3 : (task_pix == 4 ? 2 : 1);
+    int task_shift = task_pix == 8 ? 3 : (task_pix == 4 ? 2 : 1);
     // LDS byte addresses (the dynamic LDS starts at 0) and per-lane constants of the step loop below
     const uint32_t ready_base = C.s_ready.off;  // s_consumed sits kSlots words behind it, the ring at LDS address 0 (kernel set-up)
     const uint32_t top_base = C.s_meta.off + static_cast<uint32_t>(offsetof(RowMeta, top));
@@ -492,19 +525,17 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
     uint32_t n_spins = 0;    // polls of a ready counter inside the asm region (profile builds report them)
     uint32_t pix0 = uni(C.px_base);  // pixels of the stream decoded before the current step (the asm region counts on)
     uint32_t n_part = 0;             // batches decoded part by part
-    StreamBody body;
-    body.init(static_cast<uint32_t>(it.H), static_cast<uint32_t>(it.W), task_pix);
-    // segments of the grid: a step of a raster-order grid; else all steps - or, around a streamed body (StreamBody), the steps in
-    // front of it, the body as ONE step of n_pix symbols, the steps behind it
-    int seg_c = 0;
+    // segments of the grid (grid_segments): a step of a raster-order grid comes back after every step
+    GridSeg segs[3];
+    const int n_segs = grid_segments(static_cast<uint32_t>(it.H), static_cast<uint32_t>(it.W), uni(C.task_pix), segs);
+    int seg_i = 0, seg_c = 0;
     while (ok && seg_c < it.n_steps) {
-        int seg_steps = it.raster ? 1 : it.n_steps;
-        bool seg_body = false;
-        if (body.on) {
-            if (seg_c < static_cast<int>(body.first)) seg_steps = static_cast<int>(body.first) - seg_c;
-            else if (seg_c == static_cast<int>(body.first)) { seg_body = true; seg_steps = static_cast<int>(body.end - body.first); }
-            else seg_steps = it.n_steps - seg_c;
-        }
+        while (seg_i + 1 < n_segs && seg_c >= static_cast<int>(segs[seg_i].first + segs[seg_i].steps)) ++seg_i;
+        const bool seg_body = segs[seg_i].body;
+        const int seg_steps = it.raster ? 1 : static_cast<int>(segs[seg_i].steps);
+        const uint32_t seg_n_pix = uni(segs[seg_i].n_pix);
+        task_pix = uni(segs[seg_i].task_pix);
+        task_shift = task_pix == 8 ? 3 : (task_pix == 4 ? 2 : 1);
         it.seek(seg_c);
         seg_c += seg_steps;
         // ---- one wavefront step = one asm region: per batch the ready check, the symbol loop (hand-scheduled recurrence, see
@@ -513,7 +544,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
         // window miss, invalid data: status 1, handled below, then re-entered) and for a batch that is not ready (status 2).
         // The region walks the remaining steps of a wavefront-ordered grid itself (label 30); `it` only sets it up.  A grid
         // narrower than 10 (raster order, one pixel per step) comes back after every step.
-        uint32_t n_step = seg_body ? uni(body.n_pix) : static_cast<uint32_t>(it.n), step_x0 = static_cast<uint32_t>(it.x0), step_hy = static_cast<uint32_t>(it.H - it.y0);
+        uint32_t n_step = seg_body ? seg_n_pix : static_cast<uint32_t>(it.n), step_x0 = static_cast<uint32_t>(it.x0), step_hy = static_cast<uint32_t>(it.H - it.y0);
         uint32_t steps_left = (it.raster || seg_body) ? 1u : static_cast<uint32_t>(seg_steps);
         uint32_t i = 0, mode = 0;
         // lane p <-> pixel p of the current batch: LDS address of its ring cell, its byte in the latent grid (RowMeta::cell / goff,
@@ -1395,7 +1426,7 @@ __device__ __forceinline__ ExactOut exact_pixel(const ExactArgs& A, int y, int x
 // MF: this grid's tasks run the ARM on the matrix cores; DYN_RING: the kernel's ring of decoded symbols has
 // EntropyParams::ring_rows rows instead of kRingRows (every grid of a matrix-core kernel, whichever producer serves it).
 template <int NV, int kLpp, bool MF, bool DYN_RING, bool DYN, class SH>
-__device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned long long* prof) {
+__device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned long long* prof, const GridSeg& seg) {
     constexpr int in_pad = 4 * NV;
     static_assert(!SH::fixed || (!MF && SH::dim <= in_pad && SH::dim > in_pad - 4 && SH::n_sp >= 1 && SH::n_layers >= 2), "ShapeFix: vector-ALU path, matching width");
     // fixed shape: every region at its compile-time address (the same pipe_layout the kernel carved the LDS with)
@@ -1484,13 +1515,21 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
     uint32_t seq = seq_base;
     // pixels of the stream in front of this step, the previous one, the one before; rows the step start moved down in between
     uint32_t pix0 = uni(C.px_base), prev_pix0 = pix0, prev2_pix0 = pix0, prev_moved = 0;
+    const uint32_t seg_first = uni(seg.first), seg_steps = uni(seg.steps);
+    const bool seg_body = uni(seg.body ? 1 : 0) != 0;
+    if (seg_first > 0u) {  // a segment behind the grid's first step (wavefront order): as if the steps in front of it had been walked
+        it.seek_before(seg_first);
+        pix0 += uni(seg.pix_before);
+        prev_pix0 = pix0 - it.n;
+        prev2_pix0 = prev_pix0 - (seg_first > 1u ? it.len_of(seg_first - 2u) : 0u);
+        prev_moved = it.moved;
+    }
     // Task t of a step (pixels t kTaskPix ..) has the global index seq0 kHalves + t and belongs to producer index % kProducers:
     // a producer visits only its own tasks (first owned one of the step, then every kProducers-th).
     uint32_t phase = static_cast<uint32_t>((static_cast<unsigned long long>(seq_base) * kHalves) % kProducers);  // (seq0 kHalves) mod kProducers
     const bool split = k_left >= 0 && W > 9 && n_layers >= 2;  // (not in raster order)
-    StreamBody body;
-    body.init(it.H, it.W, kTaskPix);
-    const uint32_t n_steps_total = it.left;
+    const uint32_t n_steps_total = it.W <= 9u ? it.H * it.W : it.W + 10u * (it.H - 1u);
+    const uint32_t seg_end = seg_first + seg_steps;  // one past the segment's last step
     // leaves step `it` for the next one INSIDE a streamed body (wavefront order, not the last step: straight-line code, no test of
     // the grid's kind or end), with the bookkeeping of the dependencies: where the previous two steps begin in the stream
     const auto walk_on = [&]() {
@@ -1499,11 +1538,10 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
         it.x0 = mv ? it.W - 10u : nx; it.y0 += mv; it.moved = mv; --it.left;
         it.n = min(it.H - it.y0, ((it.x0 * 0xcccdu) >> 19) + 1u);
     };
-    while (it.next()) {
-        // a SEGMENT of the grid: one step - or the streamed body (StreamBody: the steps [first, end) cut into tasks without regard to
-        // step ends) as one "step" of body.n_pix pixels, during which `it` follows the tasks through the body's steps
-        const bool seg_body = body.on && n_steps_total - 1u - it.left == body.first;
-        const uint32_t seg_n = seg_body ? body.n_pix : it.n;
+    while (n_steps_total - it.left < seg_end && it.next()) {
+        // one step of the segment - or, in a streamed body (StreamBody: its steps cut into tasks without regard to step ends), the
+        // whole segment as one "step" of seg.n_pix pixels, during which `it` follows the tasks through the body's steps
+        const uint32_t seg_n = seg_body ? uni(seg.n_pix) : it.n;
         const uint32_t seg_pix0 = pix0;
         const uint32_t nb = (seg_n + kBpx - 1) >> kBpxShift;
         const uint32_t n_tasks = (seg_n + kTaskPix - 1) >> kTaskShift;
@@ -2171,7 +2209,7 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
         seq = seq0 + nb;
         phase = (phase + nb * kHalves) % kProducers;
         if (seg_body) {  // on to the body's last step: the lines below leave it like any step
-            while (n_steps_total - it.left < body.end) walk_on();
+            while (n_steps_total - it.left < seg_end) walk_on();
         }
         prev2_pix0 = prev_pix0;
         prev_pix0 = pix0;
@@ -2445,8 +2483,18 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         } else {
             // the matrix-core evaluation only serves the 8-pixel tasks of wide grids: its chain has the same length whatever
             // the number of pixels, while the vector-ALU code of a 4- / 2-pixel task spreads a pixel over 16 / 32 lanes
-            seq_end = C.task_pix == 8 ? producer_grid<NV, 8, MF, MF, DYN, SH>(C, prof)
-                                      : (C.task_pix == 4 ? producer_grid<NV, 16, false, MF, DYN, SH>(C, prof) : producer_grid<NV, 32, false, MF, DYN, SH>(C, prof));
+            GridSeg segs[3];
+            const int n_segs = grid_segments(static_cast<uint32_t>(C.H), static_cast<uint32_t>(C.W), C.task_pix, segs);
+            const uint32_t grid_seq_base = C.seq_base;
+            seq_end = grid_seq_base;
+            for (int si = 0; si < n_segs; ++si) {
+                const int tp = segs[si].task_pix;
+                C.seq_base = seq_end;  // (batches are numbered through the segments)
+                seq_end = tp == 8 ? producer_grid<NV, 8, MF, MF, DYN, SH>(C, prof, segs[si])
+                                  : (tp == 4 ? producer_grid<NV, 16, false, MF, DYN, SH>(C, prof, segs[si]) : producer_grid<NV, 32, false, MF, DYN, SH>(C, prof, segs[si]));
+                if (lds_load_acquire(C.s_abort) != 0) break;
+            }
+            C.seq_base = grid_seq_base;
         }
         const unsigned long long t_b = PROF_T();
         __syncthreads();  // also makes the decoder's global writes of this grid visible to every wave
