@@ -2368,60 +2368,68 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                     s_w32[i] = (c < fin && j < n_if) ? static_cast<int32_t>(s_fw[c * n_if + j]) : 0;
                 }
                 __syncthreads();
-                const glb_ptr<int16_t> featg = (glb_ptr<int16_t>)feat;
-                const glb_ptr<int32_t> wideg = (glb_ptr<int32_t>)P.ifce_wide;
-                const int plane = fh * fw;
-                const int fstride_g = C.fstride;
-                // source descriptors: wave-uniform, read from LDS once (inside the loop each costs an LDS round trip per position)
-                glb_ptr<const int8_t> srcp[kIfceFastIn];
-                int gwr[kIfceFastIn], shr[kIfceFastIn];
+                // one body for two channel counts: the finest grids of a 7-grid picture stack <= 6 coarser grids - half the loads and
+                // multiply-adds of the 12-channel form.  (The pass is bound by the latency of its loads, one position ahead; THREE
+                // positions in flight were tried in r04 and ran 7 x slower - the compiler then waits with vmcnt(0) between them.)
+                const auto pass = [&](auto kin_c) {
+                    constexpr int KIN = decltype(kin_c)::value;
+                    const glb_ptr<int16_t> featg = (glb_ptr<int16_t>)feat;
+                    const glb_ptr<int32_t> wideg = (glb_ptr<int32_t>)P.ifce_wide;
+                    const int plane = fh * fw;
+                    const int fstride_g = C.fstride;
+                    // source descriptors: wave-uniform, read from LDS once (inside the loop each costs an LDS round trip per position)
+                    glb_ptr<const int8_t> srcp[KIN];
+                    int gwr[KIN], shr[KIN];
 #pragma unroll
-                for (int c = 0; c < kIfceFastIn; ++c) {
-                    const int cc = min(c, fin - 1);
-                    srcp[c] = (glb_ptr<const int8_t>)reinterpret_cast<const int8_t*>(uni(reinterpret_cast<uint64_t>(s_src[cc])));
-                    gwr[c] = uni(s_gw[cc]);
-                    shr[c] = uni(s_sh[cc]);
-                }
-                auto fetch = [&](int p, int32_t (&v)[kIfceFastIn]) {
-                    const int y = p / fw, x = p - y * fw;
+                    for (int c = 0; c < KIN; ++c) {
+                        const int cc = min(c, fin - 1);
+                        srcp[c] = (glb_ptr<const int8_t>)reinterpret_cast<const int8_t*>(uni(reinterpret_cast<uint64_t>(s_src[cc])));
+                        gwr[c] = uni(s_gw[cc]);
+                        shr[c] = uni(s_sh[cc]);
+                    }
+                    auto fetch = [&](int p, int32_t (&v)[KIN]) {
+                        const int y = p / fw, x = p - y * fw;
 #pragma unroll
-                    for (int c = 0; c < kIfceFastIn; ++c) v[c] = static_cast<int32_t>(srcp[c][(y >> shr[c]) * gwr[c] + (x >> shr[c])]);
+                        for (int c = 0; c < KIN; ++c) v[c] = static_cast<int32_t>(srcp[c][(y >> shr[c]) * gwr[c] + (x >> shr[c])]);
+                    };
+                    int64_t br[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) br[j] = j < n_if ? s_fw[fin * n_if + j] : 0;
+                    int n_if_lane = n_if;
+                    asm volatile("" : "+v"(n_if_lane));  // opaque: the stores below are predicated per lane, not branched around
+                    const int in_scale = zero_input ? 0 : 65536;  // first grid: the stack is one all-zero channel; else armint.py:193's << 16
+                    int32_t v_next[KIN];
+                    fetch(min(tid, plane - 1), v_next);
+                    for (int p = tid; p < plane; p += kPipeThreads) {
+                        int32_t v[KIN];
+#pragma unroll
+                        for (int c = 0; c < KIN; ++c) v[c] = v_next[c] * in_scale;
+                        fetch(min(p + kPipeThreads, plane - 1), v_next);
+                        int64_t acc[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = br[j];
+#pragma unroll
+                        for (int c = 0; c < KIN; ++c) {
+                            const int4 w0 = *reinterpret_cast<const int4*>(s_w32 + c * 8), w1 = *reinterpret_cast<const int4*>(s_w32 + c * 8 + 4);
+                            // (plain C++, not mad64: an inline-asm statement makes the compiler wait for every outstanding load)
+                            const int64_t x = v[c];
+                            acc[0] += x * w0.x; acc[1] += x * w0.y; acc[2] += x * w0.z; acc[3] += x * w0.w;
+                            acc[4] += x * w1.x; acc[5] += x * w1.y; acc[6] += x * w1.z; acc[7] += x * w1.w;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            // |feature| >= 2^feat_bits: sentinel in the int16 plane, the value itself in the int32 side plane
+                            // (exactness notes above exact_pixel); both stores are predicated per lane, not branched around.
+                            // 32-bit tests: q8 = acc >> 24 lies in [-2^b, 2^b) iff the bits of acc from 24 + b up are all equal.
+                            const int32_t hi = static_cast<int32_t>(acc[j] >> 32), q32 = static_cast<int32_t>(acc[j] >> 24);
+                            const bool big = static_cast<uint32_t>((hi >> feat_hi_shift) + 1) > 1u || (q32 & 0xffff) == 0x8000;
+                            if (j < n_if_lane) featg[p * fstride_g + min(j, n_if - 1)] = (DYN && big) ? kFeatSentinel : static_cast<int16_t>(q32);
+                            if (DYN && j < n_if_lane && big) wideg[min(j, n_if - 1) * plane + p] = q32;
+                        }
+                    }
                 };
-                int64_t br[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) br[j] = j < n_if ? s_fw[fin * n_if + j] : 0;
-                int n_if_lane = n_if;
-                asm volatile("" : "+v"(n_if_lane));  // opaque: the stores below are predicated per lane, not branched around
-                const int in_scale = zero_input ? 0 : 65536;  // first grid: the stack is one all-zero channel; else armint.py:193's << 16
-                int32_t v_next[kIfceFastIn];
-                fetch(min(tid, plane - 1), v_next);
-                for (int p = tid; p < plane; p += kPipeThreads) {
-                    int32_t v[kIfceFastIn];
-#pragma unroll
-                    for (int c = 0; c < kIfceFastIn; ++c) v[c] = v_next[c] * in_scale;
-                    fetch(min(p + kPipeThreads, plane - 1), v_next);
-                    int64_t acc[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = br[j];
-#pragma unroll
-                    for (int c = 0; c < kIfceFastIn; ++c) {
-                        const int4 w0 = *reinterpret_cast<const int4*>(s_w32 + c * 8), w1 = *reinterpret_cast<const int4*>(s_w32 + c * 8 + 4);
-                        // (plain C++, not mad64: an inline-asm statement makes the compiler wait for every outstanding load)
-                        const int64_t x = v[c];
-                        acc[0] += x * w0.x; acc[1] += x * w0.y; acc[2] += x * w0.z; acc[3] += x * w0.w;
-                        acc[4] += x * w1.x; acc[5] += x * w1.y; acc[6] += x * w1.z; acc[7] += x * w1.w;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        // |feature| >= 2^feat_bits: sentinel in the int16 plane, the value itself in the int32 side plane
-                        // (exactness notes above exact_pixel); both stores are predicated per lane, not branched around.
-                        // 32-bit tests: q8 = acc >> 24 lies in [-2^b, 2^b) iff the bits of acc from 24 + b up are all equal.
-                        const int32_t hi = static_cast<int32_t>(acc[j] >> 32), q32 = static_cast<int32_t>(acc[j] >> 24);
-                        const bool big = static_cast<uint32_t>((hi >> feat_hi_shift) + 1) > 1u || (q32 & 0xffff) == 0x8000;
-                        if (j < n_if_lane) featg[p * fstride_g + min(j, n_if - 1)] = (DYN && big) ? kFeatSentinel : static_cast<int16_t>(q32);
-                        if (DYN && j < n_if_lane && big) wideg[min(j, n_if - 1) * plane + p] = q32;
-                    }
-                }
+                if (fin <= 6) pass(std::integral_constant<int, 6>{});
+                else pass(std::integral_constant<int, kIfceFastIn>{});
             } else
             for (int p = tid; p < fh * fw; p += kPipeThreads) {
                 const int y = p / fw, x = p - y * fw;
