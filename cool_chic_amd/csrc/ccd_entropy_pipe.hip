@@ -2369,8 +2369,8 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
                 }
                 __syncthreads();
                 // one body for two channel counts: the finest grids of a 7-grid picture stack <= 6 coarser grids - half the loads and
-                // multiply-adds of the 12-channel form.  (The pass is bound by the latency of its loads, one position ahead; THREE
-                // positions in flight were tried in r04 and ran 7 x slower - the compiler then waits with vmcnt(0) between them.)
+                // multiply-adds of the 12-channel form.  (The pass is bound by the latency of its loads, one position ahead; two or three
+                // positions in flight were tried in r04 and ran 4-7 x slower - the compiler then waits with vmcnt(0) between them.)
                 const auto pass = [&](auto kin_c) {
                     constexpr int KIN = decltype(kin_c)::value;
                     const glb_ptr<int16_t> featg = (glb_ptr<int16_t>)feat;
