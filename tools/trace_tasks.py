@@ -86,3 +86,10 @@ span = max(r[4][4] for r in rows) - min(r[4][0] for r in rows)
 nst = len({r[0] for r in rows})
 print("window: %d steps in %d ticks = %.0f per step; producers busy (early work + late work + between) %.0f %% of 7 waves" %
       (nst, span, span / nst, 100.0 * (sum(ph["early work"]) + sum(ph["late work"]) + sum(ph["between"])) / (7.0 * span)))
+# per producer (is one of them slower - e.g. the decoder's SIMD neighbour?)
+for pw in sorted(by_prod):
+    lst = [t for _, t, cnt in by_prod[pw] if cnt == tp]
+    if not lst: continue
+    k = len(lst)
+    print("  producer %d: %3d full tasks, early work %5.0f  late wait %5.0f  late work %5.0f" %
+          (pw, k, sum(t[2] - t[1] for t in lst) / k, sum(t[3] - t[2] for t in lst) / k, sum(t[4] - t[3] for t in lst) / k))
