@@ -1465,8 +1465,10 @@ __device__ __forceinline__ uint32_t producer_grid(const PipeCtx& C_run, unsigned
     const uint32_t seq_base = uni(C.seq_base);
     // this wave's activation tile [kTaskPix][in_pad] (MF: [16][in_pad], the exact redo) + 4 dummy words (stores of lanes that own
     // no activation go there by address select: no exec mask, no skip branch)
-    int32_t* act = C.s_act + pw * ((MF ? 16 : 8) * in_pad + 4);
-    int32_t* const act_dummy = act + (MF ? 16 : 8) * in_pad;
+    // (the tile's size is the KERNEL's - DYN_RING = its MF - not this instantiation's: since r04 the producers of one grid may be in
+    // different instantiations at the same time, the 4-pixel one on a ramp while another wave is already in the 8-pixel body)
+    int32_t* act = C.s_act + pw * ((DYN_RING ? 16 : 8) * in_pad + 4);
+    int32_t* const act_dummy = act + (DYN_RING ? 16 : 8) * in_pad;
     (void)act_dummy;
     const int px = MF ? (lane & 15) : lane / kLpp;   // pixel of the task
     const int q = MF ? (lane >> 4) : lane % kLpp;    // lane within the pixel's group (MF: K-slot group of the matrix operands)
