@@ -476,6 +476,7 @@ struct StreamBody {
 #ifndef CCD_RAMP_TASK_PIX
 #define CCD_RAMP_TASK_PIX 4
 #endif
+static_assert(CCD_RAMP_TASK_PIX == 4 || CCD_RAMP_TASK_PIX == 8, "ramps and body share the 16-pixel batches: 2-pixel tasks (8-pixel batches) would need the slots drained between segments");
 struct GridSeg { uint32_t first, steps, pix_before, n_pix; int task_pix; bool body; };  // steps [first, first + steps), pixels in front of / in them
 __device__ __forceinline__ int grid_segments(uint32_t H, uint32_t W, int task_pix, GridSeg* out) {
     StreamBody b;
