@@ -391,11 +391,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes (roofline.traffic then "
                     "comes from the tracked profile)")
+    ap.add_argument("--allow-variant", action="store_true", help="time the library CCD_LIB names (a profiling / experiment build of "
+                    "_build.build_variant) instead of refusing: the line then says which one")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="N > 1: nccl = RCCL over xGMI (one GPU per rank); gloo = host-staged exchange, ranks may share a GPU "
                          "(smoke run of the multi-rank path on a single-GPU box)")
     args = ap.parse_args()
 
+    if os.environ.get("CCD_LIB") and not args.allow_variant:
+        sys.exit("bench.py: CCD_LIB=%s selects a variant build of the library; the benchmark times cool_chic_amd/libccd.so. "
+                 "Unset it, or pass --allow-variant to time the variant on purpose." % os.environ["CCD_LIB"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -536,6 +541,7 @@ def main():
         res = {
             "metric": "decoded Mpixel/s", "value": px_per_step * args.steps / dt / 1e6, "unit": "Mpixel/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            **({"library_variant": os.environ["CCD_LIB"]} if os.environ.get("CCD_LIB") else {}),
             "higher_is_better": True, "scaling": "strong" if args.scaling == "strong" else "weak", "vs_baseline": None,
             "dtype": "int64+f64 entropy / f32 synthesis",
             "data": "synthetic (kodim14.cool real + 23 streams re-encoded from rolled/transposed kodim14 latents)",

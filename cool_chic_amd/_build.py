@@ -27,9 +27,7 @@ def is_stale() -> bool:
 def _flags():
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
              # every fused multiply-add of the float stages is an explicit __fmaf_rn (bit parity with the oracle)
-             "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-             # (the decoder's asm region names m0 in its clobber list on purpose: it uses m0 and restores nothing)
-             "-Wno-inline-asm"]
+             "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
     if os.environ.get("CCD_PIPE_PROFILE"):
         # cycle counters in the entropy kernel (ccd_batch_slot_stats): 1 = light (stalls, per-grid totals), 2 = every phase
         flags.append("-DCCD_PIPE_PROFILE=" + os.environ["CCD_PIPE_PROFILE"])
@@ -89,6 +87,24 @@ def build_variant(name: str, extra_flags: str) -> str:
         objs = list(pool.map(compile_one, SOURCES))
     subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
     return out
+
+
+def clean_variants(keep=()) -> list:
+    """Removes the variant libraries (libccd_<name>.so) and object trees (csrc/_obj_<name>) that tools/ built with
+    build_variant(), except the names in `keep`.  They are git-ignored but travel to the GPU box with every push (tens of MB),
+    and a stale one selected through CCD_LIB would be timed in place of the product.  Returns what was removed."""
+    import glob
+
+    gone = []
+    for path in glob.glob(os.path.join(_HERE, "libccd_*.so")):
+        if os.path.basename(path)[len("libccd_"):-len(".so")] not in keep:
+            os.remove(path)
+            gone.append(path)
+    for path in glob.glob(os.path.join(_HERE, "csrc", "_obj_*")):
+        if os.path.basename(path)[len("_obj_"):] not in keep and os.path.isdir(path):
+            shutil.rmtree(path)
+            gone.append(path)
+    return gone
 
 
 if __name__ == "__main__":

@@ -41,7 +41,8 @@ class DecodeBatch:
         self.device = int(device)
         if fused_dec is not None:
             # False / True, or 2: the fused kernel behind the batch's pyramid steps (level-1 stack pre-computed once per frame)
-            check(lib().ccd_batch_set_option(self._h, self.OPT_FUSED_DEC, int(fused_dec)), "ccd_batch_set_option")
+            # True = "the fused float path" = the library's default form of it (2); 0 / 1 / 2 select a form explicitly (ccd.h)
+            check(lib().ccd_batch_set_option(self._h, self.OPT_FUSED_DEC, 2 if fused_dec is True else int(fused_dec)), "ccd_batch_set_option")
         if keep_float is not None:
             check(lib().ccd_batch_set_option(self._h, self.OPT_KEEP_FLOAT, int(bool(keep_float))), "ccd_batch_set_option")
         if mfma_arm is not None:

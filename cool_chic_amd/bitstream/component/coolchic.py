@@ -57,8 +57,39 @@ def encode_decode_coolchic(
     want = torch.device(device)
     gpu = want if want.type == "cuda" else torch.device("cuda:0")
     c = header.c
-    out = torch.empty((1, c.out_channels, c.img_size[0], c.img_size[1]), dtype=torch.float32, device=gpu)
     stream = torch.cuda.current_stream(gpu).cuda_stream
+    if verbosity >= 2:
+        # coolchic.py:38,69,92,150,171,199-205: the reference prints the seconds of its four sections (network decode, IFCE
+        # set-up, latents, upsampling + synthesis).  Same line here, from the batch API run stage by stage with a wait behind
+        # each: parse + fixed-point conversion + upload | 0 (the feature pass is part of the entropy kernel) | entropy stage |
+        # float stages + the copy of the output.
+        import time
+
+        from ...batch import DecodeBatch
+
+        t0 = time.time()
+        batch = DecodeBatch(gpu.index or 0)
+        try:
+            batch.add(header.raw, bytes_nn, dec_bytes_latent, 0, 0)
+            torch.cuda.synchronize(gpu)
+            time_neural_net = time.time() - t0
+            t0 = time.time()
+            batch.run(stream, stage=0)
+            batch.wait(stream)
+            time_latent = time.time() - t0
+            t0 = time.time()
+            batch.run(stream, stage=1)
+            batch.run(stream, stage=2)
+            batch.wait(stream)
+            out = torch.as_tensor(batch.output_device(0), device=gpu).clone()
+            torch.cuda.synchronize(gpu)
+            time_syn = time.time() - t0
+        finally:
+            batch.close()
+        print(header.pretty_string())
+        print(f"{time_neural_net:6.2f} {0.0:6.2f} {time_latent:6.2f} {time_syn:6.2f} ")
+        return (out if want.type == "cuda" else out.cpu()), None
+    out = torch.empty((1, c.out_channels, c.img_size[0], c.img_size[1]), dtype=torch.float32, device=gpu)
     check(lib().ccd_decode_coolchic(header.raw, len(header.raw), bytes_nn, len(bytes_nn), dec_bytes_latent,
                                     len(dec_bytes_latent), gpu.index or 0, C.c_void_p(stream or None),
                                     C.c_void_p(out.data_ptr()), 1), "ccd_decode_coolchic")

@@ -102,6 +102,7 @@ def decode_video(bitstream_path: str, decoded_path: Optional[str] = None, max_de
             for k in range(max_decoding_order + 1):
                 fh, ccs, bitstream_bytes = _split_frame(bitstream_bytes)
                 if fh.get_value("frame_type") != "I":
+                    # a P / B header needs references an all-intra structure does not give (decode.py:160: IndexError)
                     raise ValueError(f"frame {k} (coding order): header says {fh.get_value('frame_type')}, the coding structure I")
                 ch, nn, lat = ccs[0]
                 bd, fdt = fh.get_value("bitdepth"), fh.get_value("frame_data_type")
@@ -155,14 +156,17 @@ def _decode_gop(rest: bytes, n_decode: int, device: int, group, verbosity: int =
             print(fh.pretty_string())
         parsed.append((fh, ccs))
     # decode.py:67-75: which frame sits at coding index k and what it predicts from come from the VIDEO header's coding
-    # structure; the frame headers' display_index / index_references are never read there.  Only the header's frame_type is
-    # used (cool-chics per frame, reconstruction): one that contradicts the structure makes the reference index references it
-    # was not given, so that alone is rejected.  Without a structure (decode_frame-style callers) the headers are followed.
+    # structure; the frame headers' display_index / index_references are never read there.  The header's frame_type alone
+    # decides the cool-chics per frame and the reconstruction (decode.py:119-128, 156-189): an "I" header at a P / B position
+    # is plain intra, a "P" header at a B position predicts from the structure's first reference.  Rejected is what the
+    # reference raises on (IndexError): a header type that needs more references than the structure gives.  Without a
+    # structure (decode_frame-style callers) the headers are followed.
     if structure is not None:
         for k, (fh, _) in enumerate(parsed):
-            if fh.get_value("frame_type") != structure[k]["frame_type"]:
-                raise ValueError(f"frame {k} (coding order): header says {fh.get_value('frame_type')}, "
-                                 f"the coding structure {structure[k]['frame_type']}{structure[k]['display_order']}")
+            if "IPB".index(fh.get_value("frame_type")) > len(structure[k]["index_references"]):
+                raise ValueError(f"frame {k} (coding order): header says {fh.get_value('frame_type')}, the coding structure "
+                                 f"{structure[k]['frame_type']}{structure[k]['display_order']} gives it "
+                                 f"{len(structure[k]['index_references'])} reference(s)")
         display = [structure[k]["display_order"] for k in range(n_decode)]
         ref_display = [list(structure[k]["index_references"]) for k in range(n_decode)]
     else:

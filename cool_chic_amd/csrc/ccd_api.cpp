@@ -74,7 +74,7 @@ using namespace ccd;
 
 namespace {
 
-// Process-wide caches of device blocks and pinned host blocks, per device: a batch is created, filled, run and destroyed
+// Caches of device blocks and pinned host blocks, one per device (free lists, byte counts and caps are all per device): a batch is created, filled, run and destroyed
 // per image set, and hipMalloc / hipFree / hipHostMalloc of its arenas were a fifth of the time from bytes to planes
 // (24 hipFree = 4.4 ms per Kodak set; 64 arenas of 50-100 MB per 1080p GOP).  Blocks are handed out in size classes
 // (power of two up to 1 MB, then eighths of a power of two: <= 12.5 % slack) and come back on destroy; the cache is capped
@@ -102,7 +102,7 @@ public:
             if (it != fl.end()) {
                 void* p = it->second;
                 fl.erase(it);
-                cached_[kind] -= cls;
+                cached_[key(device, kind)] -= cls;
                 return p;
             }
         }
@@ -119,9 +119,10 @@ public:
         if (!p) return;
         {
             std::lock_guard<std::mutex> lock(mu_);
-            if (cached_[kind] + cls <= cap(kind)) {
+            size_t& cached = cached_[key(device, kind)];  // the caps are per device (and kind), like the free lists and trim()
+            if (cached + cls <= cap(kind)) {
                 free_[key(device, kind)].emplace(cls, p);
-                cached_[kind] += cls;
+                cached += cls;
                 return;
             }
         }
@@ -133,7 +134,8 @@ public:
             std::lock_guard<std::mutex> lock(mu_);
             for (int k = 0; k < 2; ++k) {
                 auto& fl = free_[key(device, static_cast<Kind>(k))];
-                for (auto& e : fl) { drop.emplace_back(static_cast<Kind>(k), e.second); cached_[k] -= e.first; }
+                for (auto& e : fl) drop.emplace_back(static_cast<Kind>(k), e.second);
+                cached_[key(device, static_cast<Kind>(k))] = 0;
                 fl.clear();
             }
         }
@@ -151,7 +153,7 @@ private:
     }
     std::mutex mu_;
     std::map<int, std::multimap<size_t, void*>> free_;
-    size_t cached_[2] = {0, 0};
+    std::map<int, size_t> cached_;  // bytes in free_[key], same key
 };
 BlockPool& pool() { static BlockPool p; return p; }
 
@@ -390,7 +392,10 @@ int ccd_batch_create(int device, ccd_batch** out) {
     if (!b) return CCD_ERR_NOMEM;
     b->device = device;
     if (const char* e = std::getenv("CCD_FORCE_GENERIC")) b->force_generic = std::atoi(e);
-    if (const char* e = std::getenv("CCD_FUSED_DEC")) b->opt_fused_dec = std::atoi(e);
+    if (const char* e = std::getenv("CCD_FUSED_DEC")) {  // 0 / 1 / 2 like the option; anything else leaves the default
+        const int v = std::atoi(e);
+        if (v >= 0 && v <= 2) b->opt_fused_dec = v;
+    }
     if (const char* e = std::getenv("CCD_MFMA_ARM")) b->opt_mfma_arm = std::atoi(e);
     if (const char* e = std::getenv("CCD_FIXED_SHAPE")) b->opt_fixed_shape = std::atoi(e);
     b->d_scale_table = sh->d_scale_table;
@@ -1125,6 +1130,9 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
             const int side = (idx - 1) % DeviceShared::kSide;
             if (std::find(used.begin(), used.end(), side) == used.end()) {
                 used.push_back(side);
+                // drained with the caller's streams before the arenas return to the pool (ccd_batch_destroy, upload_params): an
+                // error between this fork and the join below leaves launches on the side stream that no event orders
+                b->note_stream(sh->side[side]);
                 (void)hipStreamWaitEvent(sh->side[side], b->fork, 0);
             }
             return sh->side[side];
@@ -1227,7 +1235,9 @@ const float* ccd_batch_dense(const ccd_batch* b, int slot) {
 int ccd_batch_set_option(ccd_batch* b, int option, int value) {
     if (!b) return CCD_ERR_ARG;
     switch (option) {
-        case CCD_OPT_FUSED_DEC: b->opt_fused_dec = value; return CCD_OK;
+        case CCD_OPT_FUSED_DEC:
+            if (value < 0 || value > 2) return CCD_ERR_ARG;
+            b->opt_fused_dec = value; return CCD_OK;
         case CCD_OPT_KEEP_FLOAT: b->opt_keep_float = value; return CCD_OK;
         case CCD_OPT_MFMA_ARM: b->opt_mfma_arm = value; return CCD_OK;
         case CCD_OPT_RANGE_BITS: b->opt_range_bits = value; return CCD_OK;
@@ -1414,13 +1424,16 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
         {
             // decode.py:67-75 takes the display index and the references of the frame at this coding index from the STRUCTURE and
             // never reads those fields of the frame header; the header's frame_type decides how many cool-chics follow and how the
-            // frame is reconstructed (decode.py:119-128, 156-189): with a type other than the structure's the reference's
-            // reconstruction indexes reference frames it was not given (IndexError) - only that is rejected
+            // frame is reconstructed (decode.py:119-128, 156-189), whatever the structure calls the frame: a header "I" at a P / B
+            // position decodes as plain intra (decode_frame ignores reference_frames), a header "P" at a B position predicts from
+            // the structure's first reference only (apply_global_translation zips references with flows).  Rejected is only what
+            // the reference raises on: a header type that needs MORE references than the structure gives (raw_references[0] /
+            // shifted_ref[1]: IndexError)
             const CodedFrame& want = cs[f];
-            if (fhs[f].frame_type != want.frame_type) { rc = CCD_ERR_VALUE; break; }
+            if (fhs[f].frame_type > want.n_refs) { rc = CCD_ERR_VALUE; break; }  // I / P / B = 0 / 1 / 2 = references needed
             fhs[f].display_index = want.display_order;
-            fhs[f].n_refs = want.n_refs;
-            for (int k = 0; k < want.n_refs; ++k) fhs[f].index_references[k] = want.refs[k];
+            fhs[f].n_refs = fhs[f].frame_type;
+            for (int k = 0; k < fhs[f].n_refs; ++k) fhs[f].index_references[k] = want.refs[k];
         }
         pos += static_cast<size_t>(used);
         first_slot[f] = ccd_batch_size(b);

@@ -556,6 +556,10 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
             i = uni(i); seq = uni(seq); mode = uni(mode); n_spins = uni(n_spins);  // scalar operands of the region below
             n_step = uni(n_step); step_x0 = uni(step_x0); step_hy = uni(step_hy); steps_left = uni(steps_left); pix0 = uni(pix0);
             n_part = uni(n_part);
+// (this region names m0 in its clobber list on purpose - it uses m0 and restores nothing; the diagnostic is silenced for this
+// statement only: every other asm statement of the file keeps its inline-asm warnings)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
             asm volatile(
                 "s_mov_b64 s[50:51], %[dst]\n\t"
                 "s_mov_b64 s[52:53], %[rng]\n\t"
@@ -1095,6 +1099,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                   [l4] "v"(lane_top_off), [lat] "s"(lat_addr)
                 : "memory", "vcc", "scc", "m0", "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55",
                   "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60");
+#pragma clang diagnostic pop
             if (status == 0) break;  // every step of the segment is done
             if (status == 3) {  // the region renormalised with the last buffered payload word: refill, resume inside the batch
                 wbase = word_pos;

@@ -107,8 +107,10 @@ int ccd_read_cc_header(const uint8_t* p, size_t n, ccd_cc_header* h);
  * CCD_ERR_VALUE where the reference asserts (first frame not intra, last frame neither intra nor P, a frame both I and P).
  * Positions listed twice are CCD_ERR_VALUE too: the reference only prints a warning, builds a structure that lacks a display
  * index and fails after decoding (decode.py:86 on None).  ccd_decode_video decodes in this order with these references, like
- * decode.py:67-75 (the frame headers' display_index / index_references are not read there), and rejects a frame header whose
- * frame_type contradicts the structure. */
+ * decode.py:67-75 (the frame headers' display_index / index_references are not read there).  The frame header's frame_type
+ * decides the number of cool-chics and the reconstruction, as in decode.py:119-128, 156-189: an "I" header at a P / B position
+ * is decoded as plain intra, a "P" header at a B position predicts from the structure's first reference; a header type that
+ * needs MORE references than the structure gives (the reference: IndexError) is CCD_ERR_VALUE. */
 int ccd_get_coding_structure(const ccd_video_header* h, int32_t* display_order, int32_t* frame_type, int32_t* refs, int32_t* depth);
 
 /* ---- one cool-chic: encode_decode_coolchic(mode="decode"), coolchic.py:29-207 ------------- */
@@ -204,7 +206,7 @@ int ccd_batch_planes_layout(const ccd_batch* b, int slot, size_t* total_bytes, s
 int ccd_batch_copy_planes_async(ccd_batch* b, int first_slot, int n_slots, void* const* host_blocks, void* stream);
 /* Device and pinned-host blocks of destroyed batches are cached per device for the next batch (a batch per image set is the
  * normal use); this returns them to the runtime.  The environment variables CCD_POOL_MAX_MB / CCD_PINNED_POOL_MAX_MB cap the
- * caches (defaults 16384 / 2048 MB = 5.5 % of the device: the cache is invisible to other allocators of the process, e.g. PyTorch's; a block beyond
+ * caches of EACH device (defaults 16384 / 2048 MB per device = 5.5 % of it: the cache is invisible to other allocators of the process, e.g. PyTorch's; a block beyond
  * the cap is freed at once, and an allocation that fails trims the cache and retries).
  *
  * Threading and global state.  Per device and for the life of the process the library keeps: that block cache, the two

@@ -379,6 +379,16 @@ def test_python_surface(gpu, oracle, tmp_path):
     assert np.array_equal(t[0].cpu().numpy().view(np.uint32), ref.view(np.uint32))
     with pytest.raises(ValueError):
         encode_decode_coolchic(ch, nn, "decode", dec_bytes_latent=None)
+    # verbosity >= 2 (coolchic.py:199-205): the header, then one line of four section times; same tensor
+    import contextlib
+    import io
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        t_v, _ = encode_decode_coolchic(ch, nn, "decode", dec_bytes_latent=lat, verbosity=2)
+    assert torch.equal(t_v, t)
+    last = buf.getvalue().rstrip("\n").split("\n")[-1].split()
+    assert len(last) == 4 and all(float(x) >= 0.0 for x in last) and float(last[2]) > 0.0
     # the boundary's second caller (bitstream/encode.py:83-89): mode="encode" with the decoded latents as the encoder's
     # quantised latents gives back the reference encoder's own bytes (header + NN + latent payload) and the same output
     with pytest.raises(ValueError):
