@@ -309,7 +309,7 @@ def gop_leg(device, sh, stream, steps, cpu_budget, want_cpu):
     return leg
 
 
-def timed_set(mine, world, rank, local_rank, backend, red_dev, steps, warmup):
+def timed_set(mine, world, rank, local_rank, backend, red_dev, steps, warmup, force_gather=False):
     """One image set, this rank's share of it: `mine` = [(cc_header, bytes_nn, bytes_latent, (H, W))].  Inputs go to HBM, then
     `warmup` untimed and `steps` timed steps; a step = decode of every frame of the share + (N > 1) the gather of the decoded
     integer planes to rank 0 inside the timed region.  Barrier + device synchronisation on both sides, MAX over ranks.
@@ -327,7 +327,7 @@ def timed_set(mine, world, rank, local_rank, backend, red_dev, steps, warmup):
     planes = [torch.as_tensor(batch.plane_device(s_, p), device=dev).reshape(-1) for s_ in range(n) for p in range(3)]
     n_bytes = sum(int(p.numel()) * p.element_size() for p in planes)
     gatherer = None
-    if world > 1:  # equal message sizes: pad to the largest share
+    if world > 1 or force_gather:  # equal message sizes: pad to the largest share (force_gather: the one-rank nccl test of the wire path)
         t = torch.tensor([n_bytes], dtype=torch.int64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         pad = int(t.item()) - n_bytes
@@ -343,7 +343,7 @@ def timed_set(mine, world, rank, local_rank, backend, red_dev, steps, warmup):
             gathered[0] = gatherer(planes)
 
     def fence():
-        if world > 1:
+        if world > 1 or force_gather:
             dist.barrier()
         torch.cuda.synchronize(local_rank)
 
@@ -356,7 +356,7 @@ def timed_set(mine, world, rank, local_rank, backend, red_dev, steps, warmup):
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_gather:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())

@@ -101,7 +101,8 @@ class DecodeBatch:
     def slot_kernels(self, slot: int) -> int:
         """bit 0: pipelined entropy kernel, bit 1: fused synthesis kernel, bit 2: fused upsampling + synthesis kernel,
         bit 3: the ARM on the matrix cores, bit 4: the pipelined kernel's instantiation with the device check of IFCE features,
-        bit 5: its instantiation with a compile-time ARM shape (HOP), bit 6: the fused float kernel behind the pyramid launch."""
+        bit 5: its instantiation with a compile-time ARM shape (HOP), bit 6: the fused float kernel behind the pyramid launch,
+        bit 7: the network is outside the finite envelope of the float stages (vector-ALU float kernels only, see ccd.h)."""
         return check(lib().ccd_batch_slot_kernels(self._h, slot), "ccd_batch_slot_kernels")
 
     def latent(self, slot: int, grid: int) -> np.ndarray:

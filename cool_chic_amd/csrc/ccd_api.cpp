@@ -217,6 +217,7 @@ struct Slot {
     bool use_fused_syn = false;      // whole synthesis in one kernel (ccd_synth_fused.hip)
     SynthFused fused;
     bool use_fused_dec = false;      // upsampling + synthesis + integer samples in one kernel (ccd_fused.hip)
+    bool float_finite = true;        // float_path_stays_finite(): the network cannot leave the finite float32 range
     bool fdec_pre = false;           // ... whose level-1 stack comes from the batch's pyramid launch (CCD_OPT_FUSED_DEC = 2)
     FusedDec fpyr;                   // ... descriptor of that launch: the same walk one level up (level 0 = this frame's level 1)
     FusedDec fdec;
@@ -600,7 +601,10 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
         const int C = h.out_channels;
         // common randomness: n_levels noise planes behind the latent channels (the kFdPre instantiations with NZ = CIN; pictures only)
         const int NZ = s.cr ? n_levels : 0;
-        bool ok = b->opt_fused_dec && !b->force_generic && n_levels + NZ == s.dense_c && n_levels >= 2 && n_levels <= kFdMaxLevels &&
+        // the matrix-core kernel is exact for FINITE values (its zero-weight padding: fma(v, 0, acc) == acc); a network that
+        // could overflow float32 for some latents runs the vector-ALU kernels, which evaluate the oracle's taps only
+        s.float_finite = float_path_stays_finite(net, n_levels, NZ);
+        bool ok = b->opt_fused_dec && !b->force_generic && s.float_finite && n_levels + NZ == s.dense_c && n_levels >= 2 && n_levels <= kFdMaxLevels &&
                   fused_dec_supports(n_levels, C) && (!s.cr || (b->opt_fused_dec == 2 && fused_dec_cr_supports(n_levels, C))) &&
                   net.ups_k == 8 && net.pre_k == 7 && L.size() >= 2 &&
                   L.size() <= 2 + static_cast<size_t>(kFdMaxConv) && L[0].k == 1 && L[1].k == 1 && !L[0].residual && !L[1].residual &&
@@ -1219,7 +1223,7 @@ int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64) {
 int ccd_batch_slot_kernels(const ccd_batch* b, int slot) {
     if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
     const Slot& s = *b->slots[slot];
-    return (s.use_pipe ? 1 : 0) | (s.use_fused_syn ? 2 : 0) | (s.use_fused_dec ? 4 : 0) | (s.use_mfma ? 8 : 0) | (s.use_dyn ? 16 : 0) | (s.fixed_shape ? 32 : 0) | (s.fdec_pre ? 64 : 0);
+    return (s.use_pipe ? 1 : 0) | (s.use_fused_syn ? 2 : 0) | (s.use_fused_dec ? 4 : 0) | (s.use_mfma ? 8 : 0) | (s.use_dyn ? 16 : 0) | (s.fixed_shape ? 32 : 0) | (s.fdec_pre ? 64 : 0) | (s.float_finite ? 0 : 128);
 }
 
 const float* ccd_batch_output(const ccd_batch* b, int slot) {
@@ -1581,7 +1585,11 @@ int ccd_network_kernel_class(const uint8_t* cc_header, size_t n_hdr, const uint8
     int max_w = 0;
     for (int g = 0; g < h->n_grids; ++g) max_w = std::max(max_w, static_cast<int>(h->grid_w[g]));
     const bool pipe = entropy_pipe_supports(h->total_context_arm, h->n_hidden_layers_arm + 1, (net.arm.w32 && net.feat_i32 && !net.arm.dyn_act) ? 1 : 0, max_w);
-    return (pipe ? 1 : 0) | (pipe && net.arm.dyn_feat ? 16 : 0) | (((h->total_context_arm + 3) / 4 & 15) << 8) | (((h->n_hidden_layers_arm + 1) & 15) << 12);
+    int n_levels = 0;
+    for (int g = 0; g < h->n_grids; ++g) n_levels += h->is_hyperlatent[g] ? 0 : 1;
+    const bool finite = float_path_stays_finite(net, n_levels, h->flag_common_randomness ? n_levels : 0);
+    return (pipe ? 1 : 0) | (pipe && net.arm.dyn_feat ? 16 : 0) | (finite ? 0 : 128) | (((h->total_context_arm + 3) / 4 & 15) << 8) |
+           (((h->n_hidden_layers_arm + 1) & 15) << 12);
 }
 
 int ccd_debug_fd_profile(uint64_t* out16, int reset) {

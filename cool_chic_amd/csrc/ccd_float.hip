@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void syn_layer_kernel(const float* __restrict_
             if (in2) v = v + in2[co * plane + static_cast<size_t>(y) * w + x];
             acc = acc + v;
         }
-        if (relu) acc = acc > 0.0f ? acc : 0.0f;
+        if (relu) acc = acc <= 0.0f ? 0.0f : acc;  // NaN stays NaN like torch.relu (and in the oracle)
         out[co * plane + static_cast<size_t>(y) * w + x] = acc;
     }
 }

@@ -515,6 +515,45 @@ int decode_network(const ccd_cc_header& h, const uint8_t* bytes_nn, size_t n_nn,
     return CCD_OK;
 }
 
+bool float_path_stays_finite(const Network& net, int n_levels, int noise) {
+    const double kLimit = std::ldexp(1.0, 120);  // FLT_MAX ~ 2^128: a partial sum of two bounded terms stays finite too
+    auto abs_sum = [](const float* w, size_t n) { double s = 0; for (size_t i = 0; i < n; ++i) s += std::fabs(static_cast<double>(w[i])); return s; };
+    // ---- latent pyramid: the stack's bound after each x2 step (coarsest first; filters of index step % n_ups) ----
+    double bound = 64.0;
+    for (int step = 0; step + 1 < n_levels; ++step) {
+        if (net.n_ups < 1) return false;
+        const int kidx = step % net.n_ups;
+        const double su = abs_sum(&net.ups_w[static_cast<size_t>(kidx) * net.ups_k], net.ups_k);
+        const double sp = abs_sum(&net.pre_w[static_cast<size_t>(kidx) * net.pre_k], net.pre_k);
+        const double up = bound * su * su;            // every tap of the kron kernel at once: >= any output's taps
+        const double pre = 64.0 * (sp * sp + 1.0);    // conv of the level's own latent + the latent (residual)
+        bound = std::max(up, pre);
+        if (!(bound < kLimit)) return false;
+    }
+    // ---- synthesis: one bound per layer (max over its outputs) ----
+    const double in_bound = std::max(bound, noise ? 1024.0 : 0.0);  // Box-Muller of a 31-bit generator (< 6.6) through <= 8 bicubic x2 steps
+    auto layer_bound = [&](const SynLayerParams& L, double x) {
+        const size_t per_out = static_cast<size_t>(L.c_in) * L.k * L.k;
+        double worst = 0;
+        for (int o = 0; o < L.c_out; ++o) {
+            const double b = L.b.empty() ? 0.0 : std::fabs(static_cast<double>(L.b[o]));
+            worst = std::max(worst, b + abs_sum(&L.w[static_cast<size_t>(o) * per_out], per_out) * x);
+        }
+        return worst + (L.residual ? x : 0.0);
+    };
+    double x = in_bound;
+    for (const SynLayerParams& L : net.syn) {
+        x = layer_bound(L, x);
+        if (!(x < kLimit)) return false;
+    }
+    if (net.syn_stab.c_out) {
+        x += layer_bound(net.syn_stab, in_bound);
+        if (!(x < kLimit)) return false;
+    }
+    x = layer_bound(net.syn_out, x);
+    return x < kLimit;
+}
+
 void context_offsets(int n_spatial, int* dy, int* dx) {
     // arm.py:501-509: priority of each of the 40 causal positions of the 9x9 mask, row-major.
     static const int kPriority[40] = {38, 35, 30, 25, 23, 31, 36, 37, 39, 33, 28, 21, 20, 6,  15, 22, 29, 34, 32, 18,

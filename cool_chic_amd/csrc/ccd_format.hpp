@@ -90,6 +90,15 @@ struct Network {
     SynLayerParams syn_out;              // output transform 1x1
 };
 
+// Static envelope of the float stages (upsampling.py:463-500, synthesis.py:272-294): true when NO intermediate value of the
+// latent pyramid or of the synthesis can leave the finite float32 range, whatever the latents (|x| <= 64) - worst-case
+// magnitudes propagated through every filter and layer (sum of |weights| x bound + |bias|), with a margin of 2^7.  Networks
+// inside it (every trained one: bounds of 2^10 .. 2^20) may run the matrix-core kernel, whose zero-weight padding
+// (fma(v, 0, acc) == acc) and NaN-dropping ReLU are exact only for finite v; the others run the vector-ALU kernels, which
+// evaluate exactly the oracle's taps and propagate NaN like torch.relu.  `n_levels` latent levels reach the synthesis,
+// `noise` common-randomness planes beside them.
+bool float_path_stays_finite(const Network& net, int n_levels, int noise);
+
 int decode_exp_golomb(const uint8_t* p, size_t n, int n_pad_bits, const std::vector<int>& count,
                       std::vector<int64_t>& out);
 // Number of transmitted integers per (module, weight|bias) group, stream order (types.py:18-19,98-101).

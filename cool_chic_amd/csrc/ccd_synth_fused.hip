@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kSfThreads) void syn_fused_kernel(const SynthFused*
                 }
                 if (p.relu0) {
 #pragma unroll
-                    for (int u = 0; u < kSfGroup; ++u) a[u] = a[u] > 0.0f ? a[u] : 0.0f;
+                    for (int u = 0; u < kSfGroup; ++u) a[u] = a[u] <= 0.0f ? 0.0f : a[u];  // NaN stays NaN like torch.relu
                 }
 #pragma unroll
                 for (int j = 0; j < C; ++j) {
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kSfThreads) void syn_fused_kernel(const SynthFused*
 #pragma unroll
                 for (int j = 0; j < C; ++j) {
                     float v = o[u][j];
-                    if (p.relu1) v = v > 0.0f ? v : 0.0f;
+                    if (p.relu1) v = v <= 0.0f ? 0.0f : v;
                     bufA[j * kSfPos + pos] = v;
                 }
             }
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kSfThreads) void syn_fused_kernel(const SynthFused*
                 for (int j = 0; j < C; ++j) {
                     float v = acc[j];
                     if (residual) v = v + cur[j * kSfPos + pos];
-                    if (relu) v = v > 0.0f ? v : 0.0f;
+                    if (relu) v = v <= 0.0f ? 0.0f : v;
                     nxt[j * kSfPos + pos] = v;
                 }
             }

@@ -157,7 +157,11 @@ int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64);
  * inside the pipelined entropy kernel (exact limb-split int8, ccd_entropy_pipe.hip), bit 4 = the pipelined kernel's
  * instantiation that checks the IFCE features on the device (networks whose worst-case feature does not fit 16 bits),
  * bit 5 = the pipelined kernel's instantiation with a compile-time ARM shape (intra/hop.cfg: 14 + 6 inputs, two hidden layers),
- * bit 6 = the fused float kernel runs behind the batch's pyramid launch (CCD_OPT_FUSED_DEC = 2). */
+ * bit 6 = the fused float kernel runs behind the batch's pyramid launch (CCD_OPT_FUSED_DEC = 2),
+ * bit 7 = the network is OUTSIDE the finite envelope of the float stages (some latents could drive an intermediate value of the
+ *         pyramid or the synthesis beyond float32: crafted or corrupt parameter payloads) - such a slot never runs the
+ *         matrix-core kernel (bit 2 clear) but the vector-ALU kernels, which stay bit-identical with the reference
+ *         arithmetic for inf and propagate NaN like torch.relu. */
 int ccd_batch_slot_kernels(const ccd_batch* b, int slot);
 
 /* Batch options, to be set before the slots they concern are added:
@@ -328,8 +332,9 @@ int ccd_debug_laplace_sweep(int device, int which, int scale_first, int n_scales
 int ccd_network_fits_fast_path(const uint8_t* cc_header, size_t n_hdr, const uint8_t* bytes_nn, size_t n_nn);
 /* Host only: WHICH entropy-kernel instantiation a batch with default options gives this cool-chic (tests and DESIGN.md's
  * instantiation table): bit 0 = pipelined kernel (else the generic one), bit 4 = its instantiation with the device check of the
- * IFCE features (worst-case feature >= 2^15), bits 8..11 = NV = ceil(ARM inputs / 4), bits 12..15 = ARM layers (hidden + output).
- * Same bits 0 and 4 as ccd_batch_slot_kernels.  < 0 on a malformed header / payload. */
+ * IFCE features (worst-case feature >= 2^15), bit 7 = the network is outside the finite envelope of the float stages (vector-ALU
+ * float kernels only), bits 8..11 = NV = ceil(ARM inputs / 4), bits 12..15 = ARM layers (hidden + output).
+ * Same bits 0, 4 and 7 as ccd_batch_slot_kernels.  < 0 on a malformed header / payload. */
 int ccd_network_kernel_class(const uint8_t* cc_header, size_t n_hdr, const uint8_t* bytes_nn, size_t n_nn);
 
 /* Profile builds only (-DCCD_FD_PROFILE): cycles per phase of the fused float kernel, summed over wave 0 of every

@@ -733,7 +733,7 @@ static void syn_conv(const float* in, int cin, int h, int w, const float* wt, co
                         }
                     }
                 if (residual) acc = acc + in[co * plane + (size_t)y * w + x];
-                if (relu) acc = acc > 0.0f ? acc : 0.0f;
+                if (relu) acc = acc <= 0.0f ? 0.0f : acc; /* torch.relu: NaN stays NaN (x > 0 ? x : 0 would drop it), -0 -> +0 */
                 out[co * plane + (size_t)y * w + x] = acc;
             }
 }

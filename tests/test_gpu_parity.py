@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import IMAGE_STREAMS, SMALL_STREAMS, VIDEO_STREAMS, load_golden, reference_planes
+from float_classes import nan_aware_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -669,27 +670,38 @@ def test_fuzzed_streams_never_hang_and_match_the_oracle(gpu, oracle):
             bad = bytearray(lat)
             for pos in rng.integers(8, len(bad), size=int(rng.integers(1, 6))):
                 bad[pos] ^= 1 << int(rng.integers(0, 8))
-            cases.append((hdr, nn, bytes(bad)))
+            cases.append((hdr, nn, bytes(bad), False))
         for _ in range(n_mut):  # network bit flips (weights change: decoding stays well defined)
             badn = bytearray(nn)
             badn[int(rng.integers(len(badn) // 2, len(badn)))] ^= 1 << int(rng.integers(0, 8))
-            cases.append((hdr, bytes(badn), lat))
-        cases.append((hdr, nn, lat[: 4 * (len(lat) // 8)]))  # truncated payload: the coder reads zeros past the end
-    n_rejected = 0
-    for hdr, nn, lat in cases:
+            cases.append((hdr, bytes(badn), lat, True))
+        for _ in range(n_mut):  # ... several flips at once in the upsampling / synthesis half: larger damage to the float stages
+            badn = bytearray(nn)
+            for pos in rng.integers(len(badn) // 2, len(badn), size=int(rng.integers(2, 9))):
+                badn[pos] ^= 1 << int(rng.integers(0, 8))
+            cases.append((hdr, bytes(badn), lat, True))
+        cases.append((hdr, nn, lat[: 4 * (len(lat) // 8)], False))  # truncated payload: the coder reads zeros past the end
+    cases = [c if len(c) == 4 else (*c, False) for c in cases]
+    n_rejected = n_float = n_outside = 0
+    for hdr, nn, lat, all_stages in cases:
+        # a damaged NETWORK payload goes through every stage (r05): the float stages must equal the oracle's bit for bit too
+        # - whatever the flipped weights make of them, incl. overflow (the finite envelope then selects the vector-ALU kernels)
         try:
-            ref = oracle.decode_coolchic(hdr, nn, lat, stop_after_entropy=True)
+            ref = oracle.decode_coolchic(hdr, nn, lat, stop_after_entropy=not all_stages)
         except oracle.OracleError:
             ref = None
         b = gpu(0)
         try:
             try:
-                b.add(hdr, nn, lat, 0, 0)
+                b.add(hdr, nn, lat, 8 if all_stages else 0, 0)
             except CcdError:
                 assert ref is None, "the device path rejected a stream the oracle decodes"
                 n_rejected += 1
                 continue
-            b.run(stage=0)
+            if all_stages:
+                b.run()
+            else:
+                b.run(stage=0)
             if ref is None:
                 with pytest.raises(CcdError):
                     b.wait()
@@ -698,9 +710,59 @@ def test_fuzzed_streams_never_hang_and_match_the_oracle(gpu, oracle):
                 b.wait()
                 for g in range(ref["n_grids"]):
                     assert np.array_equal(b.latent(0, g), ref["latent"][g])
+                if all_stages and ref["out"].shape[0] >= 3:
+                    ok, n_bad = nan_aware_equal(b.output(0), ref["out"])
+                    assert ok, f"{n_bad} words of the synthesis output differ from the oracle's"
+                    n_float += 1
+                    n_outside += bool(b.slot_kernels(0) & 128)
         finally:
             b.close()
     assert n_rejected < len(cases)  # most mutations still decode (to different symbols): both paths must agree on them
+    assert n_float >= 10
+
+
+def test_float_stage_operand_classes(gpu, oracle):
+    """The float stages on what a hostile network payload can produce (tests/float_classes.py: overflow to inf, inf - inf = NaN,
+    subnormal values, products that underflow, signed zeros, the extremes of the format's quantisation steps, gains stepping up
+    to FLT_MAX): synthesis output == the oracle's bit for bit (two NaNs are equal), integer planes equal wherever the output is
+    not NaN.  Networks inside the finite envelope run the matrix-core kernel in both its forms AND the vector-ALU path; the
+    others must have been routed to the vector-ALU path by the host (slot_kernels bit 7 set, bit 2 clear)."""
+    from float_classes import crafted
+
+    cases = crafted(load_golden, oracle)
+    seen = {"nan": 0, "inf": 0, "subnormal_dense": 0}
+    for name, ((hdr, nn, lat), stream, inside) in cases.items():
+        ref = oracle.decode_coolchic(hdr, nn, lat)
+        want_planes = oracle.decode_video(stream)[0]["planes"]
+        nan_px = np.isnan(ref["out"]).any(axis=0)
+        seen["nan"] += int(np.isnan(ref["out"]).any())
+        seen["inf"] += int(np.isinf(ref["out"]).any())
+        u = ref["dense"].view(np.uint32)
+        seen["subnormal_dense"] += int((((u & 0x7F800000) == 0) & ((u & 0x007FFFFF) != 0)).any())
+        for mode in (2, 1, 0):
+            b = gpu(0, fused_dec=mode)
+            try:
+                b.add(hdr, nn, lat, 8, 0)
+                b.run(); b.wait()
+                k = b.slot_kernels(0)
+                if inside is not None:
+                    assert bool(k & 128) == (not inside), name
+                if k & 128 or mode == 0:
+                    assert not k & 4, f"{name}: a network outside the finite envelope on the matrix-core kernel"
+                elif inside:
+                    assert k & 4, name
+                for g in range(ref["n_grids"]):
+                    assert np.array_equal(b.latent(0, g), ref["latent"][g]), name
+                ok, n_bad = nan_aware_equal(b.output(0), ref["out"])
+                assert ok, f"{name} (fused_dec={mode}): {n_bad} words of the synthesis output differ from the oracle's"
+                if not k & 4:
+                    ok, n_bad = nan_aware_equal(b.dense(0), ref["dense"])
+                    assert ok, f"{name}: {n_bad} words of the dense pyramid differ"
+                for p, w in zip(b.planes(0), want_planes):
+                    assert np.array_equal(p[~nan_px], w[~nan_px].astype(p.dtype)), name
+            finally:
+                b.close()
+    assert seen["nan"] and seen["inf"] and seen["subnormal_dense"], seen
 
 
 def test_rate_model_matches_the_reference(gpu):
@@ -888,6 +950,116 @@ def test_video_gop_sharded_over_two_gpus_nccl(gpu, oracle):
     _run_sharded("nccl", oracle)
 
 
+def _nccl_one_rank_worker(port, golden, q):
+    """Runs in a spawned process: everything of the N > 1 path that a single rank can execute on the "nccl" backend."""
+    import os
+    import sys
+    import traceback
+
+    try:
+        import torch
+        import torch.distributed as dist
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        sys.path.insert(0, os.path.dirname(os.path.dirname(golden)))
+        import bench
+        from cool_chic_amd import DecodeBatch, synth
+        from cool_chic_amd.bitstream.decode import decode_video_sharded
+        from cool_chic_amd.parallel import EqualSizeGather, gather_bytes, pack_planes
+        from oracle import oracle_py
+
+        res = {"backend": dist.get_backend()}
+        # (1) scalar reductions on cuda tensors, as bench.py does with red_dev = cuda
+        t = torch.tensor([7], dtype=torch.int64, device="cuda:0")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        td = torch.tensor([0.25], dtype=torch.float64, device="cuda:0")
+        dist.all_reduce(td, op=dist.ReduceOp.MAX)
+        res["all_reduce"] = (int(t.item()), float(td.item()))
+        # (2) 8-bit planes of a decoded frame, zero-copy views of library memory, through EqualSizeGather: the wire is the device tensor
+        with open(os.path.join(golden, "rgb192.cool"), "rb") as f:
+            bs8 = f.read()
+        fh, ccs = oracle_py.split_stream(bs8)[1][0]
+        b = DecodeBatch(0)
+        b.add(*ccs[0], fh.bitdepth, fh.frame_data_type)
+        b.run(); b.wait()
+        planes = [torch.as_tensor(b.plane_device(0, p), device="cuda:0").reshape(-1) for p in range(3)]
+        g = EqualSizeGather(sum(int(p.numel()) for p in planes), "cuda:0", dst=0)
+        res["staged"] = g.staged
+        got = g(planes)
+        res["wire_is_cuda"] = bool(got[0].is_cuda)
+        res["gather8_ok"] = bool(torch.equal(got[0].cpu(), torch.cat([torch.from_numpy(x.reshape(-1)) for x in b.planes(0)])))
+        b.close()
+        # (3) 16-bit planes (10-bit 4:2:0 frame): view(torch.uint8) of contiguous uint16 device tensors, variable-size gather
+        with open(os.path.join(golden, "yuv420_10b.cool"), "rb") as f:
+            bs10 = f.read()
+        fh, ccs = oracle_py.split_stream(bs10)[1][0]
+        b = DecodeBatch(0)
+        b.add(*ccs[0], fh.bitdepth, fh.frame_data_type)
+        b.run(); b.wait()
+        p16 = [torch.as_tensor(b.plane_device(0, p), device="cuda:0") for p in range(3)]
+        res["dtype16"] = str(p16[0].dtype)
+        msg = pack_planes(p16)
+        back = gather_bytes(msg, dst=0)
+        host = [x.astype("<u2").tobytes() for x in b.planes(0)]
+        res["gather16_ok"] = bool(back[0].cpu().numpy().tobytes() == b"".join(host))
+        g16 = EqualSizeGather(int(msg.numel()), "cuda:0", dst=0)
+        res["gather16_fixed_ok"] = bool(g16(p16)[0].cpu().numpy().tobytes() == b"".join(host))
+        b.close()
+        # (4) the sharded GOP entry point with an initialised nccl group (one rank owns every frame: no send / recv)
+        frames = decode_video_sharded(os.path.join(golden, "vid5.cool"), device=0)
+        res["gop"] = {k: [np.asarray(p) for p in fd.integer_planes()] for k, fd in frames.items()}
+        # (5) bench.py's timed step with the gather inside, exactly as the driver's N > 1 run enqueues it
+        streams, sizes = synth.kodak24()
+        items = [(*synth.split_image_stream(s_), hw) for s_, hw in zip(streams[:3], sizes[:3])]
+        run = bench.timed_set(items, 1, 0, 0, "nccl", "cuda:0", 2, 1, force_gather=True)
+        ver = bench.verify_gathered("kodak24", run["gathered"], lambda r: [(i, items[i][3]) for i in range(3)])
+        run["batch"].close()
+        res["bench_gather"] = {"ok": ver["ok"], "frames": ver["frames_checked"], "dt": run["dt"]}
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(("ok", res))
+    except Exception:  # noqa: BLE001 - reported to the parent
+        q.put(("error", traceback.format_exc()))
+
+
+def test_nccl_wire_path_on_one_rank(gpu, oracle):
+    """RCCL with world_size = 1 on cuda:0: it cannot prove xGMI, it does execute every `staged == False` branch of
+    cool_chic_amd/parallel.py (EqualSizeGather, gather_bytes with device tensors on the wire, 16-bit planes as
+    view(torch.uint8)), the cuda-scalar reductions and bench.py's timed step with the gather of decoded planes inside - the
+    code a single-GPU box never ran before.  Point-to-point send / recv needs a second rank:
+    test_video_gop_sharded_over_two_gpus_nccl."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from conftest import GOLDEN
+
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_nccl_one_rank_worker, args=(port, GOLDEN, q))
+    proc.start()
+    status, res = q.get(timeout=600)
+    proc.join(timeout=120)
+    assert status == "ok", res
+    assert proc.exitcode == 0
+    assert res["backend"] == "nccl" and res["all_reduce"] == (7, 0.25)
+    assert res["staged"] is False and res["wire_is_cuda"] and res["gather8_ok"]
+    assert res["dtype16"] == "torch.uint16" and res["gather16_ok"] and res["gather16_fixed_ok"]
+    bs, _, _ = load_golden("vid5")
+    want = {str(fr["display_index"]): fr["planes"] for fr in oracle.decode_video(bs)}
+    assert sorted(res["gop"]) == sorted(want)
+    for k in want:
+        for p, w in zip(res["gop"][k], want[k]):
+            assert np.array_equal(p.astype(np.uint16), w), k
+    assert res["bench_gather"]["ok"] is True and res["bench_gather"]["frames"] == 3
+
+
 def test_streams_the_reference_cannot_decode_are_rejected(gpu, oracle):
     """Headers that parse but that the reference's decoder raises on (or that would read out of bounds here) give
     CCD_ERR_VALUE instead of garbage: latent / hyperlatent ranges that do not touch (torch.cat of grids two levels
@@ -971,6 +1143,34 @@ def test_streams_the_reference_cannot_decode_are_rejected(gpu, oracle):
         for h_, n_, l_ in cc:
             out.append(h_ + n_ + l_)
     assert decode(b"".join(out)) == -2
+    # ... but a header type that needs FEWER references than the structure gives decodes, by the header's type (decode.py:119-128,
+    # 156-189; apply_global_translation zips references with flows): the B frame at coding index 2 relabelled P predicts from
+    # the structure's first reference; the P frame at coding index 1 replaced by an I header + the I frame's cool-chic is plain
+    # intra (and the B frames then predict from that).  The oracle follows the frame headers, which here agree with the structure.
+    def relabel(kind):
+        out = [writer.video_header_bytes(vh.n_frames, list(vh.intra_pos[:vh.n_intras]), list(vh.p_pos[:vh.n_p_frames]))]
+        for k, (f, cc) in enumerate(frames):
+            t, refs, gf, body = "IPB"[f.frame_type], list(f.index_references[:f.n_refs]), list(f.global_flow[:2 * f.n_refs]), cc
+            if kind == "B_as_P" and k == 2:
+                assert t == "B"
+                t, refs, gf = "P", refs[:1], gf[:2]
+            if kind == "P_as_I" and k == 1:
+                assert t == "P"
+                t, refs, gf, body = "I", [], [], frames[0][1]
+            out.append(writer.frame_header_bytes(f.display_index, t, f.frame_data_type, f.bitdepth, refs, gf, f.warp_filter_size))
+            for h_, n_, l_ in body:
+                out.append(h_ + n_ + l_)
+        return b"".join(out)
+
+    for kind in ("B_as_P", "P_as_I"):
+        stream, got = relabel(kind), []
+        assert decode(stream, got) == 0, kind
+        want = oracle.decode_video(stream)
+        assert len(got) == len(want) == 5
+        for fa, fb in zip(got, want):
+            for pa, pb in zip(fa, fb["planes"]):
+                assert np.array_equal(pa, pb), kind
+        assert any(not np.array_equal(a, b) for fa, fb in zip(got, plain) for a, b in zip(fa, fb)), kind  # the relabelling matters
 
 
 @pytest.mark.parametrize("name", ["kodak24", "kodak24_wide_envelope", "clic41", "uhd4k", "gop1080p33"])

@@ -382,3 +382,37 @@ def test_generated_kernel_tables_are_current(tmp_path, monkeypatch):
             mod.main()
     for n in names:
         assert (fake / "cool_chic_amd" / "csrc" / n).read_text() == open(os.path.join(csrc, n)).read(), n
+
+
+def test_float_envelope_of_fixtures_and_crafted_networks(oracle):
+    """ccd::float_path_stays_finite through ccd_network_kernel_class bit 7 (host only): every network the reference encoder
+    produced and every synthetic workload's network is INSIDE the finite envelope (they run the matrix-core float kernel);
+    the crafted networks of tests/float_classes.py fall on the side they were built for, the oracle's outputs for them really
+    contain the classes (NaN, inf, subnormals) the GPU test compares on, and a network inside the envelope never produces a
+    non-finite value."""
+    from float_classes import crafted
+    from cool_chic_amd import synth
+    from cool_chic_amd._lib import lib
+
+    for name in IMAGE_STREAMS + VIDEO_STREAMS:
+        for _fh, ccs in oracle.split_stream(load_golden(name)[0])[1]:
+            for hdr, nn, _lat in ccs:
+                k = lib().ccd_network_kernel_class(hdr, len(hdr), nn, len(nn))
+                assert k > 0 and not k & 128, name
+    for stream in (synth.image_stream(1365, 2048, 0), synth.image_stream(2160, 3840, 0)):  # the grown 8- and 9-level networks
+        hdr, nn, _ = synth.split_image_stream(stream)
+        assert not lib().ccd_network_kernel_class(hdr, len(hdr), nn, len(nn)) & 128
+    n_nonfinite = n_sub = 0
+    for name, ((hdr, nn, lat), _stream, inside) in crafted(load_golden, oracle).items():
+        k = lib().ccd_network_kernel_class(hdr, len(hdr), nn, len(nn))
+        assert k > 0
+        if inside is not None:
+            assert bool(k & 128) == (not inside), name
+        ref = oracle.decode_coolchic(hdr, nn, lat)
+        finite = np.isfinite(ref["out"]).all() and np.isfinite(ref["dense"]).all() and np.isfinite(ref["syn_out"]).all()
+        if not k & 128:
+            assert finite, f"{name}: inside the envelope, yet the oracle met a non-finite value"
+        n_nonfinite += not finite
+        u = ref["dense"].view(np.uint32)
+        n_sub += bool((((u & 0x7F800000) == 0) & ((u & 0x007FFFFF) != 0)).any())
+    assert n_nonfinite >= 2 and n_sub >= 1

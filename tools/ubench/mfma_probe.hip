@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -202,6 +203,107 @@ int main() {
         }
         printf("exactness: 4x4x1 MFMA chain (K=57) vs __fmaf_rn chain: %ld / %ld words differ\n", bad, total);
     }
+    // ---- 2b. exactness by operand class (r05): the float stages' claim "a chain of v_mfma_f32_4x4x1 IS the oracle's fmaf chain"
+    // for what a bit-flipped network payload can produce: subnormal operands, products that underflow, accumulators of +-0 with zero
+    // products of both signs, +-inf, NaN, values near FLT_MAX.  Three chains per case: the MFMA, __fmaf_rn on the vector ALU
+    // (the unfused kernels), std::fmaf on the host (what oracle/cc_oracle.c calls).  "differ" = bitwise; "non-NaN" leaves out the
+    // words that are NaN on both sides (IEEE 754 does not fix a NaN's payload or sign).
+    {
+        const int K = 57;
+        std::vector<float> w(K * 4), x(K * 64), c0(256), m(256), v(256), h(256);
+        float *dw, *dx, *dc, *dm, *dv;
+        CHECK(hipMalloc(&dw, K * 16)); CHECK(hipMalloc(&dx, K * 256)); CHECK(hipMalloc(&dc, 1024)); CHECK(hipMalloc(&dm, 1024)); CHECK(hipMalloc(&dv, 1024));
+        auto bits = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+        auto urand = []() { return (uint32_t)rand() * 2654435761u ^ ((uint32_t)rand() << 11); };
+        auto sgn = [&]() { return (rand() & 1) ? -1.0f : 1.0f; };
+        struct Cls { const char* name; int id; };
+        const Cls classes[] = {{"subnormal inputs (w or x below 2^-126)", 0}, {"products that underflow, small accumulators", 1},
+                               {"accumulators +-0, zero products of both signs", 2}, {"+-inf among the operands", 3},
+                               {"NaN among the operands", 4}, {"near FLT_MAX: overflowing products and sums", 5},
+                               {"arbitrary bit patterns (any exponent, any class)", 6}, {"cancellation: sums that return to 0 or to subnormals", 7}};
+        for (const Cls& cl : classes) {
+            long bad_mv = 0, bad_mv_nn = 0, bad_mh = 0, bad_mh_nn = 0, total = 0, n_nan = 0, n_sub = 0, n_inf = 0, n_negzero = 0;
+            for (int trial = 0; trial < 100; ++trial) {
+                srand(7000 + 131 * cl.id + trial);
+                for (auto& f : w) f = frand();
+                for (auto& f : x) f = frand();
+                for (auto& f : c0) f = frand();
+                switch (cl.id) {
+                    case 0:
+                        for (auto& f : w) if (rand() % 3 == 0) f = bits((urand() & 0x807fffffu));             // subnormal, either sign
+                        for (auto& f : x) if (rand() % 3 == 0) f = bits((urand() & 0x807fffffu));
+                        for (auto& f : c0) { int r = rand() % 4; if (r == 0) f = bits(urand() & 0x807fffffu); else if (r == 1) f = 0.0f; else if (r == 2) f *= 1e-38f; }
+                        if (trial & 1) { for (auto& f : w) f *= 1e-30f; }                                       // normal x subnormal -> far below
+                        break;
+                    case 1:
+                        for (auto& f : w) f *= (rand() & 1) ? 1e-22f : 1e-19f;
+                        for (auto& f : x) f *= (rand() & 1) ? 1e-22f : 1e-19f;
+                        for (auto& f : c0) { int r = rand() % 3; f = r == 0 ? 0.0f : f * (r == 1 ? 1e-41f : 1e-37f); }
+                        break;
+                    case 2:
+                        for (auto& f : w) { int r = rand() % 4; if (r == 0) f = 0.0f; else if (r == 1) f = -0.0f; }
+                        for (auto& f : x) { int r = rand() % 4; if (r == 0) f = 0.0f; else if (r == 1) f = -0.0f; }
+                        if (trial % 2 == 0) { for (auto& f : w) f = (rand() & 1) ? 0.0f : -0.0f; }              // every product a signed zero
+                        for (auto& f : c0) f = (rand() & 1) ? 0.0f : -0.0f;
+                        break;
+                    case 3:
+                        for (auto& f : w) if (rand() % 29 == 0) f = sgn() * INFINITY;
+                        for (auto& f : x) if (rand() % 97 == 0) f = sgn() * INFINITY;
+                        for (auto& f : c0) if (rand() % 7 == 0) f = sgn() * INFINITY;
+                        if (trial % 3 == 0) for (auto& f : x) if (rand() % 11 == 0) f = 0.0f;                    // inf * 0
+                        break;
+                    case 4:
+                        for (auto& f : w) if (rand() % 57 == 0) f = bits(0x7f800000u | (urand() & 0x807fffffu) | 1u);  // quiet and signalling, both signs
+                        for (auto& f : x) if (rand() % 301 == 0) f = bits(0x7fc00000u | (urand() & 0x803fffffu));
+                        for (auto& f : c0) if (rand() % 13 == 0) f = bits(0x7fc00000u | (urand() & 0x803fffffu));
+                        break;
+                    case 5:
+                        for (auto& f : w) f *= (rand() % 3 == 0) ? 1.5e19f : 1e18f;
+                        for (auto& f : x) f *= (rand() % 3 == 0) ? 1.5e19f : 1e18f;
+                        for (auto& f : c0) f = sgn() * (3.0e38f + 0.4e38f * (float)rand() / RAND_MAX);          // |c| up to FLT_MAX = 3.4028e38
+                        break;
+                    case 6:
+                        for (auto& f : w) f = bits(urand());
+                        for (auto& f : x) f = bits(urand());
+                        for (auto& f : c0) f = bits(urand());
+                        if (trial & 1) { for (auto& f : w) f = bits((urand() & 0x80ffffffu) | ((uint32_t)(100 + rand() % 56) << 23)); // exponents near 1
+                                         for (auto& f : x) f = bits((urand() & 0x80ffffffu) | ((uint32_t)(100 + rand() % 56) << 23)); }
+                        break;
+                    case 7:  // every second step undoes the one before: the accumulator passes through 0 / tiny values again and again
+                        for (int k = 0; k + 1 < K; k += 2) {
+                            for (int r = 0; r < 4; ++r) w[(k + 1) * 4 + r] = -w[k * 4 + r];
+                            for (int l = 0; l < 64; ++l) x[(k + 1) * 64 + l] = x[k * 64 + l];
+                        }
+                        for (auto& f : c0) { int r = rand() % 4; f = r == 0 ? 0.0f : (r == 1 ? -0.0f : (r == 2 ? f * 1e-39f : f * 1e-7f)); }
+                        if (trial & 1) for (auto& f : w) f *= 1e-20f, (void)0;
+                        if (trial & 1) for (auto& f : x) f *= 1e-20f;
+                        break;
+                }
+                CHECK(hipMemcpy(dw, w.data(), K * 16, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dx, x.data(), K * 256, hipMemcpyHostToDevice));
+                CHECK(hipMemcpy(dc, c0.data(), 1024, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(exact_kernel, dim3(1), dim3(64), 0, 0, dw, dx, dc, K, dm, dv);
+                CHECK(hipMemcpy(m.data(), dm, 1024, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(v.data(), dv, 1024, hipMemcpyDeviceToHost));
+                for (int l = 0; l < 64; ++l)
+                    for (int r = 0; r < 4; ++r) {
+                        volatile float acc = c0[l * 4 + r];
+                        for (int k = 0; k < K; ++k) acc = fmaf(w[k * 4 + r], x[k * 64 + l], acc);
+                        h[l * 4 + r] = acc;
+                    }
+                for (int i = 0; i < 256; ++i) {
+                    ++total;
+                    uint32_t um, uv, uh;
+                    memcpy(&um, &m[i], 4); memcpy(&uv, &v[i], 4); memcpy(&uh, &h[i], 4);
+                    const bool nm = m[i] != m[i], nv = v[i] != v[i], nh = h[i] != h[i];
+                    if (um != uv) { ++bad_mv; if (!(nm && nv)) ++bad_mv_nn; }
+                    if (um != uh) { ++bad_mh; if (!(nm && nh)) ++bad_mh_nn; }
+                    n_nan += nh; n_inf += (!nh && (uh & 0x7fffffffu) == 0x7f800000u); n_sub += ((uh & 0x7f800000u) == 0 && (uh & 0x007fffffu) != 0); n_negzero += (uh == 0x80000000u);
+                }
+            }
+            printf("class %d %-52s MFMA vs __fmaf_rn: %ld differ (%ld non-NaN) | MFMA vs host fmaf: %ld differ (%ld non-NaN) of %ld  [results: %ld NaN, %ld inf, %ld subnormal, %ld -0]\n",
+                   cl.id, cl.name, bad_mv, bad_mv_nn, bad_mh, bad_mh_nn, total, n_nan, n_inf, n_sub, n_negzero);
+        }
+    }
+    if (getenv("MFMA_PROBE_EXACT_ONLY")) return 0;
     // ---- 3/4. rates ----
     uint64_t* dout; CHECK(hipMalloc(&dout, 16 * 64)); CHECK(hipMemset(dout, 0, 16 * 64));
     uint64_t ho[128];
