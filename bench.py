@@ -226,13 +226,19 @@ def image_leg(name, device, sh, stream, steps, cpu_budget, want_cpu):
     ms_float = event_ms(stream, lambda: (b.run(sh, stage=1), b.run(sh, stage=2)), max(1, steps // 2), device)
     b.wait(sh)
     nsym = n_symbols(b, len(triples))
+    stats = [b.slot_stats(s) for s in range(len(triples))]
     verified = verify_frames(name, [b.planes(i) for i in range(len(triples))], streams=wl["streams"])
+    hdrs = [b.header(i) for i in range(len(triples))]
     b.close()
     leg = {"frames": len(triples), "mpixels": sum(px) / 1e6, "verified": verified, "value": sum(px) / ms / 1e3, "unit": "Mpixel/s", "n_gpus": 1, "steps": steps,
            "ms_per_step": ms, "entropy_ms": ms_entropy, "float_ms": ms_float, "symbols": nsym,
            "entropy_msym_per_s": nsym / ms_entropy / 1e3, "largest_frame_mpx": max(px) / 1e6,
            "slots_on_generic_entropy_kernel": sum(1 for k in kernels if not k & 1),
            "slots_on_unfused_float_path": sum(1 for k in kernels if not k & 4),
+           "entropy_kernel_widths_nv": sorted({(b_.total_context_arm + 3) // 4 for b_ in hdrs}),
+           "bpp": 8.0 * sum(len(t[2]) for t in triples) / sum(px),
+           # symbols that left the decoder's common path (window misses / sentinels), and the full 128-way searches among them
+           "rare_path_symbols": int(sum(int(st[62]) for st in stats)), "full_searches": int(sum(int(st[63]) for st in stats)),
            "stream_bytes": int(sum(len(s) for s in wl["streams"])), "build_s": round(t_build, 1),
            "note": "one batch, one workgroup (one CU) per stream: the step time is the slowest stream's serial chain"}
     if want_cpu:
@@ -386,7 +392,7 @@ def main():
     ap.add_argument("--scaling", choices=["strong", "weak", "throughput"], default="strong",
                     help="strong (default): BASELINE's kodak24, its 24 frames round-robin over the ranks; weak: every rank its own "
                          "kodak24; throughput: every rank its own 256 streams (kodak24 repeated: one per CU)")
-    ap.add_argument("--legs", default="all", help="comma list of clic41,gop1080p33,uhd4k,wide,png,e2e,float,envelope,rate (rank 0, N = 1) and sharded (N > 1: "
+    ap.add_argument("--legs", default="all", help="comma list of clic41,gop1080p33,uhd4k,wide,png,e2e,float,envelope,rate,kodak24_hq,clic41_alt,cliffs (rank 0, N = 1) and sharded (N > 1: "
                     "clic41_sharded + throughput_regime with all ranks), or all / none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes (roofline.traffic then "
@@ -415,7 +421,7 @@ def main():
         else:
             dist.init_process_group("gloo")
     red_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"  # where the scalar reductions live
-    all_legs = ["clic41", "gop1080p33", "uhd4k", "wide", "png", "e2e", "float", "envelope", "rate"]
+    all_legs = ["clic41", "gop1080p33", "uhd4k", "wide", "png", "e2e", "float", "envelope", "rate", "kodak24_hq", "clic41_alt", "cliffs"]
     legs = all_legs if args.legs == "all" else ([] if args.legs == "none" else args.legs.split(","))
     if world > 1 and args.legs == "all":
         legs = ["sharded"]  # the other configurations are single-GPU legs of the N = 1 run; with N ranks: the sharded sets
@@ -760,8 +766,39 @@ def main():
                 extra[name] = image_leg(name, local_rank, sh, stream, n_leg, 6.0 if name == "clic41" else 16.0, want_cpu)
         if "gop1080p33" in legs:
             extra["gop1080p33"] = gop_leg(local_rank, sh, stream, n_leg, 12.0, want_cpu)
+        # ---- what other content does to the chain (r05): Kodak geometry at 2.4 bpp with 12-15 % wide windows (LOP network of
+        # the reference-encoded hq192), and the CLIC sizes with the VHOP / MOP decoders (two kernel instantiations in one batch)
+        for name in ("kodak24_hq", "clic41_alt"):
+            if name in legs:
+                extra[name] = image_leg(name, local_rank, sh, stream, n_leg, 6.0, False)
+        if "kodak24_hq" in extra:
+            extra["kodak24_hq"]["entropy_ms_ratio_to_kodak24"] = extra["kodak24_hq"]["entropy_ms"] / stage_ms["entropy"]
         if extra:
             res["baseline_configs"] = extra
+        # ---- the fallback cliffs, priced on the metric's own set (r05): CCD_FORCE_GENERIC sends every slot to the generic
+        # int64 entropy kernel (the only path for ARM weights >= 2^31, which the format allows: neuralnet.py:184-188) and to the
+        # per-layer float kernels (architectures outside the presets); the vector-ALU float path alone is fused_dec = 0 above
+        if "cliffs" in legs:
+            os.environ["CCD_FORCE_GENERIC"] = "1"
+            try:
+                bg = DecodeBatch(local_rank)
+            finally:
+                del os.environ["CCD_FORCE_GENERIC"]
+            for hdr, nn, lat, _ in items:
+                bg.add(hdr, nn, lat, 8, 0)
+            bg.run(sh); bg.wait(sh)
+            k_g = [bg.slot_kernels(s_) for s_ in range(n_kodak)]
+            ms_g_ent = event_ms(stream, lambda: bg.run(sh, stage=0), 2, local_rank)
+            ms_g_flt = event_ms(stream, lambda: (bg.run(sh, stage=1), bg.run(sh, stage=2)), 2, local_rank)
+            bg.wait(sh)
+            res["fallback_cliffs"] = {
+                "workload": "kodak24 with CCD_FORCE_GENERIC=1 (every slot on the generic entropy kernel and the per-layer float kernels)",
+                "generic_entropy_ms": ms_g_ent, "ratio_to_pipelined_entropy": ms_g_ent / stage_ms["entropy"],
+                "generic_float_ms": ms_g_flt, "ratio_to_fused_float": ms_g_flt / (stage_ms["pyramid_launch"] + stage_ms["fused_float"]),
+                "value": kodak_px / (ms_g_ent + ms_g_flt) / 1e3, "unit": "Mpixel/s",
+                "slots_on_generic_entropy_kernel": sum(1 for k in k_g if not k & 1), "slots_on_unfused_float_path": sum(1 for k in k_g if not k & 4),
+                "verified": verify_frames("kodak24", [bg.planes(s_) for s_ in range(n_kodak)])}
+            bg.close()
         if want_cpu:
             res["cpu_baseline"] = cpu_sample(streams, [h * w for *_, (h, w) in items], 8.0, "kodak24 streams")
             # measured once in the build container (8-core Xeon 2.1 GHz, torch 2.10 CPU): the reference's own PyTorch decode of

@@ -1128,9 +1128,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 mode = (i & static_cast<uint32_t>(bpx - 1)) ? 1u : 0u;  // inside a batch: re-entry behind symbol i - 1
                 continue;
             }
-#ifdef CCD_PIPE_PROFILE
-            S.n_rare += 1;
-#endif
+            S.n_rare += 1;  // (always counted: status[62]; a few per stream)
             // ---- rare path for symbol i (state untouched by the asm region) -----------------------------------
             const int pi = static_cast<int>(i) - i0;  // pixel within the batch
             const uint2* tab = C.s_tab + static_cast<size_t>(row0) * 64 + lane;
@@ -1147,9 +1145,7 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
             uint64_t nd = rc_dist - ((static_cast<uint64_t>(l_hi) << 32) | l_lo);
             uint64_t nr = static_cast<uint64_t>(sc_lo) * psel + (static_cast<uint64_t>(sc_hi * psel) << 32);
             if (nr == 0) {
-#ifdef CCD_PIPE_PROFILE
-                S.n_search += 1;
-#endif
+                S.n_search += 1;  // status[63]
                 // symbol outside the window (or invalid data): full 128-way search
                 const uint64_t scale = rc_range >> kRcPrecision;
                 if ((rc_dist >> kRcPrecision) >= scale) {
@@ -2543,6 +2539,9 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
             P.status[36] = n_streamed;
         }
 #endif
+        // symbols that left the asm region's common path (renormalisations that need a payload refill aside): window misses
+        // and sentinels [62], of which full 128-way searches [63] - what a stream's statistics cost the decoder (bench.py)
+        P.status[62] = static_cast<int32_t>(S.n_rare); P.status[63] = static_cast<int32_t>(S.n_search);
         {   // symbols decoded = all grids unless aborted
             uint64_t n_sym = 0;
             for (int g2 = 0; g2 < P.n_grids; ++g2) n_sym += static_cast<uint64_t>(P.grid_h[g2]) * P.grid_w[g2];
@@ -2557,7 +2556,6 @@ __global__ __launch_bounds__(kPipeThreads) void entropy_pipe_kernel(const Entrop
         o[0] = __builtin_amdgcn_s_memtime() - prof_total0;
         if (wave == 0) {
             o[1] = S.prof_wait; o[2] = S.prof_work; o[3] = prof_ifce; o[4] = prof_bar;
-            P.status[62] = static_cast<int32_t>(S.n_rare); P.status[63] = static_cast<int32_t>(S.n_search);
             P.status[38] = static_cast<int32_t>(S.n_spins);  // polls of ready counters inside the decoder's asm region (~250 ticks each)  // leaves of the asm loop, full searches
         }
         else {

@@ -76,12 +76,17 @@ def split_image_stream(bs: bytes) -> Triple:
     return ch.raw, rest[:n_nn], rest[n_nn:n_nn + ch.get_value("n_bytes_latent")]
 
 
-def _kodim14():
-    bs, z = _golden("kodim14")
+def _image_donor(name: str):
+    """(stream, cc header bytes, NN bytes, parsed header, network integers, latent grids) of a one-frame donor stream."""
+    bs, z = _golden(name)
     hdr, nn, lat = split_image_stream(bs)
     donor = writer.parse_cc_header(hdr)
     latents = [z[f"cc0.latent{g}"] for g in range(donor.n_grids)]
     return bs, hdr, nn, donor, z["cc0.nn_ints"], latents
+
+
+def _kodim14():
+    return _image_donor("kodim14")
 
 
 def kodak24() -> Tuple[List[bytes], List[Tuple[int, int]]]:
@@ -150,9 +155,9 @@ def _rolled(latents: Sequence[np.ndarray], arch: CCHeader, seed: int) -> List[np
     return writer.variant_latents(list(latents), levels, seed, False)
 
 
-def image_stream(h: int, w: int, seed: int = 0) -> bytes:
-    """One RGB 8-bit HOP picture of any size: kodim14's networks grown to the "auto" number of levels, its latents tiled."""
-    _, _, _, donor, ints, latents = _kodim14()
+def image_stream(h: int, w: int, seed: int = 0, donor_name: str = "kodim14") -> bytes:
+    """One RGB 8-bit picture of any size: the donor's networks (kodim14: HOP) grown to the "auto" number of levels, its latents tiled."""
+    _, _, _, donor, ints, latents = _image_donor(donor_name)
     arch = _image_arch(donor, h, w)
     nn = writer.encode_network(arch, writer.adapt_network(donor, ints, arch))
     lat = writer.tile_latents(latents, donor, arch)
@@ -165,6 +170,40 @@ def clic41() -> Tuple[List[bytes], List[Tuple[int, int]]]:
     """BASELINE configs[2]: 41 RGB 8-bit pictures with CLIC20-pro-valid's pixel counts (91.45 Mpx), HOP decoder."""
     with _pool(len(CLIC41_SIZES)) as ex:
         streams = list(ex.map(lambda a: image_stream(a[1][0], a[1][1], 2000 + a[0]), enumerate(CLIC41_SIZES)))
+    return streams, list(CLIC41_SIZES)
+
+
+def kodak24_hq() -> Tuple[List[bytes], List[Tuple[int, int]]]:
+    """kodak24's geometry (18 landscape + 6 portrait 512x768) with the statistics of a HIGH-RATE stream: the network and the
+    latent pyramid of `hq192` (the reference's 192x128 test picture encoded by the reference encoder at lambda = 1e-5: 2.5 bpp,
+    12-15 % of its symbols behind the wide 62-symbol windows, LOP decoder) tiled to Kodak size, rolled / transposed per
+    picture like kodak24.  What real content at the top of results/v5.0/image-kodak.tsv's rate range does to the entropy
+    stage; bench.py leg `kodak24_hq`."""
+    _, hdr, nn, donor, _, latents = _image_donor("hq192")
+    arch = writer.derive_arch(donor, img_size=(512, 768))  # same levels ("auto": < 1 Mpx), so the donor's payload fits as it is
+    hdr = writer.cc_header_bytes(arch)
+    tiled = writer.tile_latents(latents, donor, arch)
+    _, levels = writer.grid_sizes((512, 768), hdr)
+    jobs = [(1500 + i, i in (3, 8, 9, 16, 17, 18)) for i in range(24)]
+
+    def make(job):
+        seed, portrait = job
+        v = writer.variant_latents(tiled, levels, seed, portrait)
+        return writer.encode_stream(hdr, nn, v, img_size=(768, 512) if portrait else (512, 768))
+
+    with _pool(len(jobs)) as ex:
+        streams = list(ex.map(make, jobs))
+    return streams, [((768, 512) if p else (512, 768)) for _, p in jobs]
+
+
+def clic41_alt() -> Tuple[List[bytes], List[Tuple[int, int]]]:
+    """clic41's 41 sizes with OTHER decoders than kodim14's HOP: picture i carries the network and the tiled latents of
+    `vhop192` (i even: cfg/dec/intra/vhop.cfg, 26 ARM inputs -> entropy_pipe_kernel<7>, 64 hidden synthesis units) or `mop192`
+    (i odd: intra/mop.cfg, 14 inputs -> <4>, 16 hidden units), both encoded by the reference encoder, grown to the "auto"
+    levels of the size.  Two kernel instantiations in one batch at 2 K size; bench.py leg `clic41_alt`."""
+    with _pool(len(CLIC41_SIZES)) as ex:
+        streams = list(ex.map(lambda a: image_stream(a[1][0], a[1][1], 2500 + a[0], "mop192" if a[0] & 1 else "vhop192"),
+                              enumerate(CLIC41_SIZES)))
     return streams, list(CLIC41_SIZES)
 
 
@@ -269,7 +308,8 @@ def planes_sha256(planes) -> str:
 
 
 def workload(name: str) -> Dict:
-    """{"streams": [...], "sizes": [(H, W) per frame], "video": bool} for "kodak24" | "clic41" | "uhd4k" | "gop1080p33"."""
+    """{"streams": [...], "sizes": [(H, W) per frame], "video": bool} for "kodak24" | "clic41" | "uhd4k" | "gop1080p33" (BASELINE's
+    configurations) | "kodak24_wide_envelope" | "kodak24_hq" | "clic41_alt" (variants of them)."""
     if name == "kodak24":
         s, z = kodak24()
         return {"streams": s, "sizes": z, "video": False}
@@ -278,6 +318,12 @@ def workload(name: str) -> Dict:
         return {"streams": s, "sizes": z, "video": False}
     if name == "clic41":
         s, z = clic41()
+        return {"streams": s, "sizes": z, "video": False}
+    if name == "kodak24_hq":
+        s, z = kodak24_hq()
+        return {"streams": s, "sizes": z, "video": False}
+    if name == "clic41_alt":
+        s, z = clic41_alt()
         return {"streams": s, "sizes": z, "video": False}
     if name == "uhd4k":
         s, z = uhd4k()

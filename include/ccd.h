@@ -147,7 +147,8 @@ int ccd_batch_slot_status(const ccd_batch* b, int slot);
 /* Raw per-slot counters of the entropy kernel after ccd_batch_wait: [0] status, [1] payload words read,
  * [2..3] symbols decoded (lo, hi); [36] latent grids whose body the pipelined kernel decoded as one stream of pixels
  * (batches cut without regard to wavefront steps: DESIGN.md 4.1); [37] batches its decoder took part by part; [39] pixels it
- * redid in int64 (dynamic operand check); the other words [4..63] are profiling cycle counters when built with
+ * redid in int64 (dynamic operand check); [62] symbols that left the decoder's common path (window misses, sentinels), [63] of
+ * which took the full 128-way search (pipelined kernel); the other words [4..61] are profiling cycle counters when built with
  * -DCCD_PIPE_PROFILE (which also reuses [36] and [37]).
  * `out64` receives 64 words. */
 int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64);

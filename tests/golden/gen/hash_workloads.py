@@ -18,7 +18,7 @@ from concurrent.futures import ProcessPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tests", "golden", "workload_hashes.json")
-WORKLOADS = ["kodak24", "kodak24_wide_envelope", "clic41", "uhd4k", "gop1080p33"]
+WORKLOADS = ["kodak24", "kodak24_wide_envelope", "kodak24_hq", "clic41", "clic41_alt", "uhd4k", "gop1080p33"]
 
 
 def planes_sha256(planes) -> str:

@@ -1173,7 +1173,7 @@ def test_streams_the_reference_cannot_decode_are_rejected(gpu, oracle):
         assert any(not np.array_equal(a, b) for fa, fb in zip(got, plain) for a, b in zip(fa, fb)), kind  # the relabelling matters
 
 
-@pytest.mark.parametrize("name", ["kodak24", "kodak24_wide_envelope", "clic41", "uhd4k", "gop1080p33"])
+@pytest.mark.parametrize("name", ["kodak24", "kodak24_wide_envelope", "kodak24_hq", "clic41", "clic41_alt", "uhd4k", "gop1080p33"])
 def test_workloads_match_the_oracle(gpu, name):
     """EVERY stream of EVERY benchmark workload (cool_chic_amd/synth.py: BASELINE.json configs[1..4] at full size - 24
     Kodak frames, the 41 CLIC sizes, the 4K frame, the 33-frame depth-5 hierarchical 1080p GOP with its 64 cool-chics):

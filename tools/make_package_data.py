@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Builds cool_chic_amd/data/donors.npz: what cool_chic_amd/synth.py needs to manufacture benchmark streams (the two
+"""Builds cool_chic_amd/data/donors.npz: what cool_chic_amd/synth.py needs to manufacture benchmark streams (the
 reference-encoded donor streams, their decoded latent grids and their network integers), extracted from the golden
 fixtures of tests/golden (which tests/golden/gen/dump_reference.py dumped from the imported reference).  The package
 then never reads the test tree.      python tools/make_package_data.py"""
@@ -14,7 +14,9 @@ OUT = os.path.join(ROOT, "cool_chic_amd", "data", "donors.npz")
 
 def main():
     out = {}
-    for name in ("kodim14", "vid5"):
+    # kodim14 (HOP) and vid5 (I/P/B, LOP): BASELINE's configurations; hq192 (LOP at 2.5 bpp: wide windows), mop192 / vhop192 (the
+    # MOP and VHOP decoders): the r05 workloads that vary the statistics and the network (synth.kodak24_hq, synth.clic41_alt)
+    for name in ("kodim14", "vid5", "hq192", "mop192", "vhop192"):
         with open(os.path.join(GOLDEN, name + ".cool"), "rb") as f:
             out[name + ".cool"] = np.frombuffer(f.read(), dtype=np.uint8)
         z = np.load(os.path.join(GOLDEN, name + ".npz"))
