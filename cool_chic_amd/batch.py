@@ -169,6 +169,37 @@ class DecodeBatch:
             out.append(planes)
         return out
 
+    def planes_layout(self) -> Tuple[int, List[Tuple[int, List[int]]]]:
+        """(total bytes, [(block offset, [plane offsets inside the block]) per slot]) of every slot's plane block laid end to
+        end: the host buffer copy_planes_async() fills."""
+        total, off = C.c_size_t(), (C.c_size_t * 3)()
+        layout, base = [], 0
+        for s in range(len(self._meta)):
+            check(lib().ccd_batch_planes_layout(self._h, s, C.byref(total), off), "ccd_batch_planes_layout")
+            layout.append((base, [off[0], off[1], off[2]]))
+            base += total.value
+        return base, layout
+
+    def copy_planes_async(self, host_ptr: int, layout, stream: int = 0) -> None:
+        """One device -> host copy per slot into the (pinned) buffer at `host_ptr`, laid out as planes_layout() says; returns
+        without waiting - the caller waits on `stream` (wait())."""
+        n = len(self._meta)
+        ptrs = (C.c_void_p * n)(*[host_ptr + b0 for b0, _ in layout])
+        check(lib().ccd_batch_copy_planes_async(self._h, 0, n, ptrs, C.c_void_p(stream or None)), "ccd_batch_copy_planes_async")
+
+    def plane_views(self, host: np.ndarray, layout) -> List[List[np.ndarray]]:
+        """[slot][plane] numpy views of a host buffer filled by copy_planes_async()."""
+        out = []
+        for s, (b0, offs) in enumerate(layout):
+            bd, _ = self._meta[s]
+            dt = np.uint8 if bd == 8 else np.uint16
+            planes = []
+            for p in range(3):
+                h, w = self.plane_shape(s, p)
+                planes.append(host[b0 + offs[p]: b0 + offs[p] + h * w * dt().itemsize].view(dt).reshape(h, w))
+            out.append(planes)
+        return out
+
     def planes_block_device(self, slot: int) -> Tuple[_DevArray, List[Tuple[int, Tuple[int, int]]]]:
         """The slot's three integer planes as the ONE device block they occupy (uint8 bytes) + [(byte offset, (h, w))] per
         plane: a consumer that must outlive the batch copies the block once and views the planes in its copy."""

@@ -1018,6 +1018,10 @@ def _nccl_one_rank_worker(port, golden, q):
         ver = bench.verify_gathered("kodak24", run["gathered"], lambda r: [(i, items[i][3]) for i in range(3)])
         run["batch"].close()
         res["bench_gather"] = {"ok": ver["ok"], "frames": ver["frames_checked"], "dt": run["dt"]}
+        # (6) ... and bench.py's from-bytes step: two sets in flight on two side streams, the gather enqueued on them
+        fb = bench.timed_from_bytes([(streams[i], sizes[i]) for i in range(3)], 1, 0, 0, "nccl", "cuda:0", 3, 1, force_gather=True)
+        ver = bench.verify_gathered("kodak24", fb["gathered"], lambda r: [(i, sizes[i]) for i in range(3)])
+        res["bench_from_bytes"] = {"ok": ver["ok"], "frames": ver["frames_checked"], "dt": fb["dt"]}
         dist.barrier()
         dist.destroy_process_group()
         q.put(("ok", res))
@@ -1058,6 +1062,7 @@ def test_nccl_wire_path_on_one_rank(gpu, oracle):
         for p, w in zip(res["gop"][k], want[k]):
             assert np.array_equal(p.astype(np.uint16), w), k
     assert res["bench_gather"]["ok"] is True and res["bench_gather"]["frames"] == 3
+    assert res["bench_from_bytes"]["ok"] is True and res["bench_from_bytes"]["frames"] == 3
 
 
 def test_streams_the_reference_cannot_decode_are_rejected(gpu, oracle):
@@ -1248,6 +1253,8 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert res["verified"]["ok"] is True and res["verified"]["frames_checked"] == 12  # rank 0's half of the 24 frames
     g = res["verified"]["gathered"]
     assert g["ok"] is True and g["frames_checked"] == 24, g
+    fb = res["from_bytes"]  # the same steps from the stream bytes, two sets in flight, every rank's planes in rank 0's pinned memory
+    assert fb["verified"]["ok"] is True and fb["verified"]["frames_checked"] == 24 and fb["value"] > 0, fb
     c = res["clic41_sharded"]
     assert c["scaling"] == "strong" and c["frames"] == 41 and c["frames_on_rank0"] == 21
     assert c["verified"]["ok"] is True and c["verified"]["frames_checked"] == 41, c["verified"]
