@@ -412,6 +412,7 @@ def timed_from_bytes(mine, world, rank, local_rank, backend, red_dev, steps, war
         b = DecodeBatch(local_rank, keep_float=False)
         for s_, _ in mine:
             b.add(*synth.split_image_stream(s_), 8, 0)
+        b.prepare(st.cuda_stream)           # the launch tables' upload: not behind the wait below
         if prev_decoded[0] is not None:
             st.wait_event(prev_decoded[0])  # decodes one after the other; everything else overlaps
         if n:

@@ -89,6 +89,7 @@ SIGNATURES = {
                                 C.c_int, C.c_int]),
     "ccd_batch_size": (C.c_int, [C.c_void_p]),
     "ccd_batch_header": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(CCHeader)]),
+    "ccd_batch_prepare": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ccd_batch_run": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ccd_batch_run_stage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ccd_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -77,6 +77,11 @@ class DecodeBatch:
         check(lib().ccd_batch_header(self._h, slot, C.byref(h)), "ccd_batch_header")
         return h
 
+    def prepare(self, stream: int = 0):
+        """Uploads the launch tables of the slots added so far without launching (ccd_batch_prepare): for callers that then
+        make `stream` wait for other work before run()."""
+        check(lib().ccd_batch_prepare(self._h, C.c_void_p(stream or None)), "ccd_batch_prepare")
+
     def run(self, stream: int = 0, stage: Optional[int] = None):
         st = C.c_void_p(stream or None)
         if stage is None:

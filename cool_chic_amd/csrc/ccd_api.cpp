@@ -1174,6 +1174,14 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
     return CCD_OK;
 }
 
+int ccd_batch_prepare(ccd_batch* b, void* stream) {
+    if (!b) return CCD_ERR_ARG;
+    HIP_TRY(hipSetDevice(b->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    b->note_stream(st);
+    return upload_params(b, st);
+}
+
 int ccd_batch_run(ccd_batch* b, void* stream) {
     for (int stage = 0; stage < 3; ++stage) {
         const int rc = ccd_batch_run_stage(b, stream, stage);

@@ -137,6 +137,11 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
                   const uint8_t* bytes_latent, size_t n_lat, int bitdepth, int frame_data_type);
 int ccd_batch_size(const ccd_batch* b);
 int ccd_batch_header(const ccd_batch* b, int slot, ccd_cc_header* h);
+/* Optional: builds and uploads the launch tables of the slots added so far (entropy descriptors, work lists of the float
+ * kernels: one staged copy on `stream`) without launching anything - what the first ccd_batch_run[_stage] after an add does
+ * anyway.  A caller that makes `stream` wait for other work (e.g. the decode of the batch before) calls this first, so that
+ * the copy is not queued behind that wait. */
+int ccd_batch_prepare(ccd_batch* b, void* stream);
 /* Enqueues the whole decode of every slot on `stream` (asynchronous). */
 int ccd_batch_run(ccd_batch* b, void* stream);
 /* Enqueue only one stage (profiling / tests): 0 entropy, 1 upsampling, 2 synthesis(+integer planes). */
