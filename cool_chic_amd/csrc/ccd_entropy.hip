@@ -18,20 +18,19 @@
 #include <hip/hip_runtime.h>
 
 #include "ccd_device.hpp"
+#include "ccd_laplace.hpp"
 
 namespace ccd {
 
 constexpr int kEntThreads = 256;
 constexpr int kChunk = 64;  // pixels of one wavefront step handled per phase round
 
-// Left cumulative of symbol s (> -64) under table indices (mu_idx, scale): SURVEY appendix A.
-__device__ __forceinline__ uint32_t laplace_left(int mu_idx, float scale, int s) {
+// Left cumulative of symbol s (> -64) under table indices (mu_idx, scale index): window_left of ccd_laplace.hpp, the function the
+// pipelined kernel uses (r05; r01-r04 called the device library's exp here: ~3 x the instructions, same 24-bit boundaries - both
+// were enumerated against libm, profiles/r03/cdf_sweep.log).  `rcp` = RN(1 / b) from the host's table (EntropyParams::rcp_table).
+__device__ __forceinline__ uint32_t laplace_left(int mu_idx, double rcp, int s) {
     const double mu = -64.0 + static_cast<double>(mu_idx) * (1.0 / 256.0);  // float32 table value, exact
-    const double b = static_cast<double>(scale);
-    const double x = static_cast<double>(s) - 0.5;
-    const double cdf = (x <= mu) ? 0.5 * exp((x - mu) / b) : 1.0 - 0.5 * exp((mu - x) / b);
-    const double free_weight = 16777088.0;  // 2^24 - 1 - 127
-    return static_cast<uint32_t>(free_weight * cdf) + static_cast<uint32_t>(s - kAcLo);
+    return window_left(mu, rcp, s, kExpTab);
 }
 
 template <bool NARROW>
@@ -192,14 +191,18 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                 // ---- B: 128 left cumulatives per pixel ---------------------------------------------
                 for (int it = tid; it < cnt * kAlphabet; it += kEntThreads) {
                     const int i = it >> 7, j = it & 127;
-                    s_tbl[it] = (j == 0) ? 0u : laplace_left(s_mu[i], P.scale_table[s_sc[i]], j + kAcLo);
+                    s_tbl[it] = (j == 0) ? 0u : laplace_left(s_mu[i], P.rcp_table[s_sc[i]], j + kAcLo);
                 }
                 __syncthreads();
                 // ---- C: range decoder, wave 0 only -------------------------------------------------
                 if (tid < 64 && *s_err == 0) {
+                    // (r05) the next pixel's two table rows are requested one symbol ahead, and the symbol's bounds come out of the
+                    // lanes by v_readlane with the (wave-uniform) index in a scalar register - r01-r04 paid two LDS round trips for
+                    // the rows and two more for the __shfl pair on every symbol's chain
+                    uint32_t l0 = s_tbl[lane], l1 = s_tbl[64 + lane];
                     for (int i = 0; i < cnt; ++i) {
-                        const uint32_t l0 = s_tbl[i * kAlphabet + lane];
-                        const uint32_t l1 = s_tbl[i * kAlphabet + 64 + lane];
+                        const int nx = min(i + 1, cnt - 1);
+                        const uint32_t n0 = s_tbl[nx * kAlphabet + lane], n1 = s_tbl[nx * kAlphabet + 64 + lane];
                         const uint64_t scale = rc_range >> kRcPrecision;
                         if ((rc_dist >> kRcPrecision) >= scale) {  // quantile >= 2^24: invalid data
                             if (lane == 0) *s_err = CCD_ERR_INVALID_DATA;
@@ -207,10 +210,12 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                         }
                         const unsigned long long m0 = __ballot(scale * l0 <= rc_dist);
                         const unsigned long long m1 = __ballot(scale * l1 <= rc_dist);
-                        const int sidx = __popcll(m0) + __popcll(m1) - 1;  // left(-64) = 0 always qualifies
-                        const uint32_t left = __shfl(sidx < 64 ? l0 : l1, sidx & 63);
+                        const int sidx = __builtin_amdgcn_readfirstlane(__popcll(m0) + __popcll(m1) - 1);  // left(-64) = 0 always qualifies
                         const int nidx = sidx + 1;
-                        uint32_t right = __shfl(nidx < 64 ? l0 : l1, nidx & 63);
+                        const uint32_t left = sidx < 64 ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(l0), sidx & 63))
+                                                        : static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(l1), sidx & 63));
+                        uint32_t right = nidx < 64 ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(l0), nidx & 63))
+                                                   : static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(l1), nidx & 63));
                         if (sidx == kAlphabet - 1) right = 1u << kRcPrecision;
                         rc_dist -= scale * left;
                         rc_range = scale * static_cast<uint64_t>(right - left);
@@ -220,6 +225,7 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                         }
                         if (lane == 0) lat[s_py[i] * W + s_px[i]] = static_cast<int8_t>(sidx + kAcLo);
                         ++n_decoded;
+                        l0 = n0; l1 = n1;
                     }
                 }
                 __syncthreads();
@@ -266,12 +272,13 @@ hipError_t launch_entropy(const EntropyParams* d_slots, int n_slots, size_t lds_
 // ---- debug: the CDF boundaries exactly as phase B computes them ------------------------------------
 __global__ void laplace_bounds_kernel(const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* sym,
                                       const float* scale_table, int64_t n, uint32_t* left, uint32_t* right) {
+    // (debug entry points only hold the float32 scale table: RN(1 / b) formed here like the host forms the rcp table)
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int m = min(max(mu_idx[i], 0), kNumMu - 1), c = min(max(scale_idx[i], 0), kNumScale - 1), s = sym[i];
-    const float b = scale_table[c];
-    left[i] = (s == kAcLo) ? 0u : laplace_left(m, b, s);
-    right[i] = (s == kAcLo + kAlphabet - 1) ? (1u << kRcPrecision) : laplace_left(m, b, s + 1);
+    const double rcp = 1.0 / static_cast<double>(scale_table[c]);
+    left[i] = (s == kAcLo) ? 0u : laplace_left(m, rcp, s);
+    right[i] = (s == kAcLo + kAlphabet - 1) ? (1u << kRcPrecision) : laplace_left(m, rcp, s + 1);
 }
 
 hipError_t launch_laplace_bounds(const int32_t* mu_idx, const int32_t* scale_idx, const int32_t* sym,
@@ -290,7 +297,7 @@ __global__ void laplace_sweep_generic_kernel(const float* scale_table, int scale
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const int s = static_cast<int>(i % 127) - 63;
         const int64_t r = i / 127;
-        out[i] = laplace_left(static_cast<int>(r % kNumMu), scale_table[scale_first + static_cast<int>(r / kNumMu)], s);
+        out[i] = laplace_left(static_cast<int>(r % kNumMu), 1.0 / static_cast<double>(scale_table[scale_first + static_cast<int>(r / kNumMu)]), s);
     }
 }
 hipError_t launch_laplace_sweep_generic(const float* scale_table, int scale_first, int n_scales, uint32_t* out, hipStream_t stream) {
