@@ -22,7 +22,7 @@
 
 namespace ccd {
 
-constexpr int kEntThreads = 256;
+constexpr int kEntThreads = 1024;  // 4 waves per SIMD: every phase is a handful of LDS / L2 round trips per item, and only other waves hide them (r05: 256 -> 1024)
 constexpr int kChunk = 64;  // pixels of one wavefront step handled per phase round
 
 // Left cumulative of symbol s (> -64) under table indices (mu_idx, scale index): window_left of ccd_laplace.hpp, the function the
@@ -58,7 +58,8 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
     int32_t* s_sc = s_mu + kChunk;                                            // [kChunk]
     int32_t* s_py = s_sc + kChunk;                                            // [kChunk]
     int32_t* s_px = s_py + kChunk;                                            // [kChunk]
-    int32_t* s_err = s_px + kChunk;                                           // [1]
+    int32_t* s_err = s_px + kChunk;                                           // [1] (+ 3 words of padding)
+    double* s_rcpx = reinterpret_cast<double*>(s_err + 4);                    // [kChunk] RN(1 / b) of the chunk's pixels
 
     for (int i = tid; i < P.arm_len; i += kEntThreads) s_arm[i] = P.arm[i];
     if (tid == 0) *s_err = 0;
@@ -147,6 +148,8 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                     for (int it = tid; it < cnt * 2; it += kEntThreads) {
                         const int o = it / cnt, i = it - o * cnt;
                         uint64_t acc = static_cast<uint64_t>(bs[o]);
+                        // (four operand pairs in flight: one wave per SIMD has nothing else to hide an LDS round trip behind)
+#pragma unroll 4
                         for (int k = 0; k < dim; ++k) acc = mac<NARROW>(acc, s_xa[k * kChunk + i], ws[k * 2 + o]);
                         s_stab[o * kChunk + i] = static_cast<int64_t>(acc);
                     }
@@ -159,6 +162,8 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                     for (int it = tid; it < cnt * dim; it += kEntThreads) {
                         const int o = it / cnt, i = it - o * cnt;
                         uint64_t acc = static_cast<uint64_t>(lb[o]);
+                        // (four operand pairs in flight: one wave per SIMD has nothing else to hide an LDS round trip behind)
+#pragma unroll 4
                         for (int k = 0; k < dim; ++k) acc = mac<NARROW>(acc, xin[k * kChunk + i], lw[k * dim + o]);
                         int64_t v = static_cast<int64_t>(acc);
                         v = v < 0 ? 0 : v;
@@ -175,6 +180,8 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                     for (int it = tid; it < cnt * 2; it += kEntThreads) {
                         const int o = it / cnt, i = it - o * cnt;
                         uint64_t acc = static_cast<uint64_t>(lb[o]);
+                        // (four operand pairs in flight: one wave per SIMD has nothing else to hide an LDS round trip behind)
+#pragma unroll 4
                         for (int k = 0; k < dim; ++k) acc = mac<NARROW>(acc, xin[k * kChunk + i], lw[k * 2 + o]);
                         acc += static_cast<uint64_t>(s_stab[o * kChunk + i]);
                         const int64_t q8 = static_cast<int64_t>(acc) >> 24;
@@ -184,6 +191,7 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                         } else {
                             const int64_t idx = q8 + kScaleOffset;
                             s_sc[i] = static_cast<int32_t>(idx < 0 ? 0 : (idx > kNumScale - 1 ? kNumScale - 1 : idx));
+                            s_rcpx[i] = P.rcp_table[s_sc[i]];  // one table read per pixel here, not one per boundary in phase B
                         }
                     }
                 }
@@ -191,7 +199,7 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                 // ---- B: 128 left cumulatives per pixel ---------------------------------------------
                 for (int it = tid; it < cnt * kAlphabet; it += kEntThreads) {
                     const int i = it >> 7, j = it & 127;
-                    s_tbl[it] = (j == 0) ? 0u : laplace_left(s_mu[i], P.rcp_table[s_sc[i]], j + kAcLo);
+                    s_tbl[it] = (j == 0) ? 0u : laplace_left(s_mu[i], s_rcpx[i], j + kAcLo);
                 }
                 __syncthreads();
                 // ---- C: range decoder, wave 0 only -------------------------------------------------
@@ -200,6 +208,8 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                     // lanes by v_readlane with the (wave-uniform) index in a scalar register - r01-r04 paid two LDS round trips for
                     // the rows and two more for the __shfl pair on every symbol's chain
                     uint32_t l0 = s_tbl[lane], l1 = s_tbl[64 + lane];
+                    int sym_l = 0;  // lane i: the symbol of pixel i of the chunk (stored by all lanes at once behind the loop)
+                    int n_done = 0;
                     for (int i = 0; i < cnt; ++i) {
                         const int nx = min(i + 1, cnt - 1);
                         const uint32_t n0 = s_tbl[nx * kAlphabet + lane], n1 = s_tbl[nx * kAlphabet + 64 + lane];
@@ -223,10 +233,14 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                             rc_range <<= 32;
                             rc_dist = (rc_dist << 32) | next_word();
                         }
-                        if (lane == 0) lat[s_py[i] * W + s_px[i]] = static_cast<int8_t>(sidx + kAcLo);
+                        sym_l = lane == i ? sidx : sym_l;
                         ++n_decoded;
+                        n_done = i + 1;
                         l0 = n0; l1 = n1;
                     }
+                    // (r05: one store per lane here instead of two LDS reads and a one-lane store on every symbol's path; the symbols
+                    // decoded before invalid data was met are stored too, as before)
+                    if (lane < n_done) lat[s_py[lane] * W + s_px[lane]] = static_cast<int8_t>(sym_l + kAcLo);
                 }
                 __syncthreads();
                 if (*s_err != 0) break;
@@ -255,6 +269,7 @@ size_t entropy_lds_bytes(int dim, int arm_len) {
     n += static_cast<size_t>(2 * dim * kChunk + 2 * kChunk) * 8;
     n += static_cast<size_t>(kChunk) * kAlphabet * 4;
     n += static_cast<size_t>(4 * kChunk + 4) * 4;
+    n += static_cast<size_t>(kChunk) * 8;  // s_rcpx
     return (n + 15) & ~size_t{15};
 }
 
