@@ -52,7 +52,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 SYMBOL_FLOOR_TICKS = 111.0  # bare unrolled symbol block of the entropy kernel's decoder (paired tests), ticks per symbol (tools/ubench/dcycle.hip)
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
-PROFILE_DIRS = ["profiles/r04", "profiles/r03", "profiles/r02", "profiles/r01"]
+PROFILE_DIRS = ["profiles/r05", "profiles/r04", "profiles/r03", "profiles/r02", "profiles/r01"]
 
 
 def build_kodak24(device: int = 0):

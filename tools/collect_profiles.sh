@@ -6,16 +6,16 @@
 #   pass 2: PMC FETCH_SIZE (own run)      -> gpurun_out/prof/<tag>/fetch
 #   pass 3: PMC WRITE_SIZE (own run)      -> gpurun_out/prof/<tag>/write
 # (counters are never combined with sys/hip/hsa traces; see MI355X_MICROARCH.md, rocprofv3 PMC slots)
-# Afterwards (here or in the build container):  python tools/summarise_pmc.py gpurun_out/prof/<tag> profiles/r04 <tag>
+# Afterwards (here or in the build container):  python tools/summarise_pmc.py gpurun_out/prof/<tag> profiles/r05 <tag>
 set -u
 REPO=$(pwd)
 export TMPDIR=/tmp
-for TAG in kodak24 kodak256 clic41 uhd4k rate; do
+for TAG in kodak24 kodak256 clic41 uhd4k kodak24_hq rate; do
   OUT=$REPO/gpurun_out/prof/$TAG
   rm -rf "$OUT"; mkdir -p "$OUT"
   EXTRA=""; [ "$TAG" = kodak256 ] && EXTRA="--scaling throughput"
   CMD="python $REPO/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --legs none $EXTRA"
-  case "$TAG" in clic41|uhd4k) CMD="python $REPO/tools/prof_workload.py $TAG 3";; rate) CMD="python $REPO/tools/prof_rate.py";; esac
+  case "$TAG" in clic41|uhd4k|kodak24_hq) CMD="python $REPO/tools/prof_workload.py $TAG 3";; rate) CMD="python $REPO/tools/prof_rate.py";; esac
   cd /tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- $CMD > "$OUT/bench_stats.log" 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- $CMD > "$OUT/bench_fetch.log" 2>&1
