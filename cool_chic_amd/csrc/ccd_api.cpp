@@ -36,7 +36,7 @@ void syn_fused_tiles(int h, int w, int halo, int* tiles_x, int* tiles_y);
 hipError_t launch_syn_fused(const SynthFused* d_frames, int n_frames, int c_in, int c, int max_tiles_x, int max_tiles_y,
                             hipStream_t stream);
 bool fused_dec_supports(int c_in, int c);
-size_t fused_dec_lds_bytes(int n_lv, int c, int n_conv, int n_params);
+size_t fused_dec_lds_bytes(int n_lv, int c, int n_conv, int n_params, int pre);
 void fused_dec_param_shape(int c_in, int c, int* nwv, int* nws, int* nwc, int* nwo);
 hipError_t launch_fused_dec(const FusedDec* d_frames, const void* d_work, int n_work, int c_in, int c, int pre, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_fused_pyramid(const FusedDec* d_frames, const void* d_work, int n_work, int levels, size_t lds_bytes, hipStream_t stream);
@@ -681,7 +681,7 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
                         D.k2u[i][k2_index(a2, b2)] = pu; D.k2p[i][k2_index(a2, b2)] = pp;
                     }
             }
-            s.fdec_lds = fused_dec_lds_bytes(n_levels, C, D.n_conv, D.n_params);
+            s.fdec_lds = fused_dec_lds_bytes(n_levels, C, D.n_conv, D.n_params, (b->opt_fused_dec == 2 && n_levels >= 5) ? 1 : 0);
             s.use_fused_dec = s.fdec_lds <= 160 * 1024;
             if (!s.use_fused_dec) syn_blob.resize(base);
             else D.params = reinterpret_cast<const float*>(base);  // offset for now; becomes a pointer once the arena exists

@@ -27,11 +27,12 @@ int fused_dec_profile(unsigned long long* out16, int reset) {
 bool fused_dec_supports(int c_in, int c) { return c_in >= 5 && c_in <= 9 && c >= 2 && c <= 5; }
 
 // LDS of the pyramid launch for a frame of n_lv levels (its descriptor has n_lv - 1 levels and no parameter block)
-size_t fused_pyr_lds_bytes(int n_lv) { return static_cast<size_t>(fd_layout(n_lv - 1, 2).par) * 4; }
+size_t fused_pyr_lds_bytes(int n_lv) { return static_cast<size_t>(fd_layout(n_lv - 1, 2, false).par) * 4; }
 
-size_t fused_dec_lds_bytes(int n_lv, int c, int n_conv, int n_params) {
+// `pre`: the slot runs the kFdPre instantiation (level-1 stack from the pyramid launch): no LDS for the coarse levels
+size_t fused_dec_lds_bytes(int n_lv, int c, int n_conv, int n_params, int pre) {
     (void)n_conv;
-    return static_cast<size_t>(fd_layout(n_lv, c).par + ((n_params + 3) & ~3)) * 4;
+    return static_cast<size_t>(fd_layout(n_lv, c, pre != 0).par + ((n_params + 3) & ~3)) * 4;
 }
 
 void fused_dec_param_shape(int c_in, int c, int* nwv, int* nws, int* nwc, int* nwo) {
