@@ -66,9 +66,14 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
 
     // ---- range decoder state (meaningful in wave 0) ---------------------------
     // dist = point - lower is all the decoder ever uses, so track it directly.
+    // (the coder's state is the same in every lane of wave 0: said with readfirstlane, it lives in scalar registers and the
+    // symbol loop's arithmetic, compares and branches run on the scalar unit - r05; as per-lane values the loop was ~80 vector
+    // instructions with exec-mask control flow per symbol)
+    auto uni32 = [](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); };
+    auto uni64 = [&](uint64_t v) { return (static_cast<uint64_t>(uni32(static_cast<uint32_t>(v >> 32))) << 32) | uni32(static_cast<uint32_t>(v)); };
     uint32_t word_pos = 0;
     auto next_word = [&]() -> uint32_t {
-        const uint32_t w = word_pos < P.n_words ? P.words[word_pos] : 0u;
+        const uint32_t w = uni32(word_pos < P.n_words ? P.words[word_pos] : 0u);
         ++word_pos;
         return w;
     };
@@ -76,6 +81,14 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
     uint64_t rc_dist = static_cast<uint64_t>(next_word()) << 32;
     rc_dist |= next_word();
     uint64_t n_decoded = 0;
+#ifdef CCD_GEN_PROFILE
+    unsigned long long gp[6] = {0, 0, 0, 0, 0, 0}, gp_t = 0;
+#define GP_START() gp_t = __builtin_amdgcn_s_memtime()
+#define GP_ADD(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); gp[k] += t_ - gp_t; gp_t = t_; } while (0)
+#else
+#define GP_START() (void)0
+#define GP_ADD(k) (void)0
+#endif
     __syncthreads();
 
     const int n_layers = P.n_layers;
@@ -126,6 +139,7 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
             }
             for (int i0 = 0; i0 < n; i0 += kChunk) {
                 const int cnt = min(kChunk, n - i0);
+                GP_START();
                 // ---- A1: gather contexts (already << 16, armint.py:193) ---------------------------
                 for (int it = tid; it < cnt * dim; it += kEntThreads) {
                     const int k = it / cnt, i = it - k * cnt;
@@ -141,6 +155,7 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                     if (k == 0) { s_py[i] = y; s_px[i] = x; }
                 }
                 __syncthreads();
+                GP_ADD(0);
                 // ---- A2: stabiliser branch + hidden layers ---------------------------------------
                 {
                     const int64_t* ws = s_arm + (P.arm_len - 2 - 2 * dim);
@@ -174,6 +189,7 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                     lw = lb + dim;
                 }
                 if (n_layers == 1) __syncthreads();  // stabiliser results visible
+                GP_ADD(1);
                 // ---- A3: output layer -> table indices (latent.py:156-165, rangecoder.py:90-91) ----
                 {
                     const int64_t* lb = lw + dim * 2;
@@ -196,12 +212,14 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                     }
                 }
                 __syncthreads();
+                GP_ADD(2);
                 // ---- B: 128 left cumulatives per pixel ---------------------------------------------
                 for (int it = tid; it < cnt * kAlphabet; it += kEntThreads) {
                     const int i = it >> 7, j = it & 127;
                     s_tbl[it] = (j == 0) ? 0u : laplace_left(s_mu[i], s_rcpx[i], j + kAcLo);
                 }
                 __syncthreads();
+                GP_ADD(3);
                 // ---- C: range decoder, wave 0 only -------------------------------------------------
                 if (tid < 64 && *s_err == 0) {
                     // (r05) the next pixel's two table rows are requested one symbol ahead, and the symbol's bounds come out of the
@@ -210,32 +228,52 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                     uint32_t l0 = s_tbl[lane], l1 = s_tbl[64 + lane];
                     int sym_l = 0;  // lane i: the symbol of pixel i of the chunk (stored by all lanes at once behind the loop)
                     int n_done = 0;
+                    rc_dist = uni64(rc_dist); rc_range = uni64(rc_range);
+                    word_pos = uni32(word_pos);
+                    const uint32_t tbl_lane = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(s_tbl + lane));  // LDS byte address of entry `lane` of row 0
                     for (int i = 0; i < cnt; ++i) {
-                        const int nx = min(i + 1, cnt - 1);
-                        const uint32_t n0 = s_tbl[nx * kAlphabet + lane], n1 = s_tbl[nx * kAlphabet + 64 + lane];
+                        // the next pixel's two rows: requested NOW, first used at the end of this iteration (inline asm: left to the
+                        // compiler the reads sink behind the scalar arithmetic and their round trip lands on the symbol's chain)
+                        uint32_t n0, n1;
+                        {
+                            const uint32_t a = tbl_lane + static_cast<uint32_t>(min(i + 1, cnt - 1)) * (kAlphabet * 4u);
+                            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:256" : "=&v"(n0), "=&v"(n1) : "v"(a) : "memory");
+                        }
                         const uint64_t scale = rc_range >> kRcPrecision;
-                        if ((rc_dist >> kRcPrecision) >= scale) {  // quantile >= 2^24: invalid data
+                        // quantile >= 2^24: invalid data.  (Both operands are below 2^40: the sign of their 64-bit difference decides -
+                        // scalar subtract and a 32-bit test; a 64-bit "<" only exists on the vector unit.)
+                        uint32_t diff_hi = static_cast<uint32_t>(((rc_dist >> kRcPrecision) - scale) >> 32);
+                        asm volatile("" : "+s"(diff_hi));  // (opaque: else the test is re-formed as a 64-bit compare, i.e. moved to the vector unit)
+                        if (static_cast<int32_t>(diff_hi) >= 0) {
                             if (lane == 0) *s_err = CCD_ERR_INVALID_DATA;
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                             break;
                         }
                         const unsigned long long m0 = __ballot(scale * l0 <= rc_dist);
                         const unsigned long long m1 = __ballot(scale * l1 <= rc_dist);
                         const int sidx = __builtin_amdgcn_readfirstlane(__popcll(m0) + __popcll(m1) - 1);  // left(-64) = 0 always qualifies
                         const int nidx = sidx + 1;
-                        const uint32_t left = sidx < 64 ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(l0), sidx & 63))
-                                                        : static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(l1), sidx & 63));
-                        uint32_t right = nidx < 64 ? static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(l0), nidx & 63))
-                                                   : static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(l1), nidx & 63));
+                        // (both candidates read, then a scalar select: written as `sidx < 64 ? readlane(l0) : readlane(l1)` the
+                        // compiler branches around each v_readlane - four branches on every symbol's chain)
+                        const uint32_t la = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(l0), sidx & 63));
+                        const uint32_t lb = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(l1), sidx & 63));
+                        const uint32_t ra = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(l0), nidx & 63));
+                        const uint32_t rb = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(l1), nidx & 63));
+                        const uint32_t left = (sidx & 64) ? lb : la;
+                        uint32_t right = (nidx & 64) ? rb : ra;
                         if (sidx == kAlphabet - 1) right = 1u << kRcPrecision;
-                        rc_dist -= scale * left;
-                        rc_range = scale * static_cast<uint64_t>(right - left);
-                        if ((rc_range >> 32) == 0) {
+                        rc_dist = uni64(rc_dist - scale * left);
+                        rc_range = uni64(scale * static_cast<uint64_t>(right - left));
+                        uint32_t range_hi = static_cast<uint32_t>(rc_range >> 32);
+                        asm volatile("" : "+s"(range_hi));
+                        if (range_hi == 0u) {
                             rc_range <<= 32;
                             rc_dist = (rc_dist << 32) | next_word();
                         }
                         sym_l = lane == i ? sidx : sym_l;
                         ++n_decoded;
                         n_done = i + 1;
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n0), "+v"(n1) :: "memory");
                         l0 = n0; l1 = n1;
                     }
                     // (r05: one store per lane here instead of two LDS reads and a one-lane store on every symbol's path; the symbols
@@ -243,6 +281,7 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
                     if (lane < n_done) lat[s_py[lane] * W + s_px[lane]] = static_cast<int8_t>(sym_l + kAcLo);
                 }
                 __syncthreads();
+                GP_ADD(4);
                 if (*s_err != 0) break;
             }
             if (*s_err != 0) break;
@@ -254,6 +293,9 @@ __device__ void entropy_decode_slot(const EntropyParams& P, unsigned char* smem_
         P.status[1] = static_cast<int32_t>(word_pos);
         P.status[2] = static_cast<int32_t>(n_decoded & 0xffffffffu);
         P.status[3] = static_cast<int32_t>(n_decoded >> 32);
+#ifdef CCD_GEN_PROFILE
+        for (int k = 0; k < 5; ++k) P.status[40 + k] = static_cast<int32_t>(gp[k] >> 10);  // Kticks per phase (thread 0): gather, layers, output, tables, symbols
+#endif
     }
 }
 
