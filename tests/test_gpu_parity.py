@@ -1065,6 +1065,36 @@ def test_nccl_wire_path_on_one_rank(gpu, oracle):
     assert res["bench_from_bytes"]["ok"] is True and res["bench_from_bytes"]["frames"] == 3
 
 
+def test_prepare_then_run_behind_a_stream_wait(gpu, oracle):
+    """ccd_batch_prepare uploads the launch tables without launching; a run behind it (on a stream that first waits for other
+    work, as bench.py's two sets in flight do) gives the planes of a plain run, and slots added after a prepare are picked up."""
+    import torch
+
+    bs, _, _ = load_golden("rgb192")
+    fh, ccs = oracle.split_stream(bs)[1][0]
+    want = oracle.decode_video(bs)[0]["planes"]
+    side = torch.cuda.Stream(device="cuda:0")
+    ev = torch.cuda.Event()
+    b = gpu(0, keep_float=False)
+    try:
+        b.add(*ccs[0], fh.bitdepth, fh.frame_data_type)
+        b.prepare(side.cuda_stream)
+        torch.cuda._sleep(2_000_000)          # work on the default stream the side stream has to wait for
+        ev.record(torch.cuda.current_stream(0))
+        side.wait_event(ev)
+        b.run(side.cuda_stream)
+        b.wait(side.cuda_stream)
+        for p, w in zip(b.planes(0), want):
+            assert np.array_equal(p.astype(np.uint16), w)
+        b.add(*ccs[0], fh.bitdepth, fh.frame_data_type)  # a slot behind the prepare: the next run uploads its tables itself
+        b.run(side.cuda_stream)
+        b.wait(side.cuda_stream)
+        for p, w in zip(b.planes(1), want):
+            assert np.array_equal(p.astype(np.uint16), w)
+    finally:
+        b.close()
+
+
 def test_streams_the_reference_cannot_decode_are_rejected(gpu, oracle):
     """Headers that parse but that the reference's decoder raises on (or that would read out of bounds here) give
     CCD_ERR_VALUE instead of garbage: latent / hyperlatent ranges that do not touch (torch.cat of grids two levels

@@ -416,3 +416,34 @@ def test_float_envelope_of_fixtures_and_crafted_networks(oracle):
         u = ref["dense"].view(np.uint32)
         n_sub += bool((((u & 0x7F800000) == 0) & ((u & 0x007FFFFF) != 0)).any())
     assert n_nonfinite >= 2 and n_sub >= 1
+
+
+def test_bench_refuses_a_variant_library_and_build_cleans_variants(tmp_path):
+    """Housekeeping that protects the numbers: bench.py does not time a library CCD_LIB names unless told
+    to, and _build.clean_variants removes variant libraries / object trees of earlier profiling runs (they ship to the GPU box
+    with every push), keeping the ones asked for."""
+    import subprocess
+    import sys
+
+    from cool_chic_amd import _build
+
+    env = dict(os.environ, CCD_LIB=os.path.join(ROOT, "cool_chic_amd", "libccd_does_not_exist.so"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "CCD_LIB" in r.stderr and "--allow-variant" in r.stderr
+    here = os.path.dirname(_build.LIB)
+    lib_a, lib_b = os.path.join(here, "libccd_tmpa.so"), os.path.join(here, "libccd_tmpb.so")
+    obj_a = os.path.join(here, "csrc", "_obj_tmpa")
+    try:
+        for f in (lib_a, lib_b):
+            open(f, "wb").close()
+        os.makedirs(obj_a, exist_ok=True)
+        gone = _build.clean_variants(keep=("tmpb",))
+        assert lib_a in gone and obj_a in gone and lib_b not in gone
+        assert not os.path.exists(lib_a) and not os.path.exists(obj_a) and os.path.exists(lib_b)
+        assert os.path.exists(_build.LIB) and os.path.isdir(os.path.join(here, "csrc", "_obj"))  # the product itself is never touched
+    finally:
+        for f in (lib_a, lib_b):
+            if os.path.exists(f):
+                os.remove(f)
+        if os.path.isdir(obj_a):
+            os.rmdir(obj_a)
