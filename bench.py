@@ -52,7 +52,7 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 SYMBOL_FLOOR_TICKS = 111.0  # bare unrolled symbol block of the entropy kernel's decoder (paired tests), ticks per symbol (tools/ubench/dcycle.hip)
 FP32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32 vector = f32 MFMA peak
-PROFILE_DIRS = ["profiles/r05", "profiles/r04", "profiles/r03", "profiles/r02", "profiles/r01"]
+PROFILE_DIRS = ["profiles/r06", "profiles/r05", "profiles/r04", "profiles/r03", "profiles/r02", "profiles/r01"]
 
 
 def build_kodak24(device: int = 0):
@@ -224,6 +224,7 @@ def image_leg(name, device, sh, stream, steps, cpu_budget, want_cpu):
     b.run(sh)
     b.wait(sh)
     kernels = [b.slot_kernels(s) for s in range(len(triples))]
+    launches = b.entropy_launches()
     ms = wall_ms(lambda: b.run(sh), steps, device)
     ms_entropy = event_ms(stream, lambda: b.run(sh, stage=0), max(1, steps // 2), device)
     ms_float = event_ms(stream, lambda: (b.run(sh, stage=1), b.run(sh, stage=2)), max(1, steps // 2), device)
@@ -234,7 +235,10 @@ def image_leg(name, device, sh, stream, steps, cpu_budget, want_cpu):
     hdrs = [b.header(i) for i in range(len(triples))]
     b.close()
     leg = {"frames": len(triples), "mpixels": sum(px) / 1e6, "verified": verified, "value": sum(px) / ms / 1e3, "unit": "Mpixel/s", "n_gpus": 1, "steps": steps,
-           "ms_per_step": ms, "entropy_ms": ms_entropy, "float_ms": ms_float, "symbols": nsym,
+           "ms_per_step": ms, "entropy_ms": ms_entropy, "float_ms": ms_float,
+           # r06: a run puts the float launches of the streams that finish early behind THEIR entropy launch (chain groups): what
+           # of the float path is still exposed behind the slowest entropy launch
+           "float_ms_exposed": ms - ms_entropy, "entropy_launches": launches, "symbols": nsym,
            "entropy_msym_per_s": nsym / ms_entropy / 1e3, "largest_frame_mpx": max(px) / 1e6,
            "slots_on_generic_entropy_kernel": sum(1 for k in kernels if not k & 1),
            "slots_on_unfused_float_path": sum(1 for k in kernels if not k & 4),
@@ -528,14 +532,27 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X: there is no CPU fallback"
     if args.backend == "gloo":
         local_rank %= torch.cuda.device_count()  # ranks may share a GPU: there is no device-to-device collective to collide
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)  # BEFORE the communicator exists: a rank on the wrong GPU hangs at the first collective
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL P2P buffers)
         if args.backend == "nccl":
+            assert torch.cuda.device_count() >= world, f"{world} ranks over RCCL need {world} GPUs, {torch.cuda.device_count()} visible (one GPU per rank; --backend gloo shares)"
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group("gloo")
     red_dev = f"cuda:{local_rank}" if args.backend == "nccl" else "cpu"  # where the scalar reductions live
+    # the run is what the command line says: --gpus N ranks (the driver computes scaling from N), each on its own GPU
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE = {world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (tools/run_8gpu.sh)"
+    gpus_active = 1
+    if world > 1:
+        assert dist.get_world_size() == args.gpus and dist.get_rank() == rank
+        # (host, device) of every rank: N distinct GPUs - two ranks on one device would halve the numbers silently
+        import socket
+        who = [None] * world
+        dist.all_gather_object(who, (socket.gethostname(), torch.cuda.current_device() if args.backend == "nccl" else rank))
+        gpus_active = len(set(who))
+        assert gpus_active == world, f"{world} ranks on {gpus_active} distinct GPUs: {who}"
     all_legs = ["clic41", "gop1080p33", "uhd4k", "wide", "png", "e2e", "float", "envelope", "rate", "kodak24_hq", "clic41_alt", "cliffs"]
     legs = all_legs if args.legs == "all" else ([] if args.legs == "none" else args.legs.split(","))
     if world > 1 and args.legs == "all":
@@ -543,6 +560,7 @@ def main():
     want_cpu = not args.no_cpu_baseline
 
     from cool_chic_amd import DecodeBatch, synth
+    from cool_chic_amd._lib import lib as lib_
     from cool_chic_amd.parallel import EqualSizeGather, shard_indices
 
     items, streams = build_kodak24(local_rank)
@@ -671,7 +689,7 @@ def main():
                     "v_mfma_f32_4x4x1 (bitwise the oracle's order)" % (ff_bytes / rank_px, flop_px)}]
         res = {
             "metric": "decoded Mpixel/s", "value": px_per_step * args.steps / dt / 1e6, "unit": "Mpixel/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "gpus_active": gpus_active, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             **({"library_variant": os.environ["CCD_LIB"]} if os.environ.get("CCD_LIB") else {}),
             "higher_is_better": True, "scaling": "strong" if args.scaling == "strong" else "weak", "vs_baseline": None,
             "dtype": "int64+f64 entropy / f32 synthesis",
@@ -698,6 +716,12 @@ def main():
                                    "into its pinned memory); nothing cached between steps; TWO sets in flight - parse + upload of set k+1 and "
                                    "the copy-back of set k-1 hide behind the decode of set k, the decodes themselves do not overlap"},
             "stage_ms_per_step": stage_ms,
+            # r06: the step minus its entropy stage (all entropy launches, forked and joined): the part of the float path that does NOT
+            # hide behind the longest chains since ccd_batch_run launches each chain group's frames behind that group
+            "float_ms_exposed": dt / args.steps * 1e3 - stage_ms["entropy"] if world == 1 else None,
+            "entropy_launches": batch.entropy_launches(),
+            # side streams of the library that were measured to run kernels concurrently (HIP's hardware queues: tools/ubench/queues.hip)
+            "concurrent_streams": lib_().ccd_concurrent_streams(local_rank),
             "slots_on_generic_entropy_kernel": sum(1 for k in kernels if not k & 1),
             "slots_on_unfused_float_path": sum(1 for k in kernels if not k & 4),
             "entropy_msym_per_s": nsym / (stage_ms["entropy"] / 1e3) / 1e6,
@@ -943,6 +967,11 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0:
+        # one line per regime on stderr (N > 1: strong kodak24, sharded clic41, throughput); the contract's ONE JSON line on stdout
+        for label, leg in (("kodak24 (strong)" if args.scaling == "strong" else args.scaling, res), ("clic41_sharded (strong)", res.get("clic41_sharded")),
+                           ("throughput_regime (weak)", res.get("throughput_regime"))):
+            if leg:
+                print(f"[bench] {label:28s} n_gpus {world}  {leg['value']:9.1f} Mpixel/s  {leg['ms_per_step']:8.2f} ms per step  verified {leg['verified'].get('ok')}", file=sys.stderr)
         print(json.dumps(res))
     batch.close()
     if world > 1:

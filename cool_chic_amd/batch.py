@@ -26,16 +26,18 @@ class DecodeBatch:
     enqueues kernels on `stream` (a hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream).
     """
 
-    OPT_FUSED_DEC, OPT_KEEP_FLOAT, OPT_MFMA_ARM, OPT_RANGE_BITS = 1, 2, 3, 4  # include/ccd.h
+    OPT_FUSED_DEC, OPT_KEEP_FLOAT, OPT_MFMA_ARM, OPT_RANGE_BITS, OPT_OVERLAP = 1, 2, 3, 4, 5  # include/ccd.h
 
     def __init__(self, device: int = 0, fused_dec: Optional[bool] = None, keep_float: Optional[bool] = None,
-                 mfma_arm: Optional[int] = None, range_bits: Optional[int] = None):
+                 mfma_arm: Optional[int] = None, range_bits: Optional[int] = None, overlap: Optional[bool] = None):
         """fused_dec=False: unfused float path (materialises dense()); keep_float=False: rgb / yuv444 intra slots
         write integer planes only (output() is then unavailable for them); mfma_arm=1: the integer ARM on the matrix
         cores where the stream allows (2..22: test hook, see ccd.h); range_bits=8..14: test hook that lowers the feature
         limit of the pipelined entropy kernel's dynamic operand check.
+        overlap=False: run() puts every float-path launch behind the join of the entropy launches (A/B, tests); by default the
+        frames whose streams finish early are synthesised while the longest chains still decode (ccd.h, ccd_batch_run).
         None = library default: fused_dec on, keep_float on, mfma_arm OFF (the vector-ALU ARM is the faster one),
-        production limit (15 bits)."""
+        production limit (15 bits), overlap on."""
         self._h = C.c_void_p()
         check(lib().ccd_batch_create(int(device), C.byref(self._h)), "ccd_batch_create")
         self.device = int(device)
@@ -49,6 +51,8 @@ class DecodeBatch:
             check(lib().ccd_batch_set_option(self._h, self.OPT_MFMA_ARM, int(mfma_arm)), "ccd_batch_set_option")
         if range_bits is not None:
             check(lib().ccd_batch_set_option(self._h, self.OPT_RANGE_BITS, int(range_bits)), "ccd_batch_set_option")
+        if overlap is not None:
+            check(lib().ccd_batch_set_option(self._h, self.OPT_OVERLAP, int(bool(overlap))), "ccd_batch_set_option")
         self._meta: List[Tuple[int, int]] = []
 
     def close(self):
@@ -88,6 +92,10 @@ class DecodeBatch:
             check(lib().ccd_batch_run(self._h, st), "ccd_batch_run")
         else:
             check(lib().ccd_batch_run_stage(self._h, st, int(stage)), "ccd_batch_run_stage")
+
+    def entropy_launches(self) -> int:
+        """Entropy launches per run (kernel instantiations x chain groups) as the launch tables were last built."""
+        return check(lib().ccd_batch_entropy_launches(self._h), "ccd_batch_entropy_launches")
 
     def wait(self, stream: int = 0):
         check(lib().ccd_batch_wait(self._h, C.c_void_p(stream or None)), "ccd_batch_wait")

@@ -2,6 +2,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -58,6 +61,7 @@ hipError_t launch_inter_recon(int frame_type, int h, int w, int n_taps, const in
 hipError_t launch_planes(const float* src, void* p0, void* p1, void* p2, int h, int w, int bitdepth, int frame_data_type,
                          hipStream_t stream);
 hipError_t launch_widen_u8(const uint8_t* in, uint16_t* out, size_t n, hipStream_t stream);
+hipError_t launch_spin(unsigned long long ticks, hipStream_t stream);
 
 static const uint32_t kScaleBits[kNumScale] = {
 #include "../../include/ccd_scale_table.inc"
@@ -178,8 +182,18 @@ struct DeviceShared {
     // stream is a serial chain on one CU, so launches that queue behind each other on ONE stream add their durations
     static constexpr int kSide = 8;
     hipStream_t side[kSide] = {};
+    // r06: which of them REALLY run at once.  HIP multiplexes its streams onto a few hardware queues (four by default,
+    // GPU_MAX_HW_QUEUES), and two launches on streams that share one run one after the other: tools/ubench/queues.hip on MI355X /
+    // ROCm 7.2 - the null stream + side[1] 9.7 ms where the null stream + side[0] take 4.9, three "concurrent" launches 2 x one
+    // (profiles/r06/queues.txt); r05's fork over (caller's stream, side[0], side[1], ...) was serial or not by luck - with a
+    // batch of 256 streams in two launches 72 ms instead of 37.  So the side streams are MEASURED once per device (calibrate):
+    // conc[0 .. n_conc) are mutually concurrent ones (one per hardware queue: at most four are looked for), and the launches of a
+    // batch that need to overlap go to those only - never to the caller's stream, which idles at the join and may alias any of them.
+    int n_conc = 0;
+    int conc[kSide] = {};
 };
 int device_shared(int device, DeviceShared** out);
+void calibrate_side_streams(DeviceShared& d);
 
 // Bump allocator over one pooled device block: every slot's buffers live in a single arena.
 class Arena {
@@ -239,6 +253,8 @@ struct Slot {
     int fixed_shape = 0;     // ... the instantiation with a compile-time ARM shape (1: intra/hop.cfg = 14 + 6 inputs, two hidden layers)
     int ring_rows = 64;      // rows of the pipelined kernel's decoded-symbol ring
     size_t lds_generic = 0, lds_pipe = 0;
+    int lg = -1;             // entropy launch of the batch this slot is decoded by (index into ccd_batch::pipe_groups; -1: the generic launch)
+    int fl = -1;             // launch group its float-path launches are keyed by (= lg while ccd_batch_run overlaps; -1: not keyed)
     int status = CCD_OK;
     int32_t host_status[64] = {0};
 };
@@ -250,6 +266,7 @@ struct ccd_batch {
     std::vector<std::unique_ptr<Slot>> slots;
     EntropyParams* d_params = nullptr;   // [pipe slots..., generic slots...]
     int n_params_uploaded = 0;
+    bool regroup = false;                // an option that shapes the launch tables changed: rebuild them at the next run
     // every table the launches read (entropy descriptors, fused-kernel frames and work lists, pyramid steps) and the status
     // words of all slots live in ONE pooled device block, staged through ONE pinned block: one copy up, one copy down
     Block tables, tables_staging, status_host;
@@ -263,15 +280,26 @@ struct ccd_batch {
     int drain_streams() {
         int rc = CCD_OK;
         for (hipStream_t st : streams_used) if (hipStreamSynchronize(st) != hipSuccess) rc = CCD_ERR_HIP;
+        // the device's SHARED side streams are not drained (another batch in flight may be launching on them: draining would
+        // make this batch's destroy wait for that batch's entropy chains) - this batch's own work on them ends at its events
+        for (int k = 0; k < DeviceShared::kSide; ++k)
+            if (side_pending[k] && side_done[k]) { if (hipEventSynchronize(side_done[k]) != hipSuccess) rc = CCD_ERR_HIP; side_pending[k] = false; }
         return rc;
     }
     // fork / join of the entropy launches over the device's side streams: the EVENTS belong to the batch (two host threads
     // running two batches on one GPU share the side streams, which only serialises their launches, but never an event)
     hipEvent_t fork = nullptr;
-    hipEvent_t side_done[DeviceShared::kSide] = {};
+    hipEvent_t side_done[DeviceShared::kSide] = {};   // recorded behind EVERY launch of this batch on side stream k
+    bool side_pending[DeviceShared::kSide] = {};      // ... and not yet known to have completed
+    // the launch tables' copy (upload_params): a run on ANOTHER stream than the one that carried it waits for this event
+    hipEvent_t params_up = nullptr;
+    hipStream_t params_stream = nullptr;
     bool uploads_unconfirmed = false;    // slots were added since the last ccd_batch_wait: launches order themselves behind up_done
     int n_pipe = 0, n_generic = 0;
-    struct PipeGroup { int nv, mfma, dyn, shape, first, n; size_t lds; };
+    // cg: chain group - the slots of one kernel instantiation split by the expected length of their serial chains, so that the
+    // float-path launches of the streams that finish early run while the longest chains are still decoding (ccd_batch_run)
+    struct PipeGroup { int nv, mfma, dyn, shape, cg, first, n; size_t lds; double est; };
+    int opt_overlap = 1;                 // CCD_OVERLAP=0 (environment; A/B and tests): one entropy launch per instantiation, float stages behind the join
     std::vector<PipeGroup> pipe_groups;
     float* d_scale_table = nullptr;
     double* d_rcp_table = nullptr;
@@ -282,12 +310,12 @@ struct ccd_batch {
     std::vector<FusedGroup> fused_groups;
     SynthFused* d_fused = nullptr;
     // fused float path (ccd_fused.hip): frames grouped by (latent levels, output channels); one workgroup per run of tiles
-    struct FdecGroup { int c_in, c, pre, cr, first_frame, first_work, n_work; size_t lds; };
+    struct FdecGroup { int c_in, c, pre, cr, fl, first_frame, first_work, n_work; size_t lds; };
     std::vector<FdecGroup> fdec_groups;
     FusedDec* d_fdec = nullptr;
     void* d_fdec_work = nullptr;
     // pyramid launches in front of the kFdPre groups (stage 1): descriptors grouped by their number of levels
-    struct PyrGroup { int levels, first_frame, first_work, n_work; size_t lds; };
+    struct PyrGroup { int levels, fl, first_frame, first_work, n_work; size_t lds; };
     std::vector<PyrGroup> pyr_groups;
     FusedDec* d_pyr = nullptr;
     void* d_pyr_work = nullptr;
@@ -348,6 +376,43 @@ namespace {
 std::mutex g_shared_mu;
 std::map<int, DeviceShared> g_shared;
 
+// Which side streams run concurrently (see DeviceShared::conc).  Two spin kernels of ~0.2 ms, one on each of two streams, take
+// ~0.2 ms when the streams sit on different hardware queues and ~0.4 ms when they share one; a greedy clique of up to four.  ~10 ms
+// once per device and process.  CCD_SIDE_STREAMS=k skips the measurement and takes the first k (0 < k <= 8; r05's behaviour: 8).
+// Under a profiler that serialises kernels nothing is concurrent: one stream, launches in a row - correct, only slower.
+void calibrate_side_streams(DeviceShared& d) {
+    d.n_conc = 1; d.conc[0] = 0;
+    if (const char* e = std::getenv("CCD_SIDE_STREAMS")) {
+        const int k = std::atoi(e);
+        if (k >= 1 && k <= DeviceShared::kSide) { d.n_conc = k; for (int i = 0; i < k; ++i) d.conc[i] = i; return; }
+    }
+    const unsigned long long ticks = 400000ull;  // ~0.17 ms of the shader clock
+    auto pair_ms = [&](int a, int b2) -> double {
+        double best = 1e9;
+        for (int trial = 0; trial < 3; ++trial) {
+            if (hipStreamSynchronize(d.side[a]) != hipSuccess || hipStreamSynchronize(d.side[b2]) != hipSuccess) return 1e9;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (launch_spin(ticks, d.side[a]) != hipSuccess || launch_spin(ticks, d.side[b2]) != hipSuccess) return 1e9;
+            if (hipStreamSynchronize(d.side[a]) != hipSuccess || hipStreamSynchronize(d.side[b2]) != hipSuccess) return 1e9;
+            best = std::min(best, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+        return best;
+    };
+    // one kernel alone (same stream twice = certainly serial): the yardstick, whatever the clock
+    const double serial = pair_ms(0, 0);
+    if (serial >= 1e8) return;
+    for (int j = 1; j < DeviceShared::kSide && d.n_conc < 4; ++j) {
+        bool with_all = true;
+        for (int i = 0; i < d.n_conc && with_all; ++i) with_all = pair_ms(d.conc[i], j) < 0.75 * serial;
+        if (with_all) d.conc[d.n_conc++] = j;
+    }
+    if (std::getenv("CCD_VIDEO_TIMING") || std::getenv("CCD_DEBUG_STREAMS")) {
+        std::fprintf(stderr, "[ccd] side streams that run concurrently: %d (", d.n_conc);
+        for (int i = 0; i < d.n_conc; ++i) std::fprintf(stderr, "%s%d", i ? " " : "", d.conc[i]);
+        std::fprintf(stderr, "), two kernels in a row %.3f ms\n", serial);
+    }
+}
+
 int device_shared(int device, DeviceShared** out) {
     std::lock_guard<std::mutex> lock(g_shared_mu);
     DeviceShared& d = g_shared[device];
@@ -375,6 +440,7 @@ int device_shared(int device, DeviceShared** out) {
         bool ok = true;
         for (int k = 0; k < DeviceShared::kSide && ok; ++k) ok = hipStreamCreateWithFlags(&d.side[k], hipStreamNonBlocking) == hipSuccess;
         if (!ok) return CCD_ERR_HIP;
+        calibrate_side_streams(d);
     }
     *out = &d;
     return CCD_OK;
@@ -399,6 +465,7 @@ int ccd_batch_create(int device, ccd_batch** out) {
     }
     if (const char* e = std::getenv("CCD_MFMA_ARM")) b->opt_mfma_arm = std::atoi(e);
     if (const char* e = std::getenv("CCD_FIXED_SHAPE")) b->opt_fixed_shape = std::atoi(e);
+    if (const char* e = std::getenv("CCD_OVERLAP")) b->opt_overlap = std::atoi(e);
     b->d_scale_table = sh->d_scale_table;
     b->d_rcp_table = sh->d_rcp_table;
     b->up_stream = sh->up_stream;
@@ -414,6 +481,7 @@ void ccd_batch_destroy(ccd_batch* b) {
     if (b->up_done) { (void)hipEventSynchronize(b->up_done); (void)hipEventDestroy(b->up_done); }
     (void)b->drain_streams();  // launches and copies on EVERY stream the caller used with this batch
     if (b->fork) (void)hipEventDestroy(b->fork);
+    if (b->params_up) (void)hipEventDestroy(b->params_up);
     for (hipEvent_t e : b->side_done) if (e) (void)hipEventDestroy(e);
     for (auto& s : b->slots) { s->arena.release(); s->staging.drop(); }
     b->tables.drop(); b->tables_staging.drop(); b->status_host.drop();
@@ -862,26 +930,77 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     return static_cast<int>(b->slots.size()) - 1;
 }
 
+// Expected length of a slot's serial chain in decoder ticks (only the ORDER and rough ratios matter: it decides which streams
+// share an entropy launch).  Per grid ~120 ticks per symbol + ~1.8 k per wavefront step (latent.py:66-140: W + 10 (H - 1) steps):
+// profiles/r06/prof_grids_base.txt - a portrait Kodak stream comes out 1.09 x a landscape one (measured 1.06).
+static double chain_estimate(const EntropyParams& ep) {
+    double t = 0.0;
+    for (int g = 0; g < ep.n_grids; ++g) {
+        const double h = ep.grid_h[g], w = ep.grid_w[g];
+        t += 120.0 * h * w + 1800.0 * (w > 9.0 ? w + 10.0 * (h - 1.0) : h * w);
+    }
+    return t;
+}
+
 static int upload_params(ccd_batch* b, hipStream_t st) {
     const int n = static_cast<int>(b->slots.size());
-    if (b->n_params_uploaded == n) return CCD_OK;
+    if (b->n_params_uploaded == n && !b->regroup) return CCD_OK;
+    b->regroup = false;
     std::vector<EntropyParams> host;
     std::vector<int> host_slot;  // slot of host[k]: its status words are words [64 slot, 64 slot + 64) of the batch's status array
     b->pipe_groups.clear();  // the pipelined kernel is instantiated per input width nv = ceil(dim / 4): one launch per width
+    // ---- chain groups (r06).  A stream is one serial chain on one CU and a launch ends with its slowest stream; the float path of
+    // a frame only needs THAT frame's latents.  So the slots of an instantiation are split by expected chain length into up to three
+    // launches - the streams within 3 % of the batch's longest chain, those within 20 %, the rest - and ccd_batch_run puts each
+    // launch's pyramid + fused launches directly behind it on its own stream: the float stage of the streams that finish early
+    // hides behind the longest chains (kodak24: 18 landscape pictures are done 2 ms before the 6 portrait ones).  At most ~4
+    // launches per batch: HIP streams share a handful of hardware queues.
+    std::vector<double> est(n, 0.0);
+    std::vector<int> cg_of(n, 0);
+    {
+        double est_max = 0.0;
+        std::vector<std::array<int, 3>> insts;
+        for (int i = 0; i < n; ++i) {
+            const Slot& sl = *b->slots[i];
+            est[i] = chain_estimate(sl.ep);
+            if (!sl.use_pipe) continue;
+            est_max = std::max(est_max, est[i]);
+            const std::array<int, 3> key{(sl.ep.dim + 3) / 4, sl.use_mfma ? 2 : (sl.use_dyn ? 1 : 0), sl.fixed_shape};
+            if (std::find(insts.begin(), insts.end(), key) == insts.end()) insts.push_back(key);
+        }
+        // as many launches as streams really run at once (DeviceShared::n_conc, measured), shared between the instantiations
+        int n_conc = 1;
+        { DeviceShared* shd = nullptr; if (device_shared(b->device, &shd) >= 0) n_conc = shd->n_conc; }
+        const int max_cg = !b->opt_overlap ? 1 : std::max(1, std::min(3, n_conc / std::max<int>(1, static_cast<int>(insts.size()))));
+        for (int i = 0; i < n; ++i) {
+            const int c = est[i] >= 0.97 * est_max ? 0 : (est[i] >= 0.80 * est_max ? 1 : 2);
+            cg_of[i] = std::min(c, max_cg - 1);
+        }
+    }
     for (int nv = 1; nv <= 8; ++nv)
         for (int var = 0; var < 3; ++var)  // vector ALU without / with the device check of the features, matrix cores
-            for (int shape = 0; shape < 2; ++shape) {  // run-time ARM shape / the compile-time instantiation of the HOP shape
-                const int mf = var == 2 ? 1 : 0, dyn = var == 1 ? 1 : 0;
-                const int first = static_cast<int>(host.size());
-                size_t lds = 0;
-                for (int i = 0; i < n; ++i) {
-                    const Slot& sl = *b->slots[i];
-                    if (sl.use_pipe && (sl.ep.dim + 3) / 4 == nv && (sl.use_mfma ? 1 : 0) == mf && (sl.use_dyn ? 1 : 0) == dyn && sl.fixed_shape == shape) {
-                        host.push_back(sl.ep); host_slot.push_back(i); lds = std::max(lds, sl.lds_pipe);
+            for (int shape = 0; shape < 2; ++shape)  // run-time ARM shape / the compile-time instantiation of the HOP shape
+                for (int cg = 0; cg < 3; ++cg) {
+                    const int mf = var == 2 ? 1 : 0, dyn = var == 1 ? 1 : 0;
+                    const int first = static_cast<int>(host.size());
+                    size_t lds = 0;
+                    double est_g = 0.0;
+                    for (int i = 0; i < n; ++i) {
+                        Slot& sl = *b->slots[i];
+                        if (sl.use_pipe && (sl.ep.dim + 3) / 4 == nv && (sl.use_mfma ? 1 : 0) == mf && (sl.use_dyn ? 1 : 0) == dyn && sl.fixed_shape == shape && cg_of[i] == cg) {
+                            host.push_back(sl.ep); host_slot.push_back(i); lds = std::max(lds, sl.lds_pipe);
+                            est_g = std::max(est_g, est[i]);
+                            sl.lg = static_cast<int>(b->pipe_groups.size());
+                        }
                     }
+                    if (static_cast<int>(host.size()) > first) b->pipe_groups.push_back({nv, mf, dyn, shape, cg, first, static_cast<int>(host.size()) - first, lds, est_g});
                 }
-                if (static_cast<int>(host.size()) > first) b->pipe_groups.push_back({nv, mf, dyn, shape, first, static_cast<int>(host.size()) - first, lds});
-            }
+    for (int i = 0; i < n; ++i) {
+        Slot& sl = *b->slots[i];
+        if (!sl.use_pipe) sl.lg = -1;
+        // float launches keyed by the entropy launch they follow - only worth it (and only done) when there are several launches
+        sl.fl = (b->opt_overlap && sl.use_pipe) ? sl.lg : -1;
+    }
     b->n_pipe = static_cast<int>(host.size());
     for (int i = 0; i < n; ++i) if (!b->slots[i]->use_pipe) { host.push_back(b->slots[i]->ep); host_slot.push_back(i); }
     b->n_generic = n - b->n_pipe;
@@ -918,8 +1037,8 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
             const Slot& s = *b->slots[i];
             if (!s.use_fused_dec) continue;
             bool placed = false;
-            for (auto& g : b->fdec_groups) placed = placed || (g.c_in == s.fdec.n_lv && g.c == s.fdec.c && g.pre == (s.fdec_pre ? 1 : 0) && g.cr == (s.cr ? 1 : 0));
-            if (!placed) b->fdec_groups.push_back({s.fdec.n_lv, s.fdec.c, s.fdec_pre ? 1 : 0, s.cr ? 1 : 0, 0, 0, 0, 0});
+            for (auto& g : b->fdec_groups) placed = placed || (g.c_in == s.fdec.n_lv && g.c == s.fdec.c && g.pre == (s.fdec_pre ? 1 : 0) && g.cr == (s.cr ? 1 : 0) && g.fl == s.fl);
+            if (!placed) b->fdec_groups.push_back({s.fdec.n_lv, s.fdec.c, s.fdec_pre ? 1 : 0, s.cr ? 1 : 0, s.fl, 0, 0, 0, 0});
         }
         for (auto& g : b->fdec_groups) {
             g.first_frame = static_cast<int>(frames.size());
@@ -927,13 +1046,13 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
             long total_tiles = 0;
             for (int i = 0; i < n; ++i) {
                 const Slot& s = *b->slots[i];
-                if (s.use_fused_dec && s.fdec.n_lv == g.c_in && s.fdec.c == g.c && (s.fdec_pre ? 1 : 0) == g.pre && (s.cr ? 1 : 0) == g.cr) total_tiles += static_cast<long>(s.fdec.tiles_x) * s.fdec.tiles_y;
+                if (s.use_fused_dec && s.fdec.n_lv == g.c_in && s.fdec.c == g.c && (s.fdec_pre ? 1 : 0) == g.pre && (s.cr ? 1 : 0) == g.cr && s.fl == g.fl) total_tiles += static_cast<long>(s.fdec.tiles_x) * s.fdec.tiles_y;
             }
             // ~8 workgroups per CU keep the tail short; a run of tiles amortises the parameter staging
             const int per_wg = static_cast<int>(std::min<long>(8, std::max<long>(1, (total_tiles + 2047) / 2048)));
             for (int i = 0; i < n; ++i) {
                 const Slot& s = *b->slots[i];
-                if (!s.use_fused_dec || s.fdec.n_lv != g.c_in || s.fdec.c != g.c || (s.fdec_pre ? 1 : 0) != g.pre || (s.cr ? 1 : 0) != g.cr) continue;
+                if (!s.use_fused_dec || s.fdec.n_lv != g.c_in || s.fdec.c != g.c || (s.fdec_pre ? 1 : 0) != g.pre || (s.cr ? 1 : 0) != g.cr || s.fl != g.fl) continue;
                 const int f = static_cast<int>(frames.size()) - g.first_frame;
                 frames.push_back(s.fdec);
                 g.lds = std::max(g.lds, s.fdec_lds);
@@ -947,26 +1066,27 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
     b->pyr_groups.clear();
     std::vector<FusedDec> pyr_frames;
     std::vector<Work> pyr_work;
-    for (int lv = 2; lv < kFdMaxLevels; ++lv) {
-        ccd_batch::PyrGroup g{lv, static_cast<int>(pyr_frames.size()), static_cast<int>(pyr_work.size()), 0, fused_pyr_lds_bytes(lv + 1)};
-        long total_tiles = 0;
-        for (int i = 0; i < n; ++i) {
-            const Slot& s = *b->slots[i];
-            if (s.fdec_pre && s.fpyr.n_lv == lv) total_tiles += static_cast<long>(s.fpyr.tiles_x) * s.fpyr.tiles_y;
+    for (int lv = 2; lv < kFdMaxLevels; ++lv)
+        for (int fl = -1; fl < static_cast<int>(b->pipe_groups.size()); ++fl) {
+            ccd_batch::PyrGroup g{lv, fl, static_cast<int>(pyr_frames.size()), static_cast<int>(pyr_work.size()), 0, fused_pyr_lds_bytes(lv + 1)};
+            long total_tiles = 0;
+            for (int i = 0; i < n; ++i) {
+                const Slot& s = *b->slots[i];
+                if (s.fdec_pre && s.fpyr.n_lv == lv && s.fl == fl) total_tiles += static_cast<long>(s.fpyr.tiles_x) * s.fpyr.tiles_y;
+            }
+            if (!total_tiles) continue;
+            const int per_wg = static_cast<int>(std::min<long>(8, std::max<long>(1, (total_tiles + 2047) / 2048)));
+            for (int i = 0; i < n; ++i) {
+                const Slot& s = *b->slots[i];
+                if (!s.fdec_pre || s.fpyr.n_lv != lv || s.fl != fl) continue;
+                const int f = static_cast<int>(pyr_frames.size()) - g.first_frame;
+                pyr_frames.push_back(s.fpyr);
+                const int nt = s.fpyr.tiles_x * s.fpyr.tiles_y;
+                for (int t0 = 0; t0 < nt; t0 += per_wg) pyr_work.push_back({f, t0, std::min(per_wg, nt - t0), 0});
+            }
+            g.n_work = static_cast<int>(pyr_work.size()) - g.first_work;
+            b->pyr_groups.push_back(g);
         }
-        if (!total_tiles) continue;
-        const int per_wg = static_cast<int>(std::min<long>(8, std::max<long>(1, (total_tiles + 2047) / 2048)));
-        for (int i = 0; i < n; ++i) {
-            const Slot& s = *b->slots[i];
-            if (!s.fdec_pre || s.fpyr.n_lv != lv) continue;
-            const int f = static_cast<int>(pyr_frames.size()) - g.first_frame;
-            pyr_frames.push_back(s.fpyr);
-            const int nt = s.fpyr.tiles_x * s.fpyr.tiles_y;
-            for (int t0 = 0; t0 < nt; t0 += per_wg) pyr_work.push_back({f, t0, std::min(per_wg, nt - t0), 0});
-        }
-        g.n_work = static_cast<int>(pyr_work.size()) - g.first_work;
-        b->pyr_groups.push_back(g);
-    }
     // upsampling steps: step k (k-th from the coarsest level) of all slots together
     b->ups_steps.clear();
     std::vector<UpsampleLevel> levels;
@@ -1031,6 +1151,10 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
     if (!pyr_work.empty()) std::memcpy(stg + o_pyrw, pyr_work.data(), sizeof(Work) * pyr_work.size());
     std::memset(stg + o_stat, 0, total - o_stat);
     HIP_TRY(hipMemcpyAsync(dev, stg, total, hipMemcpyHostToDevice, st));
+    // a later run on ANOTHER stream (ccd_batch_prepare on one, ccd_batch_run on the next) orders itself behind this copy
+    if (!b->params_up) HIP_TRY(hipEventCreateWithFlags(&b->params_up, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(b->params_up, st));
+    b->params_stream = st;
     b->n_params_uploaded = n;
     return CCD_OK;
 }
@@ -1107,60 +1231,95 @@ static int run_synthesis(Slot& s, hipStream_t st) {
     return CCD_OK;
 }
 
-int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
-    if (!b) return CCD_ERR_ARG;
-    HIP_TRY(hipSetDevice(b->device));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (b->uploads_unconfirmed) HIP_TRY(hipStreamWaitEvent(st, b->up_done, 0));  // the slots' uploads (ccd_batch_add) come first
-    b->note_stream(st);
-    int rc = upload_params(b, st);
-    if (rc < 0) return rc;
-    if (stage == 0) {
-        // One launch per kernel instantiation in use.  The first goes to the caller's stream; the others fork to side streams
-        // and join again, so that they overlap (each stream of a launch occupies one CU for its whole serial chain: queued on
-        // one stream, a GOP whose I frames need another instantiation than its B frames took the SUM of the two).
-        const int n_launch = static_cast<int>(b->pipe_groups.size()) + (b->n_generic > 0 ? 1 : 0);
-        DeviceShared* sh = nullptr;
-        if (n_launch > 1) {
-            rc = device_shared(b->device, &sh);
-            if (rc < 0) return rc;
-            if (!b->fork) HIP_TRY(hipEventCreateWithFlags(&b->fork, hipEventDisableTiming));
-            HIP_TRY(hipEventRecord(b->fork, st));
-        }
-        int k = 0;
-        std::vector<int> used;
-        auto stream_for = [&](int idx) -> hipStream_t {
-            if (idx == 0 || !sh) return st;
-            const int side = (idx - 1) % DeviceShared::kSide;
-            if (std::find(used.begin(), used.end(), side) == used.end()) {
-                used.push_back(side);
-                // drained with the caller's streams before the arenas return to the pool (ccd_batch_destroy, upload_params): an
-                // error between this fork and the join below leaves launches on the side stream that no event orders
-                b->note_stream(sh->side[side]);
-                (void)hipStreamWaitEvent(sh->side[side], b->fork, 0);
-            }
-            return sh->side[side];
-        };
-        for (const auto& g : b->pipe_groups) HIP_TRY(launch_entropy_pipe(b->d_params + g.first, g.n, g.nv, g.mfma, g.dyn, g.shape, g.lds, stream_for(k++)));
-        if (b->n_generic > 0) HIP_TRY(launch_entropy(b->d_params + b->n_pipe, b->n_generic, b->lds_generic, stream_for(k++)));
-        for (int side : used) {
-            if (!b->side_done[side]) HIP_TRY(hipEventCreateWithFlags(&b->side_done[side], hipEventDisableTiming));
-            HIP_TRY(hipEventRecord(b->side_done[side], sh->side[side]));
-            HIP_TRY(hipStreamWaitEvent(st, b->side_done[side], 0));
-        }
-        return CCD_OK;
+// Entropy launches of a batch (and, with `with_float`, each launch's own float-path launches right behind it) forked over the
+// device's side streams and joined on `st`.  Launch 0 - the one with the longest expected chains - stays on the caller's stream.
+// With ONE launch there is nothing to fork: it goes to `st` and the float stages follow it there (the caller enqueues them).
+static int launch_entropy_groups(ccd_batch* b, hipStream_t st, bool with_float) {
+    // launch order: longest expected chains first (they start first where launches queue behind each other)
+    std::vector<int> order(b->pipe_groups.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = static_cast<int>(i);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return b->pipe_groups[x].est > b->pipe_groups[y].est; });
+    const int n_launch = static_cast<int>(order.size()) + (b->n_generic > 0 ? 1 : 0);
+    DeviceShared* sh = nullptr;
+    if (n_launch > 1) {
+        const int rc = device_shared(b->device, &sh);
+        if (rc < 0) return rc;
+        if (!b->fork) HIP_TRY(hipEventCreateWithFlags(&b->fork, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(b->fork, st));
     }
+    std::vector<int> used;
+    // one launch: the caller's stream.  Several: ALL of them on the side streams that were measured to run concurrently
+    // (DeviceShared::conc), launch k on conc[k mod n_conc] - the caller's stream only forks and joins.
+    auto stream_for = [&](int idx, int* side_out) -> hipStream_t {
+        *side_out = -1;
+        if (!sh) return st;
+        const int side = sh->conc[idx % sh->n_conc];
+        if (std::find(used.begin(), used.end(), side) == used.end()) {
+            used.push_back(side);
+            (void)hipStreamWaitEvent(sh->side[side], b->fork, 0);
+        }
+        *side_out = side;
+        return sh->side[side];
+    };
+    // an event behind everything this batch has put on a side stream so far: what a destroy / a table replacement waits for, also
+    // after an error between the fork and the join below (the shared side streams themselves are never drained)
+    auto mark = [&](int side) -> int {
+        if (side < 0) return CCD_OK;
+        if (!b->side_done[side]) HIP_TRY(hipEventCreateWithFlags(&b->side_done[side], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(b->side_done[side], sh->side[side]));
+        b->side_pending[side] = true;
+        return CCD_OK;
+    };
+    int k = 0;
+    for (int gi : order) {
+        const auto& g = b->pipe_groups[gi];
+        int side = -1;
+        hipStream_t s = stream_for(k++, &side);
+        hipError_t e = launch_entropy_pipe(b->d_params + g.first, g.n, g.nv, g.mfma, g.dyn, g.shape, g.lds, s);
+        if (e == hipSuccess && with_float) {
+            // this launch's frames: pyramid launch(es), then the fused kernel - on the SAME stream, so they start when this launch's
+            // slowest stream is done, whatever the other launches are doing.  (Common randomness needs its noise planes first:
+            // those groups run behind the join like every per-slot launch.)
+            for (const auto& pg : b->pyr_groups)
+                if (pg.fl == gi && e == hipSuccess)
+                    e = launch_fused_pyramid(b->d_pyr + pg.first_frame, static_cast<const char*>(b->d_pyr_work) + static_cast<size_t>(pg.first_work) * 16, pg.n_work, pg.levels, pg.lds, s);
+            for (const auto& fg : b->fdec_groups)
+                if (fg.fl == gi && !fg.cr && e == hipSuccess)
+                    e = launch_fused_dec(b->d_fdec + fg.first_frame, static_cast<const char*>(b->d_fdec_work) + static_cast<size_t>(fg.first_work) * 16, fg.n_work, fg.c_in, fg.c, fg.pre, fg.lds, s);
+        }
+        const int rc = mark(side);
+        if (e != hipSuccess) return CCD_ERR_HIP;
+        if (rc < 0) return rc;
+    }
+    if (b->n_generic > 0) {
+        int side = -1;
+        hipStream_t s = stream_for(k++, &side);
+        const hipError_t e = launch_entropy(b->d_params + b->n_pipe, b->n_generic, b->lds_generic, s);
+        const int rc = mark(side);
+        if (e != hipSuccess) return CCD_ERR_HIP;
+        if (rc < 0) return rc;
+    }
+    for (int side : used) HIP_TRY(hipStreamWaitEvent(st, b->side_done[side], 0));
+    return CCD_OK;
+}
+
+// the float-path launches of stage 1 / stage 2 that belong to the whole batch; `keyed_done`: the pyramid / fused launches keyed by
+// an entropy launch were already enqueued behind it (launch_entropy_groups with_float)
+static int launch_float_stage(ccd_batch* b, hipStream_t st, int stage, bool keyed_done) {
     if (stage == 1) {
         for (const auto& u : b->ups_steps)
             HIP_TRY(launch_upsample_step(b->d_levels, b->d_zmap + u.first_z, u.n_z, u.max_w, u.max_h, st));
-        for (const auto& g : b->pyr_groups)
+        for (const auto& g : b->pyr_groups) {
+            if (keyed_done && g.fl >= 0) continue;
             HIP_TRY(launch_fused_pyramid(b->d_pyr + g.first_frame, static_cast<const char*>(b->d_pyr_work) + static_cast<size_t>(g.first_work) * 16,
                                          g.n_work, g.levels, g.lds, st));
+        }
     }
     if (stage == 2) {
         for (const auto& g : b->fused_groups)
             HIP_TRY(launch_syn_fused(b->d_fused + g.first, g.n, g.c_in, g.c, g.max_tx, g.max_ty, st));
         for (const auto& g : b->fdec_groups) {
+            if (keyed_done && g.fl >= 0 && !g.cr) continue;
             const FusedDec* fr = b->d_fdec + g.first_frame;
             const char* wk = static_cast<const char*>(b->d_fdec_work) + static_cast<size_t>(g.first_work) * 16;
             if (g.cr) HIP_TRY(launch_fused_dec_cr(fr, wk, g.n_work, g.c_in, g.c, g.lds, st));
@@ -1168,10 +1327,33 @@ int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
         }
     }
     for (auto& sp : b->slots) {
-        rc = (stage == 1) ? run_upsampling(*sp, st) : (stage == 2 ? run_synthesis(*sp, st) : CCD_ERR_ARG);
+        const int rc = (stage == 1) ? run_upsampling(*sp, st) : run_synthesis(*sp, st);
         if (rc < 0) return rc;
     }
     return CCD_OK;
+}
+
+// common head of a run: device, the slots' uploads, the launch tables (and their copy, if another stream carried it)
+static int run_prologue(ccd_batch* b, hipStream_t st) {
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->uploads_unconfirmed) HIP_TRY(hipStreamWaitEvent(st, b->up_done, 0));  // the slots' uploads (ccd_batch_add) come first
+    b->note_stream(st);
+    const int rc = upload_params(b, st);
+    if (rc < 0) return rc;
+    if (b->params_up && b->params_stream != st) HIP_TRY(hipStreamWaitEvent(st, b->params_up, 0));
+    return CCD_OK;
+}
+
+int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage) {
+    if (!b || stage < 0 || stage > 2) return CCD_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rc = run_prologue(b, st);
+    if (rc < 0) return rc;
+    // stage 0: one launch per kernel instantiation and chain group in use.  The first goes to the caller's stream; the others fork
+    // to side streams and join again, so that they overlap (each stream of a launch occupies one CU for its whole serial chain:
+    // queued on one stream, a GOP whose I frames need another instantiation than its B frames took the SUM of the two).
+    if (stage == 0) return launch_entropy_groups(b, st, false);
+    return launch_float_stage(b, st, stage, false);
 }
 
 int ccd_batch_prepare(ccd_batch* b, void* stream) {
@@ -1182,9 +1364,19 @@ int ccd_batch_prepare(ccd_batch* b, void* stream) {
     return upload_params(b, st);
 }
 
+// All three stages.  Unlike three ccd_batch_run_stage calls, the float path of a frame does not wait for the slowest stream of
+// the BATCH: every entropy launch (kernel instantiation x chain group, upload_params) is followed on its own stream by the
+// pyramid + fused launches of its own frames, and the streams join once at the end (decode.py:67-81: frames are independent).
 int ccd_batch_run(ccd_batch* b, void* stream) {
-    for (int stage = 0; stage < 3; ++stage) {
-        const int rc = ccd_batch_run_stage(b, stream, stage);
+    if (!b) return CCD_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = run_prologue(b, st);
+    if (rc < 0) return rc;
+    const bool overlap = b->opt_overlap && b->pipe_groups.size() + (b->n_generic > 0 ? 1 : 0) > 1;
+    rc = launch_entropy_groups(b, st, overlap);
+    if (rc < 0) return rc;
+    for (int stage = 1; stage <= 2; ++stage) {
+        rc = launch_float_stage(b, st, stage, overlap);
         if (rc < 0) return rc;
     }
     return CCD_OK;
@@ -1228,6 +1420,20 @@ int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64) {
     return CCD_OK;
 }
 
+int ccd_concurrent_streams(int device) {
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev) return CCD_ERR_HIP;
+    HIP_TRY(hipSetDevice(device));
+    DeviceShared* sh = nullptr;
+    const int rc = device_shared(device, &sh);
+    return rc < 0 ? rc : sh->n_conc;
+}
+
+int ccd_batch_entropy_launches(const ccd_batch* b) {
+    if (!b) return CCD_ERR_ARG;
+    return static_cast<int>(b->pipe_groups.size()) + (b->n_generic > 0 ? 1 : 0);
+}
+
 int ccd_batch_slot_kernels(const ccd_batch* b, int slot) {
     if (!b || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
     const Slot& s = *b->slots[slot];
@@ -1253,6 +1459,10 @@ int ccd_batch_set_option(ccd_batch* b, int option, int value) {
         case CCD_OPT_KEEP_FLOAT: b->opt_keep_float = value; return CCD_OK;
         case CCD_OPT_MFMA_ARM: b->opt_mfma_arm = value; return CCD_OK;
         case CCD_OPT_RANGE_BITS: b->opt_range_bits = value; return CCD_OK;
+        case CCD_OPT_OVERLAP:
+            // (decides how the launch tables are grouped: a change re-builds them at the next run)
+            if (b->opt_overlap != (value ? 1 : 0)) { b->opt_overlap = value ? 1 : 0; b->regroup = true; }
+            return CCD_OK;
         default: return CCD_ERR_ARG;
     }
 }
@@ -1414,6 +1624,13 @@ int ccd_inter_reconstruct(int device, void* stream, int frame_type, int h, int w
 int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
     if (!bs || !v) return CCD_ERR_ARG;
     v->n_frames = 0; v->frames = nullptr;
+    // CCD_VIDEO_TIMING=1: host wall clock of the call's phases on stderr (tools/prof_gop.py)
+    const bool timing = std::getenv("CCD_VIDEO_TIMING") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (timing) std::fprintf(stderr, "[ccd_decode_video] %-28s %8.2f ms\n", what,
+                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    };
     std::unique_ptr<ccd_video_header> vh(new (std::nothrow) ccd_video_header());
     if (!vh) return CCD_ERR_NOMEM;
     int used = read_video_header(bs, n, vh.get());
@@ -1463,8 +1680,11 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
             pos += static_cast<size_t>(ch.nn_n_bytes) + static_cast<size_t>(ch.n_bytes_latent);
         }
     }
+    mark("parsed + added");
     if (rc >= 0) rc = ccd_batch_run(b, nullptr);
+    mark("launched");
     if (rc >= 0) rc = ccd_batch_wait(b, nullptr);
+    mark("cool-chics decoded");
     // ---- frame reconstruction in coding order; device planes of every decoded frame are kept for references ------
     struct DevFrame { void* plane[3] = {nullptr, nullptr, nullptr}; int h = 0, w = 0, ch = 0, cw = 0, bitdepth = 0, fdt = 0; bool seen = false; Block own; };
     std::vector<DevFrame> dev(n_frames);  // by display index
@@ -1517,6 +1737,7 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
     }
     // every display index must have been produced (a gap would leave a frame without planes)
     for (int i = 0; i < n_frames && rc >= 0; ++i) if (!dev[i].seen) rc = CCD_ERR_VALUE;
+    if (timing) { (void)hipStreamSynchronize(nullptr); mark("reconstructed"); }
     // ---- all planes as u16 in one device block -> one pinned host block -> the caller (one copy, one wait) -------------
     Block wide;
     Block* host = nullptr;
@@ -1541,8 +1762,10 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
                                                           : hipMemcpyAsync(dst, dev[i].plane[p], px * 2, hipMemcpyDeviceToDevice, nullptr);
                 if (e != hipSuccess) rc = CCD_ERR_HIP;
             }
+        if (timing) { (void)hipStreamSynchronize(nullptr); mark("planes widened"); }
         if (rc >= 0 && (hipMemcpyAsync(host->p, wide.p, total, hipMemcpyDeviceToHost, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess))
             rc = CCD_ERR_HIP;
+        mark("planes on the host");
         if (rc >= 0) {
             v->n_frames = n_frames;
             v->frames[n_frames].plane[0] = reinterpret_cast<uint16_t*>(host);  // hidden: the block every plane points into (ccd_video_free)
@@ -1564,6 +1787,7 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
     for (auto& d : dev) d.own.drop();
     tmp.drop(); wide.drop();
     ccd_batch_destroy(b);
+    mark("batch destroyed");
     return rc < 0 ? rc : CCD_OK;
 }
 

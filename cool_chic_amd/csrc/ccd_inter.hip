@@ -124,6 +124,52 @@ __device__ __forceinline__ void ic_warp_pixel(const float* __restrict__ ref, int
     }
 }
 
+// The same with a compile-time tap count (r06): the runtime-sized version keeps cx / cy / xs in scratch memory (dynamic indexing
+// of per-thread arrays) and spent 0.5 ms per 1080p frame there - ccd_decode_video's 31 inter frames were 21 ms of a 190 ms call
+// (profiles/r06/gop_timing_before.txt).  Same operations in the same order: bit-identical.
+template <int NT>
+__device__ __forceinline__ void ic_coeffs_t(float s, float (&coef)[NT]) {
+    const float pi_f = 3.14159265358979323846f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const float d = s - static_cast<float>(j - NT / 2 + 1);
+        float sn, unused_c, unused_s, win;
+        ic_sincos(pi_f * d / static_cast<float>(NT), &unused_s, &win);
+        float snc = 1.0f;
+        if (d != 0.0f) { const float a = pi_f * d; ic_sincos(a, &sn, &unused_c); snc = sn / a; }
+        coef[j] = win * snc;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void ic_warp_pixel_t(const float* __restrict__ ref, int H, int W, int gx, int gy, float fx, float fy, int y, int x, float out[3]) {
+    const float rxf = floorf(fx), ryf = floorf(fy);
+    const float sx = fx - rxf, sy = fy - ryf;
+    const int rx = static_cast<int>(rxf), ry = static_cast<int>(ryf);
+    float cx[NT], cy[NT];
+    ic_coeffs_t<NT>(sx, cx);
+    ic_coeffs_t<NT>(sy, cy);
+    constexpr int lo = -(NT / 2) + 1;
+    const size_t plane = static_cast<size_t>(H) * W;
+    int xs[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) xs[j] = ic_clamp(ic_clamp(x + lo + j + rx, 0, W - 1) + gx, 0, W - 1);
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int yy = ic_clamp(ic_clamp(y + lo + i + ry, 0, H - 1) + gy, 0, H - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {  // (per channel the rows still accumulate in ascending order: the same chain as above)
+            const float* row = ref + c * plane + static_cast<size_t>(yy) * W;
+            float line = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) line = __fmaf_rn(row[xs[j]], cx[j], line);
+            acc[c] = __fmaf_rn(line, cy[i], acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = acc[c];
+}
+
 // ---- warp_filter_size 2 / 4: the Warper's native path = F.grid_sample(bilinear | bicubic, border, align_corners=True)
 // (warp.py:92-116, 325-343).  Same float32 operation sequence as oracle/cc_oracle.c section 11 (the canon of the
 // reference run: fused linspace, plain weight products + fma accumulation for bilinear, the mixed plain / fused
@@ -211,6 +257,7 @@ struct InterParams {
     int gflow[4];
 };
 
+template <int NT>  // 0: run-time tap count (any even size, and the native 2- / 4-tap paths); 8: the sinc-8 warp of every preset
 __global__ __launch_bounds__(256) void inter_recon_kernel(InterParams p) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -219,13 +266,15 @@ __global__ __launch_bounds__(256) void inter_recon_kernel(InterParams p) {
     float a = p.residue[3 * plane + i] + 0.5f;
     a = a < 0.0f ? 0.0f : (a > 1.0f ? 1.0f : a);
     float w0[3], pred[3];
-    if (p.n_taps < 6) ic_warp_pixel_native(p.ref0, p.H, p.W, p.gflow[0], p.gflow[1], p.n_taps, p.motion[i], p.motion[plane + i], y, x, w0);
+    if constexpr (NT > 0) ic_warp_pixel_t<NT>(p.ref0, p.H, p.W, p.gflow[0], p.gflow[1], p.motion[i], p.motion[plane + i], y, x, w0);
+    else if (p.n_taps < 6) ic_warp_pixel_native(p.ref0, p.H, p.W, p.gflow[0], p.gflow[1], p.n_taps, p.motion[i], p.motion[plane + i], y, x, w0);
     else ic_warp_pixel(p.ref0, p.H, p.W, p.gflow[0], p.gflow[1], p.n_taps, p.motion[i], p.motion[plane + i], y, x, w0);
     if (p.frame_type == 2) {
         float b = p.residue[4 * plane + i] + 0.5f;
         b = b < 0.0f ? 0.0f : (b > 1.0f ? 1.0f : b);
         float w1[3];
-        if (p.n_taps < 6) ic_warp_pixel_native(p.ref1, p.H, p.W, p.gflow[2], p.gflow[3], p.n_taps, p.motion[2 * plane + i], p.motion[3 * plane + i], y, x, w1);
+        if constexpr (NT > 0) ic_warp_pixel_t<NT>(p.ref1, p.H, p.W, p.gflow[2], p.gflow[3], p.motion[2 * plane + i], p.motion[3 * plane + i], y, x, w1);
+        else if (p.n_taps < 6) ic_warp_pixel_native(p.ref1, p.H, p.W, p.gflow[2], p.gflow[3], p.n_taps, p.motion[2 * plane + i], p.motion[3 * plane + i], y, x, w1);
         else ic_warp_pixel(p.ref1, p.H, p.W, p.gflow[2], p.gflow[3], p.n_taps, p.motion[2 * plane + i], p.motion[3 * plane + i], y, x, w1);
 #pragma unroll
         for (int c = 0; c < 3; ++c) { const float t0 = b * w0[c], t1 = (1.0f - b) * w1[c]; pred[c] = t0 + t1; }
@@ -244,7 +293,18 @@ hipError_t launch_inter_recon(int frame_type, int h, int w, int n_taps, const in
     p.frame_type = frame_type; p.H = h; p.W = w; p.n_taps = n_taps;
     for (int i = 0; i < 4; ++i) p.gflow[i] = gflow[i];
     dim3 grid((w + 63) / 64, (h + 3) / 4);
-    hipLaunchKernelGGL(inter_recon_kernel, grid, dim3(256), 0, stream, p);
+    if (n_taps == 8) hipLaunchKernelGGL(inter_recon_kernel<8>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(inter_recon_kernel<0>, grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// ---- a kernel that only takes time: ccd_api.cpp measures with it which of the library's side streams run concurrently
+__global__ void spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    while (__builtin_amdgcn_s_memtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+hipError_t launch_spin(unsigned long long ticks, hipStream_t stream) {
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, stream, ticks);
     return hipGetLastError();
 }
 

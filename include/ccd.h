@@ -142,7 +142,12 @@ int ccd_batch_header(const ccd_batch* b, int slot, ccd_cc_header* h);
  * anyway.  A caller that makes `stream` wait for other work (e.g. the decode of the batch before) calls this first, so that
  * the copy is not queued behind that wait. */
 int ccd_batch_prepare(ccd_batch* b, void* stream);
-/* Enqueues the whole decode of every slot on `stream` (asynchronous). */
+/* Enqueues the whole decode of every slot on `stream` (asynchronous).  The entropy launches of a batch (one per kernel
+ * instantiation and chain group: slots grouped by the expected length of their serial chains) fork over device-owned side
+ * streams; each is followed on its own stream by the float-path launches of ITS frames, and everything joins on `stream`
+ * before the call's remaining launches - so whatever is enqueued on `stream` afterwards sees every slot decoded
+ * (CCD_OPT_OVERLAP = 0: float stages only behind the join, as three ccd_batch_run_stage calls would do).
+ * ccd_batch_prepare and ccd_batch_run[_stage] may use different streams: a run orders itself behind the tables' copy. */
 int ccd_batch_run(ccd_batch* b, void* stream);
 /* Enqueue only one stage (profiling / tests): 0 entropy, 1 upsampling, 2 synthesis(+integer planes). */
 int ccd_batch_run_stage(ccd_batch* b, void* stream, int stage);
@@ -157,6 +162,14 @@ int ccd_batch_slot_status(const ccd_batch* b, int slot);
  * -DCCD_PIPE_PROFILE (which also reuses [36] and [37]).
  * `out64` receives 64 words. */
 int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64);
+/* How many of the library's side streams on `device` were MEASURED to run kernels concurrently (1 .. 4; once per process, ~10 ms
+ * at the first call or the first ccd_batch_create): HIP multiplexes streams onto a few hardware queues, and launches on streams
+ * that share one run one after the other.  The entropy launches of a batch that should overlap are put on these streams only,
+ * and a batch is never split into more launches than that (environment: CCD_SIDE_STREAMS=k skips the measurement). */
+int ccd_concurrent_streams(int device);
+/* Entropy launches per run of the batch as its launch tables were last built (ccd_batch_prepare / the first run after an add):
+ * one per kernel instantiation in use and chain group (see ccd_batch_run); 0 before the tables exist. */
+int ccd_batch_entropy_launches(const ccd_batch* b);
 /* Which kernels serve this slot: bit 0 = pipelined entropy kernel (else the generic int64 one),
  * bit 1 = fused synthesis kernel (else one launch per layer), bit 2 = the whole float path (upsampling +
  * synthesis + integer samples) in one kernel, ccd_fused.hip, bit 3 = the ARM's layers evaluated on the matrix cores
@@ -191,8 +204,12 @@ int ccd_batch_slot_kernels(const ccd_batch* b, int slot);
  *                       drive ordinary streams through the redo; results are identical bit for bit.
  *                       ccd_batch_slot_stats word [39] counts the redone pixels; word [37] counts the batches the
  *                       pipelined kernel's decoder took part by part (a producer task at a time, because only the first
- *                       part's tables were there when it looked: DESIGN.md 4.1). */
-enum { CCD_OPT_FUSED_DEC = 1, CCD_OPT_KEEP_FLOAT = 2, CCD_OPT_MFMA_ARM = 3, CCD_OPT_RANGE_BITS = 4 };
+ *                       part's tables were there when it looked: DESIGN.md 4.1).
+ *   CCD_OPT_OVERLAP     1 (default): ccd_batch_run overlaps the float path of the streams that finish early with the longest
+ *                       entropy chains (chain groups, see ccd_batch_run); 0: one entropy launch per kernel instantiation and
+ *                       every float launch behind the join.  Results are identical bit for bit (A/B, tests).  Environment:
+ *                       CCD_OVERLAP=0. */
+enum { CCD_OPT_FUSED_DEC = 1, CCD_OPT_KEEP_FLOAT = 2, CCD_OPT_MFMA_ARM = 3, CCD_OPT_RANGE_BITS = 4, CCD_OPT_OVERLAP = 5 };
 int ccd_batch_set_option(ccd_batch* b, int option, int value);
 
 /* Device pointers of a slot's results (valid until the batch is destroyed / re-run): */
@@ -221,7 +238,8 @@ int ccd_batch_copy_planes_async(ccd_batch* b, int first_slot, int n_slots, void*
  *
  * Threading and global state.  Per device and for the life of the process the library keeps: that block cache, the two
  * Laplace tables, ONE upload stream and eight side streams (entropy launches of one batch that need different kernel
- * instantiations fork onto them and join the caller's stream again).  All of it is created under a lock; the fork / join
+ * instantiations - or hold streams of very different lengths - fork onto those of them that were measured to run concurrently,
+ * ccd_concurrent_streams, and join the caller's stream again).  All of it is created under a lock; the fork / join
  * events belong to the batch.  Different batches may be driven from different host threads on one device; ONE batch is not
  * thread-safe.  ccd_batch_destroy drains every stream the caller passed to ccd_batch_run[_stage], ccd_batch_wait and
  * ccd_batch_copy_* before the batch's blocks return to the cache; work the caller enqueued on OTHER streams that reads

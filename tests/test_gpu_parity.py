@@ -654,6 +654,109 @@ def test_repeated_runs_are_identical(gpu, oracle):
         b.close()
 
 
+def test_overlapped_run_equals_staged_run(gpu, oracle):
+    """ccd_batch_run overlaps the float path of the streams that finish early with the longest entropy chains (r06: chain groups -
+    the slots of a kernel instantiation split by expected chain length, each group's pyramid + fused launches on the group's own
+    stream, one join).  Same bits as the float stages behind the join (overlap=False), as three ccd_batch_run_stage calls, and
+    after switching the option on a live batch - for a batch that mixes picture sizes (three chain groups), kernel
+    instantiations, common randomness (its fused launch stays behind the join) and a final resize; prepare() on one stream and
+    run() on another (the run orders itself behind the tables' copy)."""
+    import hashlib
+
+    import torch
+
+    from cool_chic_amd import writer
+
+    mixed = []  # several kernel instantiations (each its own launch), common randomness, a final resize
+    for name in ["kodim14", "rgb192", "cr192", "bicubic190", "kodim14", "mop192", "odd191x127", "rgb192"]:
+        bs, _, _ = load_golden(name)
+        fh, ccs = oracle.split_stream(bs)[1][0]
+        mixed.append((ccs[0], fh.bitdepth, fh.frame_data_type))
+    # ONE instantiation, three chain groups: kodim14 twice, a slightly smaller and a half-size picture of the same network
+    # (expected chains within 3 % / within 20 % / below 80 % of the longest)
+    bs, _, _ = load_golden("kodim14")
+    (fh, ccs), = oracle.split_stream(bs)[1]
+    donor = writer.parse_cc_header(ccs[0][0])
+    b0 = _decode(gpu, ccs[:1], fh.bitdepth, fh.frame_data_type)
+    lats = [b0.latent(0, g) for g in range(donor.n_grids)]
+    b0.close()
+    sized = [(ccs[0], fh.bitdepth, fh.frame_data_type)] * 2
+    for (h, w) in [(480, 704), (256, 384)]:
+        arch = writer.derive_arch(donor, img_size=(h, w))
+        st = writer.encode_stream(writer.cc_header_bytes(arch), ccs[0][1], [np.ascontiguousarray(a[: arch.grid_h[g], : arch.grid_w[g]]) for g, a in enumerate(lats)],
+                                  bitdepth=fh.bitdepth, frame_data_type=fh.frame_data_type)
+        sized.append((oracle.split_stream(st)[1][0][1][0], fh.bitdepth, fh.frame_data_type))
+    from cool_chic_amd._lib import lib
+    n_conc = lib().ccd_concurrent_streams(0)
+    assert 1 <= n_conc <= 4
+    _overlap_checks(gpu, sized, min(3, n_conc))   # one instantiation in three chain groups (as many as streams really run at once)
+    _overlap_checks(gpu, mixed, None)
+
+
+def _overlap_checks(gpu, triples, want_launches):
+    import hashlib
+
+    import torch
+
+    def digest(b):
+        h = hashlib.sha256()
+        for s in range(len(triples)):
+            for g in range(b.header(s).n_grids):
+                h.update(np.ascontiguousarray(b.latent(s, g)).tobytes())
+            for p in b.planes(s):
+                h.update(np.ascontiguousarray(p).tobytes())
+            h.update(np.ascontiguousarray(b.output(s)).tobytes())
+        return h.hexdigest()
+
+    def fresh(**opts):
+        b = gpu(0, **opts)
+        for (hdr, nn, lat), bd, fdt in triples:
+            b.add(hdr, nn, lat, bd, fdt)
+        return b
+
+    ref = None
+    b = fresh(overlap=False)
+    try:
+        b.run(); b.wait()
+        ref = digest(b)
+        n_inst = b.entropy_launches()
+        assert want_launches is None or n_inst == 1
+        for stage in range(3):
+            b.run(stage=stage)
+        b.wait()
+        assert digest(b) == ref, "staged run differs"
+    finally:
+        b.close()
+    b = fresh()
+    try:
+        for it in range(6):
+            b.run(); b.wait()
+            assert digest(b) == ref, f"overlapped run {it} differs from the float stages behind the join"
+        assert b.entropy_launches() == (want_launches or n_inst), (b.entropy_launches(), n_inst)
+        for stage in range(3):  # the staged entry points on the tables of an overlapping batch (more, smaller launches)
+            b.run(stage=stage)
+        b.wait()
+        assert digest(b) == ref
+        from cool_chic_amd._lib import check, lib
+        check(lib().ccd_batch_set_option(b._h, b.OPT_OVERLAP, 0), "set_option")  # live switch: the tables are rebuilt
+        b.run(); b.wait()
+        assert digest(b) == ref
+        check(lib().ccd_batch_set_option(b._h, b.OPT_OVERLAP, 1), "set_option")
+        b.run(); b.wait()
+        assert digest(b) == ref
+    finally:
+        b.close()
+    # prepare on one stream, run on another: no explicit ordering by the caller
+    s1, s2 = torch.cuda.Stream(device=0), torch.cuda.Stream(device=0)
+    b = fresh()
+    try:
+        b.prepare(s1.cuda_stream)
+        b.run(s2.cuda_stream); b.wait(s2.cuda_stream)
+        assert digest(b) == ref
+    finally:
+        b.close()
+
+
 def test_fuzzed_streams_never_hang_and_match_the_oracle(gpu, oracle):
     """Seeded mutations of real streams - bit flips in the latent payload, in the network payload and in the cool-chic
     header, truncated payloads - decoded by the device path and by the oracle: same verdict (both reject, or both
@@ -1009,7 +1112,21 @@ def _nccl_one_rank_worker(port, golden, q):
         res["gather16_fixed_ok"] = bool(g16(p16)[0].cpu().numpy().tobytes() == b"".join(host))
         b.close()
         # (4) the sharded GOP entry point with an initialised nccl group (one rank owns every frame: no send / recv)
-        frames = decode_video_sharded(os.path.join(golden, "vid5.cool"), device=0)
+        # r06: owner == every consumer, so run_sharded_gop must not issue a single point-to-point call (counted)
+        p2p = {"send": 0, "recv": 0}
+        real_send, real_recv = dist.send, dist.recv
+        def _count_send(*a, **k):
+            p2p["send"] += 1
+            return real_send(*a, **k)
+        def _count_recv(*a, **k):
+            p2p["recv"] += 1
+            return real_recv(*a, **k)
+        dist.send, dist.recv = _count_send, _count_recv
+        try:
+            frames = decode_video_sharded(os.path.join(golden, "vid5.cool"), device=0)
+        finally:
+            dist.send, dist.recv = real_send, real_recv
+        res["gop_p2p_calls"] = dict(p2p)
         res["gop"] = {k: [np.asarray(p) for p in fd.integer_planes()] for k, fd in frames.items()}
         # (5) bench.py's timed step with the gather inside, exactly as the driver's N > 1 run enqueues it
         streams, sizes = synth.kodak24()
@@ -1057,6 +1174,7 @@ def test_nccl_wire_path_on_one_rank(gpu, oracle):
     assert res["dtype16"] == "torch.uint16" and res["gather16_ok"] and res["gather16_fixed_ok"]
     bs, _, _ = load_golden("vid5")
     want = {str(fr["display_index"]): fr["planes"] for fr in oracle.decode_video(bs)}
+    assert res["gop_p2p_calls"] == {"send": 0, "recv": 0}, res["gop_p2p_calls"]
     assert sorted(res["gop"]) == sorted(want)
     for k in want:
         for p, w in zip(res["gop"][k], want[k]):
