@@ -35,10 +35,15 @@ def _flags():
     return flags
 
 
+LAST_BUILD = {"mode": "not run", "compiled": []}  # what the last build_lib() did (printed by __graft_entry__.build)
+
+
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 ... -> cool_chic_amd/libccd.so (cross-compiles without a GPU).
     One object per source (compiled concurrently, rebuilt only when stale), then one link."""
+    LAST_BUILD["compiled"] = []
     if not force and not is_stale():
+        LAST_BUILD["mode"] = "up to date (prebuilt libccd.so newer than every source: nothing compiled)"
         return LIB
     from concurrent.futures import ThreadPoolExecutor
 
@@ -55,6 +60,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        LAST_BUILD["compiled"].append(src)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
@@ -63,6 +69,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    LAST_BUILD["mode"] = "compiled %d of %d sources with hipcc --offload-arch=gfx950, linked" % (len(LAST_BUILD["compiled"]), len(SOURCES))
     return LIB
 
 
@@ -89,12 +96,22 @@ def build_variant(name: str, extra_flags: str) -> str:
     return out
 
 
-def clean_variants(keep=()) -> list:
-    """Removes the variant libraries (libccd_<name>.so) and object trees (csrc/_obj_<name>) that tools/ built with
-    build_variant(), except the names in `keep`.  They are git-ignored but travel to the GPU box with every push (tens of MB),
-    and a stale one selected through CCD_LIB would be timed in place of the product.  Returns what was removed."""
+def list_variants(root=None) -> list:
+    """Variant libraries (libccd_<name>.so) and object trees (csrc/_obj_<name>) that tools/ built with build_variant()."""
     import glob
 
+    root = root or _HERE
+    return sorted(glob.glob(os.path.join(root, "libccd_*.so")) + [p for p in glob.glob(os.path.join(root, "csrc", "_obj_*")) if os.path.isdir(p)])
+
+
+def clean_variants(keep=(), root=None) -> list:
+    """Removes the variant libraries (libccd_<name>.so) and object trees (csrc/_obj_<name>) that tools/ built with
+    build_variant(), except the names in `keep`.  They are git-ignored but travel to the GPU box with every push (tens of MB),
+    and a stale one selected through CCD_LIB would be timed in place of the product.  Returns what was removed.
+    `root`: the package directory (tests point it at a scratch copy: the real one may hold variants somebody is about to use)."""
+    import glob
+
+    _HERE = root or globals()["_HERE"]
     gone = []
     for path in glob.glob(os.path.join(_HERE, "libccd_*.so")):
         if os.path.basename(path)[len("libccd_"):-len(".so")] not in keep:

@@ -971,10 +971,32 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
         // as many launches as streams really run at once (DeviceShared::n_conc, measured), shared between the instantiations
         int n_conc = 1;
         { DeviceShared* shd = nullptr; if (device_shared(b->device, &shd) >= 0) n_conc = shd->n_conc; }
-        const int max_cg = !b->opt_overlap ? 1 : std::max(1, std::min(3, n_conc / std::max<int>(1, static_cast<int>(insts.size()))));
-        for (int i = 0; i < n; ++i) {
-            const int c = est[i] >= 0.97 * est_max ? 0 : (est[i] >= 0.80 * est_max ? 1 : 2);
-            cg_of[i] = std::min(c, max_cg - 1);
+        int max_cg = !b->opt_overlap ? 1 : std::max(1, std::min(3, n_conc / std::max<int>(1, static_cast<int>(insts.size()))));
+        // ... and only while every workgroup still finds a CU at once.  A stream's workgroup owns a CU (139 KB of LDS), and the
+        // hardware deals the workgroups of ONE launch out to the 8 XCDs round-robin: two launches of 63 + 193 workgroups put 8 + 25
+        // on one 32-CU XCD, the 33rd waits for a whole chain - 68 ms instead of 36.6 (profiles/r06/diag_wide.txt; a single launch of
+        // 256 deals 32 to each).  So the split must leave room on the fullest XCD: sum over launches of ceil(n / 8) <= CUs / 8.
+        int n_cu = 256;
+        { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
+        constexpr int kXcd = 8;  // gfx950
+        for (; max_cg >= 1; --max_cg) {
+            for (int i = 0; i < n; ++i) {
+                const int c = est[i] >= 0.97 * est_max ? 0 : (est[i] >= 0.80 * est_max ? 1 : 2);
+                cg_of[i] = std::min(c, max_cg - 1);
+            }
+            if (max_cg == 1) break;
+            int per_xcd = 0;
+            for (const auto& key : insts)
+                for (int cg = 0; cg < max_cg; ++cg) {
+                    int cnt = 0;
+                    for (int i = 0; i < n; ++i) {
+                        const Slot& sl = *b->slots[i];
+                        if (sl.use_pipe && cg_of[i] == cg && key == std::array<int, 3>{(sl.ep.dim + 3) / 4, sl.use_mfma ? 2 : (sl.use_dyn ? 1 : 0), sl.fixed_shape}) ++cnt;
+                    }
+                    per_xcd += (cnt + kXcd - 1) / kXcd;
+                }
+            per_xcd += (static_cast<int>(std::count_if(b->slots.begin(), b->slots.end(), [](const std::unique_ptr<Slot>& sp) { return !sp->use_pipe; })) + kXcd - 1) / kXcd;
+            if (per_xcd <= n_cu / kXcd) break;
         }
     }
     for (int nv = 1; nv <= 8; ++nv)
@@ -1685,23 +1707,71 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
     mark("launched");
     if (rc >= 0) rc = ccd_batch_wait(b, nullptr);
     mark("cool-chics decoded");
-    // ---- frame reconstruction in coding order; device planes of every decoded frame are kept for references ------
+    // ---- frame reconstruction in coding order; device planes of every decoded frame are kept for references.  r06: a frame's
+    // planes start their way to the host (u16 widening + one device -> host copy per frame on the library's upload stream, behind
+    // an event) as soon as the frame is reconstructed, while the following frames are still being warped: the 200 MB of a 33-frame
+    // 1080p GOP used to cross PCIe after the last frame (3.6 ms of a 190 ms call, profiles/r06/gop_timing_before.txt).
     struct DevFrame { void* plane[3] = {nullptr, nullptr, nullptr}; int h = 0, w = 0, ch = 0, cw = 0, bitdepth = 0, fdt = 0; bool seen = false; Block own; };
     std::vector<DevFrame> dev(n_frames);  // by display index
     Block tmp;  // two references and the result as 4:4:4 f32 planes, reused by every inter frame (one stream: ordered)
     size_t tmp_elems = 0;
+    // geometry of every frame is known from the headers: the host block and the u16 staging block are laid out up front
+    Block wide;
+    Block* host = nullptr;
+    std::vector<size_t> off(static_cast<size_t>(n_frames) * 3, 0);
+    size_t total = 0;
+    hipStream_t copy_st = b->up_stream;
+    hipEvent_t frame_done = nullptr;
+    if (rc >= 0) {
+        for (int f = 0; f < n_frames && rc >= 0; ++f) {  // sizes by display index
+            const ccd_frame_header& fh = fhs[f];
+            if (fh.display_index < 0 || fh.display_index >= n_frames) { rc = CCD_ERR_VALUE; break; }
+            DevFrame& d = dev[fh.display_index];
+            if (d.seen) { rc = CCD_ERR_VALUE; break; }  // two frames with one display index: the second would overwrite the first
+            d.seen = true;
+            const Slot& s0 = *b->slots[first_slot[f]];
+            d.h = s0.hdr.img_size[0]; d.w = s0.hdr.img_size[1]; d.bitdepth = fh.bitdepth; d.fdt = fh.frame_data_type;
+            // 4:2:0 needs even sizes: F.avg_pool2d(2) drops the odd row / column and write_yuv's chroma planes are h/2 x w/2,
+            // while the reference's 4:4:4 round trip of such a frame (yuv.py:303-316) no longer matches the luma size
+            if (fh.frame_data_type == 1 && ((d.h | d.w) & 1)) { rc = CCD_ERR_VALUE; break; }
+            d.ch = fh.frame_data_type == 1 ? d.h / 2 : d.h; d.cw = fh.frame_data_type == 1 ? d.w / 2 : d.w;
+        }
+        // every display index must have been produced (a gap would leave a frame without planes)
+        for (int i = 0; i < n_frames && rc >= 0; ++i) if (!dev[i].seen) rc = CCD_ERR_VALUE;
+    }
+    if (rc >= 0) {
+        for (int i = 0; i < n_frames; ++i)
+            for (int p = 0; p < 3; ++p) {
+                off[static_cast<size_t>(i) * 3 + p] = total;
+                total += ((p == 0 ? static_cast<size_t>(dev[i].h) * dev[i].w : static_cast<size_t>(dev[i].ch) * dev[i].cw) * 2 + 63) & ~size_t{63};
+            }
+        host = new (std::nothrow) Block();
+        v->frames = static_cast<ccd_frame*>(std::calloc(static_cast<size_t>(n_frames) + 1, sizeof(ccd_frame)));
+        if (!host || !v->frames || !wide.get(device, BlockPool::kDevice, std::max<size_t>(total, 64)) ||
+            !host->get(device, BlockPool::kPinned, std::max<size_t>(total, 64)))
+            rc = CCD_ERR_NOMEM;
+        if (rc >= 0 && hipEventCreateWithFlags(&frame_done, hipEventDisableTiming) != hipSuccess) rc = CCD_ERR_HIP;
+    }
+    // planes of display index di: widened to u16 and copied to the host on the copy stream, behind everything enqueued so far
+    auto send_frame = [&](int di) -> int {
+        const DevFrame& d = dev[di];
+        HIP_TRY(hipEventRecord(frame_done, nullptr));
+        HIP_TRY(hipStreamWaitEvent(copy_st, frame_done, 0));
+        for (int p = 0; p < 3; ++p) {
+            const size_t px = p == 0 ? static_cast<size_t>(d.h) * d.w : static_cast<size_t>(d.ch) * d.cw;
+            uint16_t* dst = reinterpret_cast<uint16_t*>(wide.as<char>() + off[static_cast<size_t>(di) * 3 + p]);
+            const hipError_t e = d.bitdepth == 8 ? launch_widen_u8(static_cast<const uint8_t*>(d.plane[p]), dst, px, copy_st)
+                                                 : hipMemcpyAsync(dst, d.plane[p], px * 2, hipMemcpyDeviceToDevice, copy_st);
+            if (e != hipSuccess) return CCD_ERR_HIP;
+        }
+        const size_t o0 = off[static_cast<size_t>(di) * 3], o1 = di + 1 < n_frames ? off[static_cast<size_t>(di + 1) * 3] : total;
+        HIP_TRY(hipMemcpyAsync(host->as<char>() + o0, wide.as<char>() + o0, o1 - o0, hipMemcpyDeviceToHost, copy_st));
+        return CCD_OK;
+    };
     for (int f = 0; f < n_frames && rc >= 0; ++f) {
         const ccd_frame_header& fh = fhs[f];
-        if (fh.display_index < 0 || fh.display_index >= n_frames) { rc = CCD_ERR_VALUE; break; }
         DevFrame& d = dev[fh.display_index];
-        if (d.seen) { rc = CCD_ERR_VALUE; break; }  // two frames with one display index: the second would overwrite the first
-        d.seen = true;
         const Slot& s0 = *b->slots[first_slot[f]];
-        d.h = s0.hdr.img_size[0]; d.w = s0.hdr.img_size[1]; d.bitdepth = fh.bitdepth; d.fdt = fh.frame_data_type;
-        // 4:2:0 needs even sizes: F.avg_pool2d(2) drops the odd row / column and write_yuv's chroma planes are h/2 x w/2,
-        // while the reference's 4:4:4 round trip of such a frame (yuv.py:303-316) no longer matches the luma size
-        if (fh.frame_data_type == 1 && ((d.h | d.w) & 1)) { rc = CCD_ERR_VALUE; break; }
-        d.ch = fh.frame_data_type == 1 ? d.h / 2 : d.h; d.cw = fh.frame_data_type == 1 ? d.w / 2 : d.w;
         if (fh.frame_type == 0) {
             if (s0.hdr.out_channels < 3) { rc = CCD_ERR_VALUE; break; }
             for (int p = 0; p < 3; ++p) d.plane[p] = s0.d_plane[p];
@@ -1734,55 +1804,29 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
             rc = inter_reconstruct_on(nullptr, tmp.as<float>(), fh.frame_type, d.h, d.w, d.bitdepth, d.fdt, s0.d_out, s1.d_out, refs[0],
                                       fh.frame_type == 2 ? refs[1] : nullptr, fh.global_flow, fh.warp_filter_size, d.plane);
         }
+        if (rc >= 0) rc = send_frame(fh.display_index);
     }
-    // every display index must have been produced (a gap would leave a frame without planes)
-    for (int i = 0; i < n_frames && rc >= 0; ++i) if (!dev[i].seen) rc = CCD_ERR_VALUE;
     if (timing) { (void)hipStreamSynchronize(nullptr); mark("reconstructed"); }
-    // ---- all planes as u16 in one device block -> one pinned host block -> the caller (one copy, one wait) -------------
-    Block wide;
-    Block* host = nullptr;
+    if (rc >= 0 && hipStreamSynchronize(copy_st) != hipSuccess) rc = CCD_ERR_HIP;
+    mark("planes on the host");
     if (rc >= 0) {
-        size_t total = 0;
-        std::vector<size_t> off(static_cast<size_t>(n_frames) * 3);
-        for (int i = 0; i < n_frames; ++i)
-            for (int p = 0; p < 3; ++p) {
-                off[static_cast<size_t>(i) * 3 + p] = total;
-                total += ((p == 0 ? static_cast<size_t>(dev[i].h) * dev[i].w : static_cast<size_t>(dev[i].ch) * dev[i].cw) * 2 + 63) & ~size_t{63};
-            }
-        host = new (std::nothrow) Block();
-        v->frames = static_cast<ccd_frame*>(std::calloc(static_cast<size_t>(n_frames) + 1, sizeof(ccd_frame)));
-        if (!host || !v->frames || !wide.get(device, BlockPool::kDevice, std::max<size_t>(total, 64)) ||
-            !host->get(device, BlockPool::kPinned, std::max<size_t>(total, 64)))
-            rc = CCD_ERR_NOMEM;
-        for (int i = 0; i < n_frames && rc >= 0; ++i)
-            for (int p = 0; p < 3 && rc >= 0; ++p) {
-                const size_t px = p == 0 ? static_cast<size_t>(dev[i].h) * dev[i].w : static_cast<size_t>(dev[i].ch) * dev[i].cw;
-                uint16_t* dst = reinterpret_cast<uint16_t*>(wide.as<char>() + off[static_cast<size_t>(i) * 3 + p]);
-                const hipError_t e = dev[i].bitdepth == 8 ? launch_widen_u8(static_cast<const uint8_t*>(dev[i].plane[p]), dst, px, nullptr)
-                                                          : hipMemcpyAsync(dst, dev[i].plane[p], px * 2, hipMemcpyDeviceToDevice, nullptr);
-                if (e != hipSuccess) rc = CCD_ERR_HIP;
-            }
-        if (timing) { (void)hipStreamSynchronize(nullptr); mark("planes widened"); }
-        if (rc >= 0 && (hipMemcpyAsync(host->p, wide.p, total, hipMemcpyDeviceToHost, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess))
-            rc = CCD_ERR_HIP;
-        mark("planes on the host");
-        if (rc >= 0) {
-            v->n_frames = n_frames;
-            v->frames[n_frames].plane[0] = reinterpret_cast<uint16_t*>(host);  // hidden: the block every plane points into (ccd_video_free)
-            for (int f = 0; f < n_frames; ++f) {
-                const int di = fhs[f].display_index;
-                const DevFrame& d = dev[di];
-                ccd_frame& fr = v->frames[di];
-                fr.display_index = di; fr.frame_type = fhs[f].frame_type; fr.frame_data_type = d.fdt; fr.bitdepth = d.bitdepth;
-                fr.h = d.h; fr.w = d.w; fr.ch = d.ch; fr.cw = d.cw;
-                for (int p = 0; p < 3; ++p) fr.plane[p] = reinterpret_cast<uint16_t*>(host->as<char>() + off[static_cast<size_t>(di) * 3 + p]);
-            }
-        } else {
-            if (host) { host->drop(); delete host; }
-            std::free(v->frames);
-            v->frames = nullptr; v->n_frames = 0;
+        v->n_frames = n_frames;
+        v->frames[n_frames].plane[0] = reinterpret_cast<uint16_t*>(host);  // hidden: the block every plane points into (ccd_video_free)
+        for (int f = 0; f < n_frames; ++f) {
+            const int di = fhs[f].display_index;
+            const DevFrame& d = dev[di];
+            ccd_frame& fr = v->frames[di];
+            fr.display_index = di; fr.frame_type = fhs[f].frame_type; fr.frame_data_type = d.fdt; fr.bitdepth = d.bitdepth;
+            fr.h = d.h; fr.w = d.w; fr.ch = d.ch; fr.cw = d.cw;
+            for (int p = 0; p < 3; ++p) fr.plane[p] = reinterpret_cast<uint16_t*>(host->as<char>() + off[static_cast<size_t>(di) * 3 + p]);
         }
+    } else {
+        if (host) { host->drop(); delete host; }
+        std::free(v->frames);
+        v->frames = nullptr; v->n_frames = 0;
     }
+    (void)hipStreamSynchronize(copy_st);
+    if (frame_done) (void)hipEventDestroy(frame_done);
     (void)hipStreamSynchronize(nullptr);  // nothing may still read the blocks that go back to the pool
     for (auto& d : dev) d.own.drop();
     tmp.drop(); wide.drop();

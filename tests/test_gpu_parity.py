@@ -492,6 +492,34 @@ def test_full_size_configs(gpu, oracle, name):
         b.close()
 
 
+def test_picture_wider_than_the_symbol_ring(gpu, oracle):
+    """A 7 680 x 256 picture (the format allows 16 383 columns, header.py:244-307): wider than the 5 060 columns the pipelined
+    entropy kernel's symbol ring holds, so the GENERIC entropy kernel serves it (slot_kernels bit 0 clear) while the float path
+    stays on the fused kernels.  Round trip of every grid and integer planes against the oracle."""
+    from cool_chic_amd import writer
+
+    bs, z, _ = load_golden("kodim14")
+    hdr, _, _ = oracle.split_stream(bs)[1][0][1][0]
+    donor = writer.parse_cc_header(hdr)
+    arch = writer.derive_arch(donor, img_size=(256, 7680))
+    nn = writer.encode_network(arch, writer.adapt_network(donor, z["cc0.nn_ints"], arch))
+    latents = writer.tile_latents([z[f"cc0.latent{g}"] for g in range(donor.n_grids)], donor, arch)
+    stream = writer.encode_stream(writer.cc_header_bytes(arch), nn, latents)
+    triple = oracle.split_stream(stream)[1][0][1][0]
+    b = _decode(gpu, [triple], 8, 0)
+    try:
+        assert b.slot_status(0) == 0
+        assert b.slot_kernels(0) & 1 == 0, "wider than the ring: the generic entropy kernel"
+        assert b.slot_kernels(0) & 4, "the float path does not depend on the width"
+        for g, a in enumerate(latents):
+            assert np.array_equal(b.latent(0, g), a), f"grid {g}"
+        want = oracle.decode_video(stream)[0]["planes"]
+        for p, w in zip(b.planes(0), want):
+            assert np.array_equal(p.astype(np.uint16), w)
+    finally:
+        b.close()
+
+
 def test_video_1080p_gop(gpu, oracle):
     """SURVEY 8d config 3 at full picture size (reduced GOP): the I/P/B/B/B structure, networks and headers of
     the reference-encoded `vid5` stream with its latents tiled to 1920x1080 4:2:0, re-written frame by frame.

@@ -283,6 +283,25 @@ def test_fixtures_reach_every_entropy_instantiation(oracle):
     assert {c[1] for c in sweep.values()} >= {7, 8}
 
 
+def test_symbol_ring_width_limit(oracle):
+    """The pipelined entropy kernel keeps the recent symbols of W / 10 + 6 picture rows in a 512-row LDS ring: pictures up to
+    5 069 columns (documented as 5 060) (include/ccd.h "envelope"); the format's 14-bit img_size allows 16 383 (header.py:244-307), and a
+    wider picture is served by the generic kernel (priced in bench.py's fallback_cliffs; GPU test
+    test_picture_wider_than_the_symbol_ring).  Host only: ccd_network_fits_fast_path at both sides of the limit."""
+    from cool_chic_amd import writer
+    from cool_chic_amd._lib import lib
+
+    bs, z, _ = load_golden("kodim14")
+    hdr, _, _ = oracle.split_stream(bs)[1][0][1][0]
+    donor = writer.parse_cc_header(hdr)
+    for w, want in ((5060, 1), (5069, 1), (5070, 0), (7680, 0), (16383, 0)):  # W / 10 + 6 <= 512 rows
+        arch = writer.derive_arch(donor, img_size=(64, w))
+        nn = writer.encode_network(arch, writer.adapt_network(donor, z["cc0.nn_ints"], arch))
+        h = writer.cc_header_bytes(arch)
+        assert lib().ccd_network_fits_fast_path(h, len(h), nn, len(nn)) == want, w
+        assert lib().ccd_network_kernel_class(h, len(h), nn, len(nn)) & 1 == want, w
+
+
 @pytest.mark.parametrize("name", IMAGE_STREAMS + VIDEO_STREAMS)
 def test_every_reference_network_fits_the_pipelined_kernel(oracle, name):
     """ccd_network_fits_fast_path (host only): the static envelope of the pipelined entropy kernel is on the WEIGHTS (int32);
@@ -430,20 +449,17 @@ def test_bench_refuses_a_variant_library_and_build_cleans_variants(tmp_path):
     env = dict(os.environ, CCD_LIB=os.path.join(ROOT, "cool_chic_amd", "libccd_does_not_exist.so"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "CCD_LIB" in r.stderr and "--allow-variant" in r.stderr
-    here = os.path.dirname(_build.LIB)
+    # on a scratch copy of the package layout: the real directory may hold variants somebody is about to use (r05 advisor)
+    here = str(tmp_path)
+    os.makedirs(os.path.join(here, "csrc", "_obj"))
+    open(os.path.join(here, "libccd.so"), "wb").close()
     lib_a, lib_b = os.path.join(here, "libccd_tmpa.so"), os.path.join(here, "libccd_tmpb.so")
     obj_a = os.path.join(here, "csrc", "_obj_tmpa")
-    try:
-        for f in (lib_a, lib_b):
-            open(f, "wb").close()
-        os.makedirs(obj_a, exist_ok=True)
-        gone = _build.clean_variants(keep=("tmpb",))
-        assert lib_a in gone and obj_a in gone and lib_b not in gone
-        assert not os.path.exists(lib_a) and not os.path.exists(obj_a) and os.path.exists(lib_b)
-        assert os.path.exists(_build.LIB) and os.path.isdir(os.path.join(here, "csrc", "_obj"))  # the product itself is never touched
-    finally:
-        for f in (lib_a, lib_b):
-            if os.path.exists(f):
-                os.remove(f)
-        if os.path.isdir(obj_a):
-            os.rmdir(obj_a)
+    for f in (lib_a, lib_b):
+        open(f, "wb").close()
+    os.makedirs(obj_a, exist_ok=True)
+    assert set(_build.list_variants(root=here)) == {lib_a, lib_b, obj_a}
+    gone = _build.clean_variants(keep=("tmpb",), root=here)
+    assert lib_a in gone and obj_a in gone and lib_b not in gone
+    assert not os.path.exists(lib_a) and not os.path.exists(obj_a) and os.path.exists(lib_b)
+    assert os.path.exists(os.path.join(here, "libccd.so")) and os.path.isdir(os.path.join(here, "csrc", "_obj"))  # the product itself is never touched
