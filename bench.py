@@ -197,11 +197,18 @@ def measure_traffic_live(timeout_s: float = 150.0):
                         if row["Counter_Name"] == counter:
                             vals[row["Kernel_Name"]].append(float(row["Counter_Value"]) * 1024.0 * factor)
             for short, sub in names.items():
-                # every kernel of the step whose name holds `sub` (the fused float path is two launches: pyramid + tiles):
-                # mean over the launches of each (first dropped), summed over the kernels
-                tot = [sum(v[1:]) / len(v[1:]) for k, v in vals.items() if sub in k and len(v) > 1]
+                # every kernel of the step whose name holds `sub` (the fused float path is two launches: pyramid + tiles; r06: per
+                # chain group): mean over the launches of each (first dropped) x its launches per step, summed over the kernels
+                key = "fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"
+                tot = 0.0
+                for k, v in vals.items():
+                    if sub in k and len(v) > 1:
+                        per_step = max(1, round(len(v) / 3))  # prof_workload runs 1 warm-up + 2 timed steps
+                        kb = sum(v[per_step:]) / max(1, len(v[per_step:])) * per_step
+                        tot += kb
+                        out.setdefault(short, {}).setdefault("per_kernel", {}).setdefault(k.replace("ccd::(anonymous namespace)::", "")[:70], {})[key] = kb
                 if tot:
-                    out.setdefault(short, {})["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = sum(tot)
+                    out.setdefault(short, {})[key] = tot
     return out if all("fetch_bytes" in v and "write_bytes" in v for v in out.values()) and out else {}
 
 
@@ -334,6 +341,7 @@ def timed_set(mine, world, rank, local_rank, backend, red_dev, steps, warmup, fo
     batch = DecodeBatch(local_rank)
     for hdr, nn, lat, _ in mine:
         batch.add(hdr, nn, lat, 8, 0)
+    batch.time_launches()  # HIP events around every entropy launch ON THE STREAM IT RUNS ON (two records per launch): the roofline's ms_per_launch
     stream = torch.cuda.current_stream(local_rank)
     sh = stream.cuda_stream
     n = len(mine)
@@ -374,7 +382,8 @@ def timed_set(mine, world, rank, local_rank, backend, red_dev, steps, warmup, fo
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     batch.wait(sh)
-    return {"dt": dt, "batch": batch, "gathered": gathered[0], "stream": stream, "sh": sh}
+    return {"dt": dt, "batch": batch, "gathered": gathered[0], "stream": stream, "sh": sh,
+            "launch_ms": batch.launch_ms() if n else []}  # the entropy launches of the LAST TIMED step
 
 
 def timed_from_bytes(mine, world, rank, local_rank, backend, red_dev, steps, warmup, force_gather=False):
@@ -585,6 +594,7 @@ def main():
     # to rank 0's HBM); its batch serves the per-stage timing below
     run = timed_set(mine, world, rank, local_rank, args.backend, red_dev, args.steps, args.warmup)
     dt, batch, stream, sh = run["dt"], run["batch"], run["stream"], run["sh"]
+    launch_ms = run["launch_ms"]
     gathered = [run["gathered"]]
     # ---- beside it, same steps / warmup, all ranks: from the .cool BYTES in host memory to integer planes in pinned host memory,
     # two sets in flight (`from_bytes`: what a caller who holds files gets; the gap to `value` is what does not hide behind the decode)
@@ -670,8 +680,13 @@ def main():
             k = pmc.get(name, {})
             return k["fetch_bytes"] + k["write_bytes"] if "fetch_bytes" in k and "write_bytes" in k else None
 
-        ent_bytes = n_payload + nsym  # payload in + one byte per symbol out
-        ent_ach = ent_bytes / (stage_ms["entropy"] / 1e3) / 1e9
+        ent_bytes = n_payload + nsym  # payload in + one byte per symbol out, all streams of the step
+        # r06: a step's streams are decoded by SEVERAL concurrent launches of the kernel (chain groups on side streams): the roofline
+        # is per launch - algorithmic bytes of a launch's streams over that launch's duration, HIP events on its own stream inside
+        # the timed region (last timed step), mean over the step's launches (= what rocprofv3 --stats averages)
+        n_l = max(1, len(launch_ms))
+        ent_ms_launch = sum(m for m, _ in launch_ms) / n_l if launch_ms else stage_ms["entropy"]
+        ent_ach = ent_bytes / n_l / (ent_ms_launch / 1e3) / 1e9
         # fused float kernel: algorithmic bytes = int8 latents in + (4 C f32 +) C integer samples out; flops as executed by
         # the reference's 2-D kernels: synthesis 2 x 672 (HOP) + upsampling ~380 per pixel
         flop_px = 2.0 * 672 + 380.0
@@ -685,6 +700,7 @@ def main():
             "frac": flop_px * rank_px / ff_ms / 1e9 / FP32_PEAK_TFLOPS, "ms_per_launch": ff_ms,
             "algorithmic_gbs": ff_bytes / ff_ms / 1e6, "frac_of_hbm_peak": ff_bytes / ff_ms / 1e6 / HBM_PEAK_GBS,
             "algorithmic_bytes": ff_bytes, "traffic": traffic("decode_fused_kernel"),
+            "traffic_by_kernel": pmc.get("decode_fused_kernel", {}).get("per_kernel"),
             "note": "compute-bound by construction (%.1f B/px, ~%.0f flop/px): priced against the fp32 peak; exact fmaf chains on "
                     "v_mfma_f32_4x4x1 (bitwise the oracle's order)" % (ff_bytes / rank_px, flop_px)}]
         res = {
@@ -732,9 +748,11 @@ def main():
             "serial_chain_bound": {"achieved": nsym / (stage_ms["entropy"] / 1e3) / 1e6, "peak": n_frames * 2.4e9 / SYMBOL_FLOOR_TICKS / 1e6,
                                    "unit": "Msymbol/s", "frac": (nsym / (stage_ms["entropy"] / 1e3)) / (n_frames * 2.4e9 / SYMBOL_FLOOR_TICKS),
                                    "streams": n_frames, "ticks_per_symbol_floor": SYMBOL_FLOOR_TICKS},
-            "roofline": {"bound": "hbm", "kernel": f"entropy_pipe_kernel<5, false, false> ({n_frames} streams, one workgroup each)", "achieved": ent_ach,
+            "roofline": {"bound": "hbm", "kernel": f"entropy_pipe_kernel<5, false, false, ShapeFix<20, 3, 14>> ({n_frames} streams, one workgroup each, in {n_l} concurrent launches)", "achieved": ent_ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ent_ach / HBM_PEAK_GBS, "traffic": traffic("entropy_pipe_kernel"),
-                         "algorithmic_bytes": ent_bytes, "ms_per_launch": stage_ms["entropy"],
+                         "algorithmic_bytes": ent_bytes / n_l, "ms_per_launch": ent_ms_launch,
+                         "launches_per_step": [{"ms": m, "streams": k} for m, k in launch_ms],
+                         "stage_ms": stage_ms["entropy"],
                          "note": "latency-bound serial chain (one range decoder per stream): see entropy_msym_per_s, serial_chain_bound "
                                  "and DESIGN.md 4.1"},
             "roofline_float_stages": float_lines,

@@ -26,7 +26,7 @@ class DecodeBatch:
     enqueues kernels on `stream` (a hipStream_t handle, e.g. torch.cuda.current_stream().cuda_stream).
     """
 
-    OPT_FUSED_DEC, OPT_KEEP_FLOAT, OPT_MFMA_ARM, OPT_RANGE_BITS, OPT_OVERLAP = 1, 2, 3, 4, 5  # include/ccd.h
+    OPT_FUSED_DEC, OPT_KEEP_FLOAT, OPT_MFMA_ARM, OPT_RANGE_BITS, OPT_OVERLAP, OPT_TIME_LAUNCHES = 1, 2, 3, 4, 5, 6  # include/ccd.h
 
     def __init__(self, device: int = 0, fused_dec: Optional[bool] = None, keep_float: Optional[bool] = None,
                  mfma_arm: Optional[int] = None, range_bits: Optional[int] = None, overlap: Optional[bool] = None):
@@ -96,6 +96,17 @@ class DecodeBatch:
     def entropy_launches(self) -> int:
         """Entropy launches per run (kernel instantiations x chain groups) as the launch tables were last built."""
         return check(lib().ccd_batch_entropy_launches(self._h), "ccd_batch_entropy_launches")
+
+    def time_launches(self, on: bool = True):
+        """Timing events around every entropy launch (on the stream it runs on); launch_ms() reads the last run's."""
+        check(lib().ccd_batch_set_option(self._h, self.OPT_TIME_LAUNCHES, int(bool(on))), "ccd_batch_set_option")
+
+    def launch_ms(self):
+        """[(ms, streams)] of every entropy launch of the last run, longest expected chains first (needs time_launches())."""
+        ms = (C.c_float * 32)()
+        ns = (C.c_int * 32)()
+        n = check(lib().ccd_batch_launch_ms(self._h, ms, ns, 32), "ccd_batch_launch_ms")
+        return [(float(ms[i]), int(ns[i])) for i in range(n)]
 
     def wait(self, stream: int = 0):
         check(lib().ccd_batch_wait(self._h, C.c_void_p(stream or None)), "ccd_batch_wait")

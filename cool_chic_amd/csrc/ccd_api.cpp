@@ -299,6 +299,11 @@ struct ccd_batch {
     // cg: chain group - the slots of one kernel instantiation split by the expected length of their serial chains, so that the
     // float-path launches of the streams that finish early run while the longest chains are still decoding (ccd_batch_run)
     struct PipeGroup { int nv, mfma, dyn, shape, cg, first, n; size_t lds; double est; };
+    // CCD_OPT_TIME_LAUNCHES: timing events around every entropy launch, on the stream it runs on (bench.py's roofline: the launches
+    // of a step overlap on side streams, so events on the caller's stream only see the whole stage)
+    int opt_time_launches = 0;
+    std::vector<hipEvent_t> lt0, lt1;    // per entropy launch of the last run (launch order)
+    int n_timed = 0;
     int opt_overlap = 1;                 // CCD_OVERLAP=0 (environment; A/B and tests): one entropy launch per instantiation, float stages behind the join
     std::vector<PipeGroup> pipe_groups;
     float* d_scale_table = nullptr;
@@ -482,6 +487,8 @@ void ccd_batch_destroy(ccd_batch* b) {
     (void)b->drain_streams();  // launches and copies on EVERY stream the caller used with this batch
     if (b->fork) (void)hipEventDestroy(b->fork);
     if (b->params_up) (void)hipEventDestroy(b->params_up);
+    for (hipEvent_t e : b->lt0) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : b->lt1) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : b->side_done) if (e) (void)hipEventDestroy(e);
     for (auto& s : b->slots) { s->arena.release(); s->staging.drop(); }
     b->tables.drop(); b->tables_staging.drop(); b->status_host.drop();
@@ -930,6 +937,12 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
     return static_cast<int>(b->slots.size()) - 1;
 }
 
+// XCD-aware order of one launch's work list (r06).  The hardware deals the workgroups of a launch out to the 8 XCDs round-robin
+// (workgroup i -> XCD i mod 8, tools/ubench/queues.hip prints it) and every XCD has its own L2: with the work items in raster
+// order, neighbouring tiles - which share the halo rows / columns of the level-1 stack and the latent tile - always sat on
+// DIFFERENT XCDs and each fetched the shared cache lines from HBM for itself (main launch of the fused float path: 165 MB
+// fetched per 24 Kodak frames for ~70 MB of stack + latents, profiles/r05/kodak24_pmc_traffic.json).  Here item j of the natural
+// order goes to a workgroup of XCD x = the eighth of the list it lies in: every XCD walks ONE contiguous run of tiles.
 // Expected length of a slot's serial chain in decoder ticks (only the ORDER and rough ratios matter: it decides which streams
 // share an entropy launch).  Per grid ~120 ticks per symbol + ~1.8 k per wavefront step (latent.py:66-140: W + 10 (H - 1) steps):
 // profiles/r06/prof_grids_base.txt - a portrait Kodak stream comes out 1.09 x a landscape one (measured 1.06).
@@ -1052,6 +1065,18 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
     // fused float path: frames grouped by (levels, channels); a workgroup takes a run of `per_wg` tiles of one frame
     b->fdec_groups.clear();
     struct Work { int32_t frame, tile_first, tile_count, pad; };
+    const auto xcd_interleave = [](auto& work, size_t first, size_t n) {
+        using W = typename std::remove_reference<decltype(work)>::type::value_type;
+        constexpr size_t kXcd = 8;
+        if (n < 2 * kXcd || std::getenv("CCD_NO_XCD_ORDER")) return;
+        std::vector<W> nat(work.begin() + static_cast<std::ptrdiff_t>(first), work.begin() + static_cast<std::ptrdiff_t>(first + n));
+        size_t start = 0;
+        for (size_t x = 0; x < kXcd; ++x) {
+            const size_t cnt = (n - x + kXcd - 1) / kXcd;  // workgroups x, x + 8, ... of the launch
+            for (size_t k = 0; k < cnt; ++k) work[first + x + kXcd * k] = nat[start + k];
+            start += cnt;
+        }
+    };
     std::vector<FusedDec> frames;
     std::vector<Work> work;
     {
@@ -1082,6 +1107,7 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
                 for (int t0 = 0; t0 < nt; t0 += per_wg) work.push_back({f, t0, std::min(per_wg, nt - t0), 0});
             }
             g.n_work = static_cast<int>(work.size()) - g.first_work;
+            xcd_interleave(work, static_cast<size_t>(g.first_work), static_cast<size_t>(g.n_work));
         }
     }
     // pyramid launches of the kFdPre slots: one per number of levels; a workgroup takes a run of tiles of one frame
@@ -1107,6 +1133,7 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
                 for (int t0 = 0; t0 < nt; t0 += per_wg) pyr_work.push_back({f, t0, std::min(per_wg, nt - t0), 0});
             }
             g.n_work = static_cast<int>(pyr_work.size()) - g.first_work;
+            xcd_interleave(pyr_work, static_cast<size_t>(g.first_work), static_cast<size_t>(g.n_work));
             b->pyr_groups.push_back(g);
         }
     // upsampling steps: step k (k-th from the coarsest level) of all slots together
@@ -1293,11 +1320,24 @@ static int launch_entropy_groups(ccd_batch* b, hipStream_t st, bool with_float) 
         return CCD_OK;
     };
     int k = 0;
+    if (b->opt_time_launches) {
+        while (static_cast<int>(b->lt0.size()) < n_launch) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            HIP_TRY(hipEventCreate(&e0));
+            b->lt0.push_back(e0);
+            HIP_TRY(hipEventCreate(&e1));
+            b->lt1.push_back(e1);
+        }
+        b->n_timed = n_launch;
+    }
     for (int gi : order) {
         const auto& g = b->pipe_groups[gi];
         int side = -1;
+        const int kk = k;
         hipStream_t s = stream_for(k++, &side);
+        if (b->opt_time_launches) HIP_TRY(hipEventRecord(b->lt0[kk], s));
         hipError_t e = launch_entropy_pipe(b->d_params + g.first, g.n, g.nv, g.mfma, g.dyn, g.shape, g.lds, s);
+        if (b->opt_time_launches) HIP_TRY(hipEventRecord(b->lt1[kk], s));
         if (e == hipSuccess && with_float) {
             // this launch's frames: pyramid launch(es), then the fused kernel - on the SAME stream, so they start when this launch's
             // slowest stream is done, whatever the other launches are doing.  (Common randomness needs its noise planes first:
@@ -1315,8 +1355,11 @@ static int launch_entropy_groups(ccd_batch* b, hipStream_t st, bool with_float) 
     }
     if (b->n_generic > 0) {
         int side = -1;
+        const int kk = k;
         hipStream_t s = stream_for(k++, &side);
+        if (b->opt_time_launches) HIP_TRY(hipEventRecord(b->lt0[kk], s));
         const hipError_t e = launch_entropy(b->d_params + b->n_pipe, b->n_generic, b->lds_generic, s);
+        if (b->opt_time_launches) HIP_TRY(hipEventRecord(b->lt1[kk], s));
         const int rc = mark(side);
         if (e != hipSuccess) return CCD_ERR_HIP;
         if (rc < 0) return rc;
@@ -1451,6 +1494,21 @@ int ccd_concurrent_streams(int device) {
     return rc < 0 ? rc : sh->n_conc;
 }
 
+int ccd_batch_launch_ms(ccd_batch* b, float* ms, int* n_streams, int cap) {
+    if (!b || !ms || cap < 0) return CCD_ERR_ARG;
+    if (!b->opt_time_launches) return 0;
+    // launch order = longest expected chains first (launch_entropy_groups); the generic launch last
+    std::vector<int> order(b->pipe_groups.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = static_cast<int>(i);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return b->pipe_groups[x].est > b->pipe_groups[y].est; });
+    const int n = std::min(b->n_timed, cap);
+    for (int k = 0; k < n; ++k) {
+        if (hipEventSynchronize(b->lt1[k]) != hipSuccess || hipEventElapsedTime(&ms[k], b->lt0[k], b->lt1[k]) != hipSuccess) return CCD_ERR_HIP;
+        if (n_streams) n_streams[k] = k < static_cast<int>(order.size()) ? b->pipe_groups[order[k]].n : b->n_generic;
+    }
+    return n;
+}
+
 int ccd_batch_entropy_launches(const ccd_batch* b) {
     if (!b) return CCD_ERR_ARG;
     return static_cast<int>(b->pipe_groups.size()) + (b->n_generic > 0 ? 1 : 0);
@@ -1481,6 +1539,7 @@ int ccd_batch_set_option(ccd_batch* b, int option, int value) {
         case CCD_OPT_KEEP_FLOAT: b->opt_keep_float = value; return CCD_OK;
         case CCD_OPT_MFMA_ARM: b->opt_mfma_arm = value; return CCD_OK;
         case CCD_OPT_RANGE_BITS: b->opt_range_bits = value; return CCD_OK;
+        case CCD_OPT_TIME_LAUNCHES: b->opt_time_launches = value ? 1 : 0; return CCD_OK;
         case CCD_OPT_OVERLAP:
             // (decides how the launch tables are grouped: a change re-builds them at the next run)
             if (b->opt_overlap != (value ? 1 : 0)) { b->opt_overlap = value ? 1 : 0; b->regroup = true; }

@@ -178,6 +178,8 @@ struct ShapeDyn { static constexpr bool fixed = false; static constexpr int dim 
 template <int DIM, int NL, int NSP>
 struct ShapeFix { static constexpr bool fixed = true; static constexpr int dim = DIM, n_layers = NL, n_sp = NSP; };
 using ShapeHop = ShapeFix<20, 3, 14>;
+// (r06: ShapeFix<8, 3, 6> = intra/lop.cfg, the I frames of the 1080p GOP, was built and measured: 164.85 against 163.98 ms for the
+// GOP's cool-chics, kodak24_hq 39.58 against 39.4 - nothing; a two-vector network has no register pressure to relieve.  Not kept.)
 
 // The IFCE features of one position of the previous grid sit NEXT to each other in the int16 scratch (position-major, stride =
 // the number of features: 12 bytes for the usual six): a task's feature reads touch one cache line per pixel instead of one per

@@ -167,6 +167,10 @@ int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64);
  * that share one run one after the other.  The entropy launches of a batch that should overlap are put on these streams only,
  * and a batch is never split into more launches than that (environment: CCD_SIDE_STREAMS=k skips the measurement). */
 int ccd_concurrent_streams(int device);
+/* With CCD_OPT_TIME_LAUNCHES: duration in ms of every entropy launch of the LAST run (in launch order: longest expected chains
+ * first) and the number of streams each holds; waits for those launches.  Returns the number of launches written (<= cap),
+ * 0 when the option is off. */
+int ccd_batch_launch_ms(ccd_batch* b, float* ms, int* n_streams, int cap);
 /* Entropy launches per run of the batch as its launch tables were last built (ccd_batch_prepare / the first run after an add):
  * one per kernel instantiation in use and chain group (see ccd_batch_run); 0 before the tables exist. */
 int ccd_batch_entropy_launches(const ccd_batch* b);
@@ -208,8 +212,10 @@ int ccd_batch_slot_kernels(const ccd_batch* b, int slot);
  *   CCD_OPT_OVERLAP     1 (default): ccd_batch_run overlaps the float path of the streams that finish early with the longest
  *                       entropy chains (chain groups, see ccd_batch_run); 0: one entropy launch per kernel instantiation and
  *                       every float launch behind the join.  Results are identical bit for bit (A/B, tests).  Environment:
- *                       CCD_OVERLAP=0. */
-enum { CCD_OPT_FUSED_DEC = 1, CCD_OPT_KEEP_FLOAT = 2, CCD_OPT_MFMA_ARM = 3, CCD_OPT_RANGE_BITS = 4, CCD_OPT_OVERLAP = 5 };
+ *                       CCD_OVERLAP=0.
+ *   CCD_OPT_TIME_LAUNCHES  0 (default); 1: timing events around every entropy launch on the stream it runs on; ccd_batch_launch_ms
+ *                       returns the durations of the last run (measurement only: bench.py's roofline). */
+enum { CCD_OPT_FUSED_DEC = 1, CCD_OPT_KEEP_FLOAT = 2, CCD_OPT_MFMA_ARM = 3, CCD_OPT_RANGE_BITS = 4, CCD_OPT_OVERLAP = 5, CCD_OPT_TIME_LAUNCHES = 6 };
 int ccd_batch_set_option(ccd_batch* b, int option, int value);
 
 /* Device pointers of a slot's results (valid until the batch is destroyed / re-run): */

@@ -682,6 +682,43 @@ def test_repeated_runs_are_identical(gpu, oracle):
         b.close()
 
 
+def test_fixed_shape_instantiations_match_the_runtime_shape(gpu, oracle, monkeypatch):
+    """The pipelined entropy kernel is instantiated with a compile-time ARM shape for the intra preset the benchmark sets use -
+    hop.cfg (14 + 6 inputs: kodim14, kodak24, clic41, uhd4k), slot_kernels bit 5 (lop.cfg got one in r06 and lost it again: no
+    gain).  CCD_FIXED_SHAPE=0 sends the same stream through the run-time-shape instantiation: identical latents and planes, and
+    both are the reference's (the fixtures' expected values); the other networks never take a fixed shape."""
+    names = ["kodim14", "rgb192", "cr192", "yuv444_10b", "hq192", "mop192"]
+    triples = []
+    for n in names:
+        bs, _, _ = load_golden(n)
+        fh, ccs = oracle.split_stream(bs)[1][0]
+        triples.append((ccs[0], fh.bitdepth, fh.frame_data_type))
+
+    def decode():
+        b = gpu(0)
+        for (hdr, nn, lat), bd, fdt in triples:
+            b.add(hdr, nn, lat, bd, fdt)
+        b.run(); b.wait()
+        out = [([b.latent(s, g) for g in range(b.header(s).n_grids)], b.planes(s), b.slot_kernels(s)) for s in range(len(triples))]
+        b.close()
+        return out
+
+    fixed = decode()
+    monkeypatch.setenv("CCD_FIXED_SHAPE", "0")
+    dyn = decode()
+    for n, f, d in zip(names, fixed, dyn):
+        want_fixed = n == "kodim14"   # only hop (14 + 6 inputs) has a compile-time instantiation
+        assert bool(f[2] & 32) == want_fixed, (n, f[2])
+        assert not d[2] & 32, (n, d[2])
+        for a, b_ in zip(f[0], d[0]):
+            assert np.array_equal(a, b_), n
+        for a, b_ in zip(f[1], d[1]):
+            assert np.array_equal(a, b_), n
+        z = load_golden(n)[1]
+        for g, a in enumerate(f[0]):
+            assert np.array_equal(a, z[f"cc0.latent{g}"]), f"{n} grid {g} differs from the reference decoder's"
+
+
 def test_overlapped_run_equals_staged_run(gpu, oracle):
     """ccd_batch_run overlaps the float path of the streams that finish early with the longest entropy chains (r06: chain groups -
     the slots of a kernel instantiation split by expected chain length, each group's pyramid + fused launches on the group's own

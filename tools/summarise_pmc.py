@@ -26,6 +26,9 @@ KERNELS = {  # short name -> (substring of the kernel name, launches per bench s
 }
 
 
+RUNS = {"kodak24": 3, "clic41": 4, "uhd4k": 4, "kodak24_hq": 4}  # runs of the batch in the profiled command (tools/prof_workload.py: 1 + steps)
+
+
 def read(dir_, counter):
     vals = defaultdict(list)
     for f in sorted(glob.glob(os.path.join(dir_, "**", "*counter_collection.csv"), recursive=True)):
@@ -51,12 +54,18 @@ def main():
         e = {"full_names": names, "launches": 0}
         tot_f = tot_w = 0.0
         for name in names:
-            f, w = fetch[name][1:] or fetch[name], write.get(name, [0.0])[1:] or write.get(name, [0.0])
+            # r06: a kernel may be launched several times per step (chain groups: one entropy / pyramid / fused launch per group).
+            # Where the number of runs of the profiled command is known (RUNS), the figure is bytes per STEP: the launches of the
+            # first run dropped, the others summed and divided by the runs left
+            runs = RUNS.get(tag)
+            k = len(fetch[name]) // runs if runs and len(fetch[name]) % runs == 0 else 1
+            f, w = fetch[name][k:] or fetch[name], write.get(name, [0.0])[k:] or write.get(name, [0.0])
             e["launches"] += len(f)
-            tot_f += sum(f) / len(f)
-            tot_w += sum(w) / len(w)
+            e.setdefault("launches_per_step_by_kernel", {})[name[:120]] = k
+            tot_f += sum(f) / len(f) * k
+            tot_w += sum(w) / len(w) * k
             if len(names) > 1:
-                e.setdefault("per_kernel", {})[name[:120]] = {"fetch_bytes": sum(f) / len(f), "write_bytes": sum(w) / len(w)}
+                e.setdefault("per_kernel", {})[name[:120]] = {"fetch_bytes": sum(f) / len(f) * k, "write_bytes": sum(w) / len(w) * k}
         if per_step:
             e["launches_per_step"] = per_step
             e["fetch_bytes_per_step"] = tot_f * per_step
@@ -65,12 +74,12 @@ def main():
             e["fetch_bytes"] = tot_f
             e["write_bytes"] = tot_w
         out[short] = e
-    cmd = {"kodak24": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --legs none",
+    cmd = {"kodak24": "python tools/prof_workload.py kodak24 2 keep_float [= bench.py's live pass, measure_traffic_live: the metric's batch alone]",
            "kodak256": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-live-traffic --legs none --scaling throughput",
            "rate": "python tools/prof_rate.py"}.get(tag, f"python tools/prof_workload.py {tag} 3")
     doc = {
         "command": cmd + " (tools/collect_profiles.sh; one rocprofv3 run per counter)",
-        "unit": "bytes per launch: rocprofv3 FETCH_SIZE x 1024 x 2, WRITE_SIZE x 1024 x 1",
+        "unit": "bytes per step of the batch (= per launch where a kernel is launched once per step; launches_per_step_by_kernel says): rocprofv3 FETCH_SIZE x 1024 x 2, WRITE_SIZE x 1024 x 1",
         "calibration": "profiles/r03/pmc_calibration.json (tools/pmc_calibrate.sh, tools/ubench/pmc_calib.hip): on gfx950 FETCH_SIZE = 0.500 of "
                        "the bytes streamed with 1, 2, 4 and 16 bytes per lane; WRITE_SIZE = 1.000 with 1, 4, 8 and 16 bytes per lane",
         "kernels": out,
