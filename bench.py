@@ -703,6 +703,23 @@ def main():
             "traffic_by_kernel": pmc.get("decode_fused_kernel", {}).get("per_kernel"),
             "note": "compute-bound by construction (%.1f B/px, ~%.0f flop/px): priced against the fp32 peak; exact fmaf chains on "
                     "v_mfma_f32_4x4x1 (bitwise the oracle's order)" % (ff_bytes / rank_px, flop_px)}]
+        # r06: the step launches the float path once per chain group (two smaller launches each on kodak24, so that the 18 landscape
+        # frames are synthesised while the 6 portrait streams still decode): the line above prices THOSE launches; beside it the same
+        # kernels as ONE launch each over all frames (overlap off) - the kernel's own efficiency, comparable with earlier rounds
+        if world == 1 and n_frames:
+            b1 = DecodeBatch(local_rank, overlap=False)
+            for hdr, nn, lat, _ in mine:
+                b1.add(hdr, nn, lat, 8, 0)
+            b1.run(sh); b1.wait(sh)
+            one = {name: event_ms(stream, lambda st=st: b1.run(sh, stage=st), args.steps, local_rank) for st, name in ((1, "pyramid_launch"), (2, "fused_float"))}
+            b1.close()
+            ff1 = one["pyramid_launch"] + one["fused_float"]
+            float_lines[0]["note"] += "; launched per chain group (%d groups): see the next entry for one launch over all frames" % batch.entropy_launches()
+            float_lines.append({"kernel": float_lines[0]["kernel"].replace("two launches", "ONE launch per kernel over all frames (CCD_OPT_OVERLAP = 0)"),
+                                "ms_pyramid_launch": one["pyramid_launch"], "ms_fused_kernel": one["fused_float"], "bound": "fp32",
+                                "achieved": flop_px * rank_px / ff1 / 1e9, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": flop_px * rank_px / ff1 / 1e9 / FP32_PEAK_TFLOPS, "ms_per_launch": ff1,
+                                "algorithmic_gbs": ff_bytes / ff1 / 1e6, "frac_of_hbm_peak": ff_bytes / ff1 / 1e6 / HBM_PEAK_GBS})
         res = {
             "metric": "decoded Mpixel/s", "value": px_per_step * args.steps / dt / 1e6, "unit": "Mpixel/s",
             "n_gpus": world, "gpus_active": gpus_active, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -783,7 +800,7 @@ def main():
                                     ("pyramid launch + fused kernel, integer planes + f32 output", dict(fused_dec=2, keep_float=True)),
                                     ("fused kernel alone (whole pyramid per tile), integer planes + f32 output", dict(fused_dec=1, keep_float=True)),
                                     ("unfused (6 upsampling launches + synthesis kernel)", dict(fused_dec=False))):
-                    b = DecodeBatch(local_rank, **opts)
+                    b = DecodeBatch(local_rank, overlap=False, **opts)  # (one launch per kernel: the kernels' own times)
                     for _ in range(copies_f):
                         for hdr, nn, lat, _ in items:
                             b.add(hdr, nn, lat, 8, 0)
@@ -974,6 +991,24 @@ def main():
                 "slots_on_generic_entropy_kernel": sum(1 for k in k_g if not k & 1), "slots_on_unfused_float_path": sum(1 for k in k_g if not k & 4),
                 "verified": verify_frames("kodak24", [bg.planes(s_) for s_ in range(n_kodak)])}
             bg.close()
+            # r06: the one cliff a picture's SIZE decides: wider than the 5 069 columns the pipelined kernel's 512-row symbol ring
+            # holds (the format allows 16 383, header.py:244-307) -> the generic entropy kernel.  Two pictures of the same network
+            # and ~1.97 Mpx, one each side of the limit (parity: tests/test_gpu_parity.py::test_picture_wider_than_the_symbol_ring)
+            rows = {}
+            for label, (h_, w_) in (("5056x388 (pipelined kernel)", (388, 5056)), ("7680x256 (wider than the ring: generic kernel)", (256, 7680))):
+                bw = DecodeBatch(local_rank)
+                bw.add(*synth.split_image_stream(synth.image_stream(h_, w_, 0)), 8, 0)
+                bw.run(sh); bw.wait(sh)
+                ms_w_ = event_ms(stream, lambda: bw.run(sh, stage=0), 2, local_rank)
+                bw.wait(sh)
+                rows[label] = {"entropy_ms": ms_w_, "symbols": n_symbols(bw, 1), "ns_per_symbol": ms_w_ * 1e6 / n_symbols(bw, 1),
+                               "on_pipelined_kernel": bool(bw.slot_kernels(0) & 1), "status": int(bw.slot_status(0))}
+                bw.close()
+            ks = list(rows)
+            res["fallback_cliffs"]["picture_wider_than_the_symbol_ring"] = {
+                **rows, "ratio_ns_per_symbol": rows[ks[1]]["ns_per_symbol"] / rows[ks[0]]["ns_per_symbol"],
+                "limit": "pictures up to 5 069 columns run the pipelined kernel (W / 10 + 6 <= 512 ring rows x 64 B = 32 KB of its 139 KB of LDS; "
+                         "16 383 columns would need 1 645 rows = 105 KB next to 66 KB of window tables: not in 160 KB)"}
         if want_cpu:
             res["cpu_baseline"] = cpu_sample(streams, [h * w for *_, (h, w) in items], 8.0, "kodak24 streams")
             # measured once in the build container (8-core Xeon 2.1 GHz, torch 2.10 CPU): the reference's own PyTorch decode of
