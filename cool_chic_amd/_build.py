@@ -5,7 +5,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["ccd_format.cpp", "ccd_writer.cpp", "ccd_api.cpp", "ccd_entropy.hip", "ccd_entropy_pipe.hip", "ccd_float.hip", "ccd_synth_fused.hip", "ccd_fused.hip", "ccd_fused_pre.hip", "ccd_fused_cr.hip", "ccd_inter.hip", "ccd_png.hip", "ccd_rate.hip"]
-HEADERS = ["ccd_format.hpp", "ccd_device.hpp", "ccd_laplace.hpp", "ccd_fused_kernel.inc", "ccd_exp_table.inc", "ccd_dec_block16.inc", "ccd_dec_block16p.inc", "ccd_dec_block16pm.inc", "ccd_dec_parts8.inc", "ccd_dec_parts4.inc", "ccd_dec_tramp16p.inc", "ccd_dec_block32.inc", "ccd_dec_tramp16.inc", "ccd_dec_tramp32.inc", "../../include/ccd.h", "../../include/ccd_scale_table.inc"]
+HEADERS = ["ccd_format.hpp", "ccd_device.hpp", "ccd_laplace.hpp", "ccd_fused_kernel.inc", "ccd_exp_table.inc", "ccd_dec_block16.inc", "ccd_dec_block16p.inc", "ccd_dec_block16pm.inc", "ccd_dec_parts8.inc", "ccd_dec_parts4.inc", "ccd_dec_parts4_nc.inc", "ccd_dec_tramp16p.inc", "ccd_dec_block32.inc", "ccd_dec_tramp16.inc", "ccd_dec_tramp32.inc", "../../include/ccd.h", "../../include/ccd_scale_table.inc"]
 LIB = os.path.join(_HERE, "libccd.so")
 
 

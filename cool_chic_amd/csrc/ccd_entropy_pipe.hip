@@ -367,7 +367,11 @@ struct StreamBody {
     __device__ void init(uint32_t H, uint32_t W, int task_pix) {
         const uint32_t T = kStreamMinStep;
 #if CCD_BPX_WIDE == 16 && !defined(CCD_NO_STREAM_BODY)
+#ifdef CCD_STREAM_T4  // experiment (r06): the body of a grid with 4-pixel tasks streamed too (r04 measured it slower, before the 4-symbol parts chained)
+        on = (task_pix == 8 || task_pix == 4) && W > 10u * (T - 1u) && H >= T;
+#else
         on = task_pix == 8 && W > 10u * (T - 1u) && H >= T;  // (4-pixel tasks streamed: measured slower, profiles/r04/ab_entropy_stream.txt)
+#endif
 #ifndef CCD_STREAM_EVERY_WIDE_GRID
         {   // where it pays: long steps (the decoder is the limit: its per-step costs go away) or steps whose last task is mostly empty.
             // Elsewhere - 39-pixel steps = 8 + 8 + 8 + 8 + 7 - the tasks of step-aligned batches wait for ONE earlier task each instead
@@ -993,7 +997,11 @@ __device__ __forceinline__ uint32_t decoder_grid(const PipeCtx& C, DecState& S) 
                 // ---- the two 8-symbol parts of a batch that is decoded part by part (the producers are the limit: every short-step
                 // grid, grid 0 of a portrait picture): the paired block above cut in two, each half ending in the part-end handler 2:
 #include "ccd_dec_parts8.inc"
+#ifdef CCD_NO_CHAIN4
+#include "ccd_dec_parts4_nc.inc"  // r05: every 4-symbol part through the part-end handler and a look at the ready word
+#else
 #include "ccd_dec_parts4.inc"
+#endif
 #endif
                 "15:\n\t"
                 "s_mov_b32 %[st], 3\n\t"

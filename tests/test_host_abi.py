@@ -384,7 +384,7 @@ def test_generated_kernel_tables_are_current(tmp_path, monkeypatch):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "cool_chic_amd", "csrc")
-    names = ["ccd_dec_block16.inc", "ccd_dec_block16p.inc", "ccd_dec_block16pm.inc", "ccd_dec_tramp16p.inc", "ccd_dec_parts8.inc", "ccd_dec_parts4.inc", "ccd_dec_block32.inc", "ccd_dec_tramp16.inc",
+    names = ["ccd_dec_block16.inc", "ccd_dec_block16p.inc", "ccd_dec_block16pm.inc", "ccd_dec_tramp16p.inc", "ccd_dec_parts8.inc", "ccd_dec_parts4.inc", "ccd_dec_parts4_nc.inc", "ccd_dec_block32.inc", "ccd_dec_tramp16.inc",
              "ccd_dec_tramp32.inc", "ccd_exp_table.inc"]
     # run the generators on a copy of the tree layout (they write next to the sources)
     fake = tmp_path / "repo"

@@ -82,12 +82,17 @@ def pair(p):
     return "s[%s:%s]" % (p[0][1:], p[1][1:])
 
 
-def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False, cont=False):
+def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False, cont=False, chain=None):
     """mid_publish: behind the test of symbols n/2 - 2 and n/2 - 1 the first n/2 symbols go to the ring and the stream's pixel count
     is published - the first task of the NEXT step (8 pixels: it waits for its left neighbours, the first 8 or 9 symbols of this
     step) starts its late part half a batch earlier (measured: no gain on the chain-bound grids, + 2 ticks per symbol on grid 0).
     part: the block of ONE 8-pixel part of a batch that is decoded part by part (symbols lane0 .. lane0 + 7 of the batch; v50 = the
-    part's first row); it ends in the loop's part-end handler (2:) like a part that ran through the 3-copy loop."""
+    part's first row); it ends in the loop's part-end handler (2:) like a part that ran through the 3-copy loop.
+    chain (r06, 4-symbol parts): label of the NEXT part's block.  The part asks for the slot's ready word two symbols before its end;
+    behind its last symbol it publishes itself and, if the next part's bit is set, goes straight on in that part's block (rows
+    4 / 5 of this block are that part's first two: moved to where its block expects them) - ~28 instructions between two parts
+    instead of the part-end handler + a look at the ready word + the dispatch (~45 instructions, an LDS round trip, four taken
+    branches: ~480 ticks per part measured with 4-pixel tasks on a half-size grid, profiles/r06/prof_grids_t8_40.txt)."""
     assert n % 2 == 0
     out = []
     for j in range(n):
@@ -96,7 +101,7 @@ def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False, 
         dcur, dnew = DP[j % 2], DP[(j + 1) % 2]
         lp_lo, lp_hi, lane = HS[j % 2]
         out.append(q("%d:" % (label0 + j)))
-        if part and cont and j == n - 2:
+        if part and (cont or chain) and j == n - 2:
             # first part of a batch: ask for the slot's ready word now - behind the block it says whether the second part is there
             out.append(q("ds_read_b32 v54, v51"))
         if mid_publish and j == n // 2:
@@ -104,7 +109,7 @@ def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False, 
                     q("ds_write_b8 %[ring], v52"), q("s_mov_b64 exec, -1"), q("s_add_u32 s58, %[pix0], %[i]"), q("s_add_u32 s58, s58, %d" % (n // 2)),
                     q("v_mov_b32 v56, s58"), q("ds_write_b32 %[rdy], v56 offset:68")]
         wait = "s_waitcnt lgkmcnt(4)" if (mid_publish and j in (n // 2, n // 2 + 1)) else "s_waitcnt lgkmcnt(2)"
-        if part and cont and j >= n - 2:
+        if part and (cont or chain) and j >= n - 2:
             wait = "s_waitcnt lgkmcnt(3)"
         out += [q("s_lshr_b64 s[40:41], %s, 24" % pair(rcur)),
                 q("ds_read_b64 %s, v50 offset:%d" % (nxt, 512 * (j + 2))),
@@ -144,6 +149,29 @@ def block_paired(n, tramp0, mid_publish=False, label0=300, lane0=0, part=False, 
                 q("s_cmp_eq_u32 s59, 16"), q("s_cbranch_scc0 %df" % (label0 + n + 1)),
                 q("s_bitcmp1_b32 s58, 1"), q("s_cbranch_scc0 %df" % (label0 + n + 1)),
                 q("ds_read_b32 %[top], v53"), q("ds_read_b32 %[ring], v53 offset:520"), q("ds_read_b32 %[goff], v53 offset:1040"), q("s_mov_b32 s65, 0"), q("s_mov_b32 s54, s66"), q("s_branch 308b"),
+                q("%d:" % (label0 + n + 1)),
+                q("s_mov_b64 s[52:53], %s" % pair(RP[n % 3])), q("s_add_u32 %%[i], %%[i], %d" % n), q("s_mov_b32 s67, %[i]"), q("s_branch 126b")]
+        return out
+    if part and chain:
+        assert n == 4 and DP[n % 2] == DP[0] and lane0 in (0, 4, 8)
+        nxt_bit = lane0 // 4 + 1
+        out += [q("s_mov_b64 exec, 0x%x" % (0xf << lane0)), q("v_sub_u32 v52, %[top], %[raw]"), q("v_add_u32 v52, 1, v52"), q("ds_write_b8 %[ring], v52"),
+                q("global_store_byte %[goff], v52, %[lat]"), q("s_mov_b64 exec, -1"),
+                q("s_add_u32 s58, %[pix0], %[i]"), q("s_add_u32 s58, s58, 4"), q("v_mov_b32 v56, s58"), q("ds_write_b32 %[rdy], v56 offset:68"),
+                q("s_add_u32 s59, %[i], 8"),
+                q("s_waitcnt lgkmcnt(4)"),          # (the ready word: in front of rows 4 and 5 and the two stores)
+                q("v_readfirstlane_b32 s58, v54"),
+                q("s_cmp_le_u32 s59, s66"), q("s_cbranch_scc0 %df" % (label0 + n + 1)),      # a FULL part of this batch behind this one?
+                q("s_bitcmp1_b32 s58, %d" % nxt_bit), q("s_cbranch_scc0 %df" % (label0 + n + 1)),
+                # go on in the next part's block: range in s[52:53], its rows 0 / 1 in v[40:41] / v[42:43], v50 = its first row, the
+                # part's top symbols / ring cells / grid offsets read again (its producer has stored them by now)
+                q("s_mov_b64 s[52:53], %s" % pair(RP[n % 3])),
+                q("s_waitcnt lgkmcnt(2)"),          # rows 4 and 5
+                q("v_mov_b32 v40, v42"), q("v_mov_b32 v41, v43"), q("v_mov_b32 v42, v46"), q("v_mov_b32 v43, v47"),
+                q("v_add_u32 v50, 0x800, v50"),
+                q("ds_read_b32 %[top], v53"), q("ds_read_b32 %[ring], v53 offset:520"), q("ds_read_b32 %[goff], v53 offset:1040"),
+                q("s_add_u32 %[i], %[i], 4"), q("s_mov_b32 s67, %[i]"), q("s_add_u32 s54, %[i], 4"),
+                q("s_branch %db" % chain if chain < label0 else "s_branch %df" % chain),
                 q("%d:" % (label0 + n + 1)),
                 q("s_mov_b64 s[52:53], %s" % pair(RP[n % 3])), q("s_add_u32 %%[i], %%[i], %d" % n), q("s_mov_b32 s67, %[i]"), q("s_branch 126b")]
         return out
@@ -238,12 +266,14 @@ def main():
     for label0, lane0, tramp0 in ((400, 0, 1001), (420, 8, 1401)):
         parts += [q(".p2align 6")] + block_paired(8, tramp0, label0=label0, lane0=lane0, part=True, cont=lane0 == 0) + trampolines_paired(8, tramp0, label0)
     (root / "ccd_dec_parts8.inc").write_text(head + "\n".join(parts) + "\n")
-    # the four 4-symbol parts of a 16-pixel batch of 4-pixel tasks (grids whose widest step has 9 .. 24 pixels)
-    parts = []
-    for k in range(4):
-        label0, tramp0 = 440 + 10 * k, 1801 + 400 * k
-        parts += [q(".p2align 6")] + block_paired(4, tramp0, label0=label0, lane0=4 * k, part=True) + trampolines_paired(4, tramp0, label0)
-    (root / "ccd_dec_parts4.inc").write_text(head + "\n".join(parts) + "\n")
+    # the four 4-symbol parts of a 16-pixel batch of 4-pixel tasks (grids whose widest step has 9 .. 24 pixels); r06: chained - and
+    # the unchained r05 form beside it for A/B (-DCCD_NO_CHAIN4)
+    for chained, fname in ((True, "ccd_dec_parts4.inc"), (False, "ccd_dec_parts4_nc.inc")):
+        parts = []
+        for k in range(4):
+            label0, tramp0 = 440 + 10 * k, 1801 + 400 * k
+            parts += [q(".p2align 6")] + block_paired(4, tramp0, label0=label0, lane0=4 * k, part=True, chain=(label0 + 10) if (chained and k < 3) else None) + trampolines_paired(4, tramp0, label0)
+        (root / fname).write_text(head + "\n".join(parts) + "\n")
     (root / "ccd_dec_tramp16p.inc").write_text(head + "\n".join(trampolines_paired(16, 201)) + "\n")
 
 
