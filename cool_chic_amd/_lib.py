@@ -94,6 +94,7 @@ SIGNATURES = {
     "ccd_batch_entropy_launches": (C.c_int, [C.c_void_p]),
     "ccd_batch_launch_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "ccd_concurrent_streams": (C.c_int, [C.c_int]),
+    "ccd_debug_chain_groups": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "ccd_batch_run_stage": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "ccd_batch_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ccd_batch_slot_status": (C.c_int, [C.c_void_p, C.c_int]),

@@ -943,6 +943,41 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
 // DIFFERENT XCDs and each fetched the shared cache lines from HBM for itself (main launch of the fused float path: 165 MB
 // fetched per 24 Kodak frames for ~70 MB of stack + latents, profiles/r05/kodak24_pmc_traffic.json).  Here item j of the natural
 // order goes to a workgroup of XCD x = the eighth of the list it lies in: every XCD walks ONE contiguous run of tiles.
+// Chain groups of a batch (pure: ccd_debug_chain_groups exposes it to the CPU tests).  est[i]: expected chain of slot i; inst[i]: its
+// kernel instantiation (0 .. k - 1; -1: the generic kernel's launch); n_conc: streams that really run at once; n_cu: CUs of the
+// device.  cg[i] = 0 for the slots within 3 % of the batch's longest chain, 1 within 20 %, 2 for the rest - capped so that
+// (a) instantiations x groups <= n_conc: a launch per group only helps on a stream of its own;
+// (b) every workgroup still finds a CU at once.  A stream's workgroup owns a CU (139 KB of LDS) and the hardware deals the
+//     workgroups of ONE launch out to the 8 XCDs round-robin: two launches of 63 + 193 workgroups put 8 + 25 on one 32-CU XCD, the
+//     33rd waits for a whole chain - 68 ms instead of 36.6 (profiles/r06/streams_in_flight_overlap_before_xcd_rule.txt; a single
+//     launch of 256 deals 32 to each): sum over launches of ceil(n / 8) <= CUs / 8, else fewer groups.
+static void plan_chain_groups(const double* est, const int* inst, int n, int n_conc, int n_cu, int* cg) {
+    constexpr int kXcd = 8;  // gfx950
+    double est_max = 0.0;
+    int n_inst = 0, n_generic = 0;
+    for (int i = 0; i < n; ++i) {
+        if (inst[i] < 0) { ++n_generic; continue; }
+        est_max = std::max(est_max, est[i]);
+        n_inst = std::max(n_inst, inst[i] + 1);
+    }
+    int max_cg = std::max(1, std::min(3, n_conc / std::max(1, n_inst)));
+    for (; max_cg >= 1; --max_cg) {
+        for (int i = 0; i < n; ++i) {
+            const int c = est[i] >= 0.97 * est_max ? 0 : (est[i] >= 0.80 * est_max ? 1 : 2);
+            cg[i] = inst[i] < 0 ? 0 : std::min(c, max_cg - 1);
+        }
+        if (max_cg == 1) break;
+        int per_xcd = (n_generic + kXcd - 1) / kXcd;
+        for (int k = 0; k < n_inst; ++k)
+            for (int g = 0; g < max_cg; ++g) {
+                int cnt = 0;
+                for (int i = 0; i < n; ++i) cnt += (inst[i] == k && cg[i] == g) ? 1 : 0;
+                per_xcd += (cnt + kXcd - 1) / kXcd;
+            }
+        if (per_xcd <= n_cu / kXcd) break;
+    }
+}
+
 // Expected length of a slot's serial chain in decoder ticks (only the ORDER and rough ratios matter: it decides which streams
 // share an entropy launch).  Per grid ~120 ticks per symbol + ~1.8 k per wavefront step (latent.py:66-140: W + 10 (H - 1) steps):
 // profiles/r06/prof_grids_base.txt - a portrait Kodak stream comes out 1.09 x a landscape one (measured 1.06).
@@ -969,48 +1004,24 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
     // hides behind the longest chains (kodak24: 18 landscape pictures are done 2 ms before the 6 portrait ones).  At most ~4
     // launches per batch: HIP streams share a handful of hardware queues.
     std::vector<double> est(n, 0.0);
-    std::vector<int> cg_of(n, 0);
+    std::vector<int> cg_of(n, 0), inst_of(n, -1);
     {
-        double est_max = 0.0;
         std::vector<std::array<int, 3>> insts;
         for (int i = 0; i < n; ++i) {
             const Slot& sl = *b->slots[i];
             est[i] = chain_estimate(sl.ep);
-            if (!sl.use_pipe) continue;
-            est_max = std::max(est_max, est[i]);
+            if (!sl.use_pipe) continue;  // (-1: the generic launch)
             const std::array<int, 3> key{(sl.ep.dim + 3) / 4, sl.use_mfma ? 2 : (sl.use_dyn ? 1 : 0), sl.fixed_shape};
-            if (std::find(insts.begin(), insts.end(), key) == insts.end()) insts.push_back(key);
+            auto it = std::find(insts.begin(), insts.end(), key);
+            inst_of[i] = static_cast<int>(it - insts.begin());
+            if (it == insts.end()) insts.push_back(key);
         }
         // as many launches as streams really run at once (DeviceShared::n_conc, measured), shared between the instantiations
         int n_conc = 1;
         { DeviceShared* shd = nullptr; if (device_shared(b->device, &shd) >= 0) n_conc = shd->n_conc; }
-        int max_cg = !b->opt_overlap ? 1 : std::max(1, std::min(3, n_conc / std::max<int>(1, static_cast<int>(insts.size()))));
-        // ... and only while every workgroup still finds a CU at once.  A stream's workgroup owns a CU (139 KB of LDS), and the
-        // hardware deals the workgroups of ONE launch out to the 8 XCDs round-robin: two launches of 63 + 193 workgroups put 8 + 25
-        // on one 32-CU XCD, the 33rd waits for a whole chain - 68 ms instead of 36.6 (profiles/r06/diag_wide.txt; a single launch of
-        // 256 deals 32 to each).  So the split must leave room on the fullest XCD: sum over launches of ceil(n / 8) <= CUs / 8.
         int n_cu = 256;
         { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
-        constexpr int kXcd = 8;  // gfx950
-        for (; max_cg >= 1; --max_cg) {
-            for (int i = 0; i < n; ++i) {
-                const int c = est[i] >= 0.97 * est_max ? 0 : (est[i] >= 0.80 * est_max ? 1 : 2);
-                cg_of[i] = std::min(c, max_cg - 1);
-            }
-            if (max_cg == 1) break;
-            int per_xcd = 0;
-            for (const auto& key : insts)
-                for (int cg = 0; cg < max_cg; ++cg) {
-                    int cnt = 0;
-                    for (int i = 0; i < n; ++i) {
-                        const Slot& sl = *b->slots[i];
-                        if (sl.use_pipe && cg_of[i] == cg && key == std::array<int, 3>{(sl.ep.dim + 3) / 4, sl.use_mfma ? 2 : (sl.use_dyn ? 1 : 0), sl.fixed_shape}) ++cnt;
-                    }
-                    per_xcd += (cnt + kXcd - 1) / kXcd;
-                }
-            per_xcd += (static_cast<int>(std::count_if(b->slots.begin(), b->slots.end(), [](const std::unique_ptr<Slot>& sp) { return !sp->use_pipe; })) + kXcd - 1) / kXcd;
-            if (per_xcd <= n_cu / kXcd) break;
-        }
+        plan_chain_groups(est.data(), inst_of.data(), n, b->opt_overlap ? n_conc : 1, n_cu, cg_of.data());
     }
     for (int nv = 1; nv <= 8; ++nv)
         for (int var = 0; var < 3; ++var)  // vector ALU without / with the device check of the features, matrix cores
@@ -1483,6 +1494,14 @@ int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64) {
     if (!b || !out64 || slot < 0 || slot >= static_cast<int>(b->slots.size())) return CCD_ERR_ARG;
     std::memcpy(out64, b->slots[slot]->host_status, sizeof(b->slots[slot]->host_status));
     return CCD_OK;
+}
+
+int ccd_debug_chain_groups(const double* est, const int32_t* inst, int n, int n_conc, int n_cu, int32_t* cg) {
+    if (!est || !inst || !cg || n < 0 || n_conc < 1 || n_cu < 8) return CCD_ERR_ARG;
+    plan_chain_groups(est, inst, n, n_conc, n_cu, cg);
+    int groups = 0;
+    for (int i = 0; i < n; ++i) groups = std::max(groups, cg[i] + 1);
+    return groups;
 }
 
 int ccd_concurrent_streams(int device) {

@@ -162,6 +162,10 @@ int ccd_batch_slot_status(const ccd_batch* b, int slot);
  * -DCCD_PIPE_PROFILE (which also reuses [36] and [37]).
  * `out64` receives 64 words. */
 int ccd_batch_slot_stats(const ccd_batch* b, int slot, int32_t* out64);
+/* Host only (tests): the chain groups ccd_batch_run would make of n slots with expected chain lengths est[] (any unit) and kernel
+ * instantiations inst[] (0 .. k - 1; -1 = generic kernel) on a device with n_conc concurrent streams and n_cu CUs: cg[i] in 0 .. 2;
+ * returns the number of groups in use.  See ccd_batch_run. */
+int ccd_debug_chain_groups(const double* est, const int32_t* inst, int n, int n_conc, int n_cu, int32_t* cg);
 /* How many of the library's side streams on `device` were MEASURED to run kernels concurrently (1 .. 4; once per process, ~10 ms
  * at the first call or the first ccd_batch_create): HIP multiplexes streams onto a few hardware queues, and launches on streams
  * that share one run one after the other.  The entropy launches of a batch that should overlap are put on these streams only,

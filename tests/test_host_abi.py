@@ -283,6 +283,44 @@ def test_fixtures_reach_every_entropy_instantiation(oracle):
     assert {c[1] for c in sweep.values()} >= {7, 8}
 
 
+def test_chain_groups_plan():
+    """ccd_debug_chain_groups = the pure planning function behind ccd_batch_run's chain groups: which slots share an
+    entropy launch.  kodak24's shape (18 + 6), the caps by concurrent streams and instantiations, and the XCD rule: a split must leave
+    every workgroup a CU - sum over launches of ceil(n / 8) <= CUs / 8 - so 63 + 193 streams stay ONE launch (33 workgroups would
+    land on one 32-CU XCD and the 33rd would wait a whole chain: measured 68 ms against 36.6), 56 + 168 are split."""
+    from cool_chic_amd._lib import lib
+
+    def plan(est, inst, n_conc=4, n_cu=256):
+        e = np.asarray(est, np.float64)
+        k = np.asarray(inst, np.int32)
+        cg = np.full(len(e), -7, np.int32)
+        g = lib().ccd_debug_chain_groups(e.ctypes.data, k.ctypes.data, len(e), n_conc, n_cu, cg.ctypes.data)
+        return g, cg.tolist()
+
+    # 6 portrait streams 9 % longer than 18 landscape ones, one instantiation
+    g, cg = plan([1.09] * 6 + [1.0] * 18, [0] * 24)
+    assert g == 2 and cg == [0] * 6 + [1] * 18
+    # three size classes -> three groups; with two concurrent streams only two; with one (or under a serialising profiler) one
+    est = [1.0, 0.99, 0.9, 0.85, 0.5, 0.2]
+    assert plan(est, [0] * 6) == (3, [0, 0, 1, 1, 2, 2])
+    assert plan(est, [0] * 6, n_conc=2) == (2, [0, 0, 1, 1, 1, 1])
+    assert plan(est, [0] * 6, n_conc=1) == (1, [0] * 6)
+    # two instantiations share four streams: two groups each; four instantiations: one each; the generic launch (-1) is never split
+    assert plan(est, [0, 1, 0, 1, 0, 1])[0] == 2
+    assert plan(est, [0, 1, 2, 3, 0, 1]) == (1, [0] * 6)
+    assert plan(est, [-1] * 6) == (1, [0] * 6)
+    # the XCD rule at a full chip
+    g, cg = plan([1.09] * 63 + [1.0] * 193, [0] * 256)
+    assert g == 1 and set(cg) == {0}
+    g, cg = plan([1.09] * 64 + [1.0] * 192, [0] * 256)   # 8 + 24 = 32 per XCD: fits exactly
+    assert g == 2
+    g, cg = plan([1.09] * 56 + [1.0] * 168, [0] * 224)
+    assert g == 2 and cg.count(0) == 56
+    # uniform batches are not split at all
+    assert plan([1.0] * 24, [0] * 24) == (1, [0] * 24)
+    assert lib().ccd_debug_chain_groups(None, None, 0, 4, 256, None) < 0
+
+
 def test_symbol_ring_width_limit(oracle):
     """The pipelined entropy kernel keeps the recent symbols of W / 10 + 6 picture rows in a 512-row LDS ring: pictures up to
     5 069 columns (documented as 5 060) (include/ccd.h "envelope"); the format's 14-bit img_size allows 16 383 (header.py:244-307), and a
