@@ -127,6 +127,9 @@ __device__ __forceinline__ void ic_warp_pixel(const float* __restrict__ ref, int
 // The same with a compile-time tap count (r06): the runtime-sized version keeps cx / cy / xs in scratch memory (dynamic indexing
 // of per-thread arrays) and spent 0.5 ms per 1080p frame there - ccd_decode_video's 31 inter frames were 21 ms of a 190 ms call
 // (profiles/r06/gop_timing_before.txt).  Same operations in the same order: bit-identical.
+// (r06, measured and dropped: evaluating only the polynomial the quadrant needs where a wave agrees on it - the window's cos does,
+// per tap - behind a ballot: bit-exact, and 0.55 ms per 1080p frame instead of 0.34: the scalar branches serialise what the
+// scheduler interleaves when all 32 evaluations of a pixel are straight-line code.)
 template <int NT>
 __device__ __forceinline__ void ic_coeffs_t(float s, float (&coef)[NT]) {
     const float pi_f = 3.14159265358979323846f;
