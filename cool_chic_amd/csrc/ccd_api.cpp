@@ -191,6 +191,7 @@ struct DeviceShared {
     // batch that need to overlap go to those only - never to the caller's stream, which idles at the join and may alias any of them.
     int n_conc = 0;
     int conc[kSide] = {};
+    int n_cu = 256;   // multiProcessorCount, read once (hipGetDeviceProperties is not a call for the path of every batch)
 };
 int device_shared(int device, DeviceShared** out);
 void calibrate_side_streams(DeviceShared& d);
@@ -446,6 +447,7 @@ int device_shared(int device, DeviceShared** out) {
         for (int k = 0; k < DeviceShared::kSide && ok; ++k) ok = hipStreamCreateWithFlags(&d.side[k], hipStreamNonBlocking) == hipSuccess;
         if (!ok) return CCD_ERR_HIP;
         calibrate_side_streams(d);
+        { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) d.n_cu = v; }
     }
     *out = &d;
     return CCD_OK;
@@ -1017,10 +1019,8 @@ static int upload_params(ccd_batch* b, hipStream_t st) {
             if (it == insts.end()) insts.push_back(key);
         }
         // as many launches as streams really run at once (DeviceShared::n_conc, measured), shared between the instantiations
-        int n_conc = 1;
-        { DeviceShared* shd = nullptr; if (device_shared(b->device, &shd) >= 0) n_conc = shd->n_conc; }
-        int n_cu = 256;
-        { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, b->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
+        int n_conc = 1, n_cu = 256;
+        { DeviceShared* shd = nullptr; if (device_shared(b->device, &shd) >= 0) { n_conc = shd->n_conc; n_cu = shd->n_cu; } }
         plan_chain_groups(est.data(), inst_of.data(), n, b->opt_overlap ? n_conc : 1, n_cu, cg_of.data());
     }
     for (int nv = 1; nv <= 8; ++nv)
