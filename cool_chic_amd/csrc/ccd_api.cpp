@@ -62,6 +62,10 @@ hipError_t launch_planes(const float* src, void* p0, void* p1, void* p2, int h, 
                          hipStream_t stream);
 hipError_t launch_widen_u8(const uint8_t* in, uint16_t* out, size_t n, hipStream_t stream);
 hipError_t launch_spin(unsigned long long ticks, hipStream_t stream);
+size_t inter_coef_bytes(int frame_type, int h, int w);
+hipError_t launch_inter_coef8(int frame_type, int h, int w, const float* motion, void* coef, hipStream_t stream);
+hipError_t launch_inter_apply8(int frame_type, int h, int w, const int* gflow, const float* residue, const float* motion, const float* ref0,
+                               const float* ref1, const void* coef, float* out, hipStream_t stream);
 
 static const uint32_t kScaleBits[kNumScale] = {
 #include "../../include/ccd_scale_table.inc"
@@ -304,6 +308,10 @@ struct ccd_batch {
     // of a step overlap on side streams, so events on the caller's stream only see the whole stage)
     int opt_time_launches = 0;
     std::vector<hipEvent_t> lt0, lt1;    // per entropy launch of the last run (launch order)
+    // behind the float launches of pipe group gi in the last OVERLAPPED run (ccd_decode_video: a frame's flows are ready when the
+    // launch of its motion cool-chic is, long before the whole batch); lg_valid: recorded in the last run
+    std::vector<hipEvent_t> lg_done;
+    bool lg_valid = false;
     int n_timed = 0;
     int opt_overlap = 1;                 // CCD_OVERLAP=0 (environment; A/B and tests): one entropy launch per instantiation, float stages behind the join
     std::vector<PipeGroup> pipe_groups;
@@ -489,6 +497,7 @@ void ccd_batch_destroy(ccd_batch* b) {
     (void)b->drain_streams();  // launches and copies on EVERY stream the caller used with this batch
     if (b->fork) (void)hipEventDestroy(b->fork);
     if (b->params_up) (void)hipEventDestroy(b->params_up);
+    for (hipEvent_t e : b->lg_done) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : b->lt0) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : b->lt1) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : b->side_done) if (e) (void)hipEventDestroy(e);
@@ -1256,10 +1265,14 @@ static int run_upsampling(Slot& s, hipStream_t st) {
     return CCD_OK;  // the pyramid steps were launched for the whole batch (ccd_batch_run_stage)
 }
 
-static int run_synthesis(Slot& s, hipStream_t st) {
+// a slot whose whole float path - fused kernel, final resize, integer planes - can follow its entropy launch on that launch's stream
+static bool tail_keyed(const Slot& s) { return s.fl >= 0 && s.use_fused_dec && !s.cr; }
+
+static int run_synthesis(Slot& s, hipStream_t st, bool keyed_done = false) {
     const Network& net = s.net;
     const int h = s.dense_h, w = s.dense_w;
     if (s.use_fused_syn || s.use_fused_dec) {  // the fused kernel itself was launched for the whole group (ccd_batch_run_stage)
+        if (keyed_done && tail_keyed(s)) return CCD_OK;  // ... and so were its resize / planes launches (launch_entropy_groups)
         const int H = s.hdr.img_size[0], W = s.hdr.img_size[1];
         if (s.d_out != s.d_syn_out) HIP_TRY(launch_final_resize(s.d_syn_out, s.d_out, s.hdr.out_channels, h, w, H, W, s.hdr.final_upsampling_type, st));
         if (s.bitdepth && !(s.use_fused_dec ? s.fdec.write_planes : s.fused.write_planes))
@@ -1360,10 +1373,22 @@ static int launch_entropy_groups(ccd_batch* b, hipStream_t st, bool with_float) 
                 if (fg.fl == gi && !fg.cr && e == hipSuccess)
                     e = launch_fused_dec(b->d_fdec + fg.first_frame, static_cast<const char*>(b->d_fdec_work) + static_cast<size_t>(fg.first_work) * 16, fg.n_work, fg.c_in, fg.c, fg.pre, fg.lds, s);
         }
+        if (e == hipSuccess && with_float) {
+            // ... and what follows the fused kernel per slot: the final resize (the motion cool-chics' nearest x 4) and, where the
+            // fused kernel did not write them, the integer planes
+            for (auto& sp : b->slots)
+                if (sp->lg == gi && tail_keyed(*sp) && run_synthesis(*sp, s) < 0) { e = hipErrorUnknown; break; }
+        }
+        if (e == hipSuccess && with_float) {
+            while (b->lg_done.size() <= static_cast<size_t>(gi)) b->lg_done.push_back(nullptr);
+            if (!b->lg_done[gi] && hipEventCreateWithFlags(&b->lg_done[gi], hipEventDisableTiming) != hipSuccess) e = hipErrorUnknown;
+            if (e == hipSuccess) e = hipEventRecord(b->lg_done[gi], s);
+        }
         const int rc = mark(side);
         if (e != hipSuccess) return CCD_ERR_HIP;
         if (rc < 0) return rc;
     }
+    b->lg_valid = with_float;
     if (b->n_generic > 0) {
         int side = -1;
         const int kk = k;
@@ -1403,7 +1428,7 @@ static int launch_float_stage(ccd_batch* b, hipStream_t st, int stage, bool keye
         }
     }
     for (auto& sp : b->slots) {
-        const int rc = (stage == 1) ? run_upsampling(*sp, st) : run_synthesis(*sp, st);
+        const int rc = (stage == 1) ? run_upsampling(*sp, st) : run_synthesis(*sp, st, keyed_done);
         if (rc < 0) return rc;
     }
     return CCD_OK;
@@ -1688,7 +1713,7 @@ void ccd_video_free(ccd_video* v) {
 // 4:4:4 f32 planes).
 static int inter_reconstruct_on(hipStream_t st, float* tmp, int frame_type, int h, int w, int bitdepth, int frame_data_type,
                                 const float* residue, const float* motion, const void* const* ref0_planes, const void* const* ref1_planes,
-                                const int32_t* global_flow, int warp_filter_size, void* const* out_planes) {
+                                const int32_t* global_flow, int warp_filter_size, void* const* out_planes, const void* coef = nullptr) {
     float* ref0 = tmp;
     float* ref1 = tmp + static_cast<size_t>(3) * h * w;
     float* out = tmp + static_cast<size_t>(6) * h * w;
@@ -1696,7 +1721,9 @@ static int inter_reconstruct_on(hipStream_t st, float* tmp, int frame_type, int 
     if (launch_planes_to_444(ref0_planes[0], ref0_planes[1], ref0_planes[2], ref0, h, w, bitdepth, frame_data_type, st) != hipSuccess) return CCD_ERR_HIP;
     if (frame_type == 2 &&
         launch_planes_to_444(ref1_planes[0], ref1_planes[1], ref1_planes[2], ref1, h, w, bitdepth, frame_data_type, st) != hipSuccess) return CCD_ERR_HIP;
-    if (launch_inter_recon(frame_type, h, w, warp_filter_size, gf, residue, motion, ref0, frame_type == 2 ? ref1 : ref0, out, st) != hipSuccess) return CCD_ERR_HIP;
+    if (coef) {  // the sinc-8 coefficients were computed ahead of the references (ccd_decode_video): gather only
+        if (launch_inter_apply8(frame_type, h, w, gf, residue, motion, ref0, frame_type == 2 ? ref1 : ref0, coef, out, st) != hipSuccess) return CCD_ERR_HIP;
+    } else if (launch_inter_recon(frame_type, h, w, warp_filter_size, gf, residue, motion, ref0, frame_type == 2 ? ref1 : ref0, out, st) != hipSuccess) return CCD_ERR_HIP;
     if (launch_planes(out, out_planes[0], out_planes[1], out_planes[2], h, w, bitdepth, frame_data_type, st) != hipSuccess) return CCD_ERR_HIP;
     return CCD_OK;
 }
@@ -1783,6 +1810,40 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
     mark("parsed + added");
     if (rc >= 0) rc = ccd_batch_run(b, nullptr);
     mark("launched");
+    // ---- r06, OFF by default (CCD_VIDEO_COEF_MB = scratch budget in MB): the warp coefficients of the inter frames ahead of their
+    // references.  The cool-chics of a hierarchical GOP's B frames are decoded at about half of the I frames' chains, and every
+    // reconstruction then waits for the I frames; a frame's sinc coefficients (f64 sin / cos) only need its flows.  With a budget they
+    // are computed on the copy stream as soon as the launch of the frame's motion cool-chic is done (ccd_batch::lg_done), 64 B per pixel
+    // and reference, and the reconstruction only gathers.  Same bits either way (test_video_warp_coefficients_ahead_of_the_references).
+    // Measured on the 33-frame 1080p GOP (profiles/r06/gop_timing_coefficients_ahead.txt): 174.0 against 175.1 ms for 8.2 GB of
+    // scratch - the gather of the 2 x 64 x 3 taps is 0.26 of the 0.34 ms a frame takes, the f64 work only the rest.  Not worth the
+    // memory by default.
+    std::vector<Block> coef(n_frames);
+    std::vector<hipEvent_t> coef_done(n_frames, nullptr);
+    if (rc >= 0 && b->lg_valid) {
+        size_t budget = 0;
+        if (const char* e = std::getenv("CCD_VIDEO_COEF_MB")) budget = static_cast<size_t>(std::max(0, std::atoi(e)));
+        budget <<= 20;
+        size_t spent = 0;
+        for (int f = 0; f < n_frames; ++f) {
+            const ccd_frame_header& fh = fhs[f];
+            if (fh.frame_type == 0 || fh.warp_filter_size != 8) continue;
+            const Slot& s0 = *b->slots[first_slot[f]];
+            const Slot& s1 = *b->slots[first_slot[f] + 1];
+            const int h = s0.hdr.img_size[0], w = s0.hdr.img_size[1];
+            if (s1.hdr.out_channels < (fh.frame_type == 1 ? 2 : 4) || s1.hdr.img_size[0] != h || s1.hdr.img_size[1] != w) continue;  // (rejected below)
+            if (s1.lg < 0 || s1.fl != s1.lg || static_cast<size_t>(s1.lg) >= b->lg_done.size() || !b->lg_done[s1.lg] || !s1.use_fused_dec || s1.cr)
+                continue;  // its output is only complete behind the join
+            const size_t bytes = inter_coef_bytes(fh.frame_type, h, w);
+            if (spent + bytes > budget) break;
+            if (!coef[f].get(device, BlockPool::kDevice, bytes)) break;
+            spent += bytes;
+            if (hipStreamWaitEvent(b->up_stream, b->lg_done[s1.lg], 0) != hipSuccess ||
+                launch_inter_coef8(fh.frame_type, h, w, s1.d_out, coef[f].p, b->up_stream) != hipSuccess ||
+                hipEventCreateWithFlags(&coef_done[f], hipEventDisableTiming) != hipSuccess ||
+                hipEventRecord(coef_done[f], b->up_stream) != hipSuccess) { rc = CCD_ERR_HIP; break; }
+        }
+    }
     if (rc >= 0) rc = ccd_batch_wait(b, nullptr);
     mark("cool-chics decoded");
     // ---- frame reconstruction in coding order; device planes of every decoded frame are kept for references.  r06: a frame's
@@ -1879,8 +1940,10 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
                 if (!tmp.get(device, BlockPool::kDevice, need * sizeof(float))) { rc = CCD_ERR_NOMEM; break; }
                 tmp_elems = need;
             }
+            if (coef_done[f] && hipStreamWaitEvent(nullptr, coef_done[f], 0) != hipSuccess) { rc = CCD_ERR_HIP; break; }
             rc = inter_reconstruct_on(nullptr, tmp.as<float>(), fh.frame_type, d.h, d.w, d.bitdepth, d.fdt, s0.d_out, s1.d_out, refs[0],
-                                      fh.frame_type == 2 ? refs[1] : nullptr, fh.global_flow, fh.warp_filter_size, d.plane);
+                                      fh.frame_type == 2 ? refs[1] : nullptr, fh.global_flow, fh.warp_filter_size, d.plane,
+                                      coef_done[f] ? coef[f].p : nullptr);
         }
         if (rc >= 0) rc = send_frame(fh.display_index);
     }
@@ -1905,6 +1968,8 @@ int ccd_decode_video(const uint8_t* bs, size_t n, int device, ccd_video* v) {
     }
     (void)hipStreamSynchronize(copy_st);
     if (frame_done) (void)hipEventDestroy(frame_done);
+    for (hipEvent_t e : coef_done) if (e) (void)hipEventDestroy(e);
+    for (auto& c : coef) c.drop();
     (void)hipStreamSynchronize(nullptr);  // nothing may still read the blocks that go back to the pool
     for (auto& d : dev) d.own.drop();
     tmp.drop(); wide.drop();

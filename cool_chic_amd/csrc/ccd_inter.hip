@@ -143,14 +143,10 @@ __device__ __forceinline__ void ic_coeffs_t(float s, float (&coef)[NT]) {
         coef[j] = win * snc;
     }
 }
+// the N x N taps of one pixel from its coefficients (rows accumulate in ascending order per channel: the oracle's chain)
 template <int NT>
-__device__ __forceinline__ void ic_warp_pixel_t(const float* __restrict__ ref, int H, int W, int gx, int gy, float fx, float fy, int y, int x, float out[3]) {
-    const float rxf = floorf(fx), ryf = floorf(fy);
-    const float sx = fx - rxf, sy = fy - ryf;
-    const int rx = static_cast<int>(rxf), ry = static_cast<int>(ryf);
-    float cx[NT], cy[NT];
-    ic_coeffs_t<NT>(sx, cx);
-    ic_coeffs_t<NT>(sy, cy);
+__device__ __forceinline__ void ic_taps_t(const float* __restrict__ ref, int H, int W, int gx, int gy, int rx, int ry, const float (&cx)[NT],
+                                          const float (&cy)[NT], int y, int x, float out[3]) {
     constexpr int lo = -(NT / 2) + 1;
     const size_t plane = static_cast<size_t>(H) * W;
     int xs[NT];
@@ -161,7 +157,7 @@ __device__ __forceinline__ void ic_warp_pixel_t(const float* __restrict__ ref, i
     for (int i = 0; i < NT; ++i) {
         const int yy = ic_clamp(ic_clamp(y + lo + i + ry, 0, H - 1) + gy, 0, H - 1);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {  // (per channel the rows still accumulate in ascending order: the same chain as above)
+        for (int c = 0; c < 3; ++c) {
             const float* row = ref + c * plane + static_cast<size_t>(yy) * W;
             float line = 0.0f;
 #pragma unroll
@@ -171,6 +167,15 @@ __device__ __forceinline__ void ic_warp_pixel_t(const float* __restrict__ ref, i
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[c] = acc[c];
+}
+template <int NT>
+__device__ __forceinline__ void ic_warp_pixel_t(const float* __restrict__ ref, int H, int W, int gx, int gy, float fx, float fy, int y, int x, float out[3]) {
+    const float rxf = floorf(fx), ryf = floorf(fy);
+    const float sx = fx - rxf, sy = fy - ryf;
+    float cx[NT], cy[NT];
+    ic_coeffs_t<NT>(sx, cx);
+    ic_coeffs_t<NT>(sy, cy);
+    ic_taps_t<NT>(ref, H, W, gx, gy, static_cast<int>(rxf), static_cast<int>(ryf), cx, cy, y, x, out);
 }
 
 // ---- warp_filter_size 2 / 4: the Warper's native path = F.grid_sample(bilinear | bicubic, border, align_corners=True)
@@ -287,6 +292,77 @@ __global__ __launch_bounds__(256) void inter_recon_kernel(InterParams p) {
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) { const float m = a * pred[c]; p.out[c * plane + i] = m + p.residue[c * plane + i]; }
+}
+
+// ---- r06: the warp's coefficients ahead of the references.  A frame's flows (the motion cool-chic's output) are known long before
+// its references are: in a hierarchical GOP every B-frame cool-chic is decoded at ~0.5 of the I frames' chains (fewer symbols), and
+// everything then waits for the I frames.  The f64 sin / cos of the sinc window - 64 evaluations per pixel and reference pair - only
+// depend on the flows, so ccd_decode_video CAN compute them in that gap (CCD_VIDEO_COEF_MB: inter_coef8_kernel, 16 coefficients per
+// pixel and reference, 64 B) and only gather behind the references (inter_apply8_kernel).  Same functions, same operation order:
+// bit-identical to the one-kernel form.  Measured: the gather alone is 0.26 of the 0.34 ms - off by default (ccd_api.cpp).
+// coef layout: float4 [ref][4][H * W] - quad 0 / 1 = cx[0..3] / cx[4..7], quad 2 / 3 = cy: every access a coalesced 16 bytes per lane.
+__global__ __launch_bounds__(256) void inter_coef8_kernel(const float* __restrict__ motion, int H, int W, int n_refs, float4* __restrict__ coef) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t plane = static_cast<size_t>(H) * W, i = static_cast<size_t>(y) * W + x;
+    for (int r = 0; r < n_refs; ++r) {
+        const float fx = motion[(2 * r) * plane + i], fy = motion[(2 * r + 1) * plane + i];
+        const float sx = fx - floorf(fx), sy = fy - floorf(fy);
+        float cx[8], cy[8];
+        ic_coeffs_t<8>(sx, cx);
+        ic_coeffs_t<8>(sy, cy);
+        float4* o = coef + static_cast<size_t>(r) * 4 * plane + i;
+        o[0] = make_float4(cx[0], cx[1], cx[2], cx[3]);
+        o[plane] = make_float4(cx[4], cx[5], cx[6], cx[7]);
+        o[2 * plane] = make_float4(cy[0], cy[1], cy[2], cy[3]);
+        o[3 * plane] = make_float4(cy[4], cy[5], cy[6], cy[7]);
+    }
+}
+__device__ __forceinline__ void ic_warp_pixel_coef8(const float* __restrict__ ref, const float4* __restrict__ coef, size_t plane, size_t i, int H, int W, int gx,
+                                                    int gy, float fx, float fy, int y, int x, float out[3]) {
+    const float4 a = coef[i], b = coef[plane + i], c = coef[2 * plane + i], d = coef[3 * plane + i];
+    const float cx[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}, cy[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    ic_taps_t<8>(ref, H, W, gx, gy, static_cast<int>(floorf(fx)), static_cast<int>(floorf(fy)), cx, cy, y, x, out);
+}
+__global__ __launch_bounds__(256) void inter_apply8_kernel(InterParams p, const float4* __restrict__ coef) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= p.W || y >= p.H) return;
+    const size_t plane = static_cast<size_t>(p.H) * p.W, i = static_cast<size_t>(y) * p.W + x;
+    float a = p.residue[3 * plane + i] + 0.5f;
+    a = a < 0.0f ? 0.0f : (a > 1.0f ? 1.0f : a);
+    float w0[3], pred[3];
+    ic_warp_pixel_coef8(p.ref0, coef, plane, i, p.H, p.W, p.gflow[0], p.gflow[1], p.motion[i], p.motion[plane + i], y, x, w0);
+    if (p.frame_type == 2) {
+        float b = p.residue[4 * plane + i] + 0.5f;
+        b = b < 0.0f ? 0.0f : (b > 1.0f ? 1.0f : b);
+        float w1[3];
+        ic_warp_pixel_coef8(p.ref1, coef + 4 * plane, plane, i, p.H, p.W, p.gflow[2], p.gflow[3], p.motion[2 * plane + i], p.motion[3 * plane + i], y, x, w1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float t0 = b * w0[c], t1 = (1.0f - b) * w1[c]; pred[c] = t0 + t1; }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) pred[c] = w0[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const float m = a * pred[c]; p.out[c * plane + i] = m + p.residue[c * plane + i]; }
+}
+size_t inter_coef_bytes(int frame_type, int h, int w) { return static_cast<size_t>(frame_type == 2 ? 2 : 1) * 4 * h * w * sizeof(float4); }
+hipError_t launch_inter_coef8(int frame_type, int h, int w, const float* motion, void* coef, hipStream_t stream) {
+    dim3 grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(inter_coef8_kernel, grid, dim3(256), 0, stream, motion, h, w, frame_type == 2 ? 2 : 1, static_cast<float4*>(coef));
+    return hipGetLastError();
+}
+hipError_t launch_inter_apply8(int frame_type, int h, int w, const int* gflow, const float* residue, const float* motion, const float* ref0,
+                               const float* ref1, const void* coef, float* out, hipStream_t stream) {
+    InterParams p;
+    p.residue = residue; p.motion = motion; p.ref0 = ref0; p.ref1 = ref1; p.out = out;
+    p.frame_type = frame_type; p.H = h; p.W = w; p.n_taps = 8;
+    for (int i = 0; i < 4; ++i) p.gflow[i] = gflow[i];
+    dim3 grid((w + 63) / 64, (h + 3) / 4);
+    hipLaunchKernelGGL(inter_apply8_kernel, grid, dim3(256), 0, stream, p, static_cast<const float4*>(coef));
+    return hipGetLastError();
 }
 
 hipError_t launch_inter_recon(int frame_type, int h, int w, int n_taps, const int* gflow, const float* residue, const float* motion,

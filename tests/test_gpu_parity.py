@@ -520,6 +520,40 @@ def test_picture_wider_than_the_symbol_ring(gpu, oracle):
         b.close()
 
 
+def test_video_warp_coefficients_ahead_of_the_references(oracle, monkeypatch):
+    """With a scratch budget (CCD_VIDEO_COEF_MB; off by default: measured -0.6 % for 8 GB on the 1080p GOP) ccd_decode_video computes
+    the sinc-8 warp's coefficients (f64 sin / cos of the flows) as soon as a frame's motion cool-chic is decoded and only gathers
+    behind the references (ccd_inter.hip: inter_coef8_kernel + inter_apply8_kernel); without - or for frames beyond the budget, other
+    filter sizes - the one-kernel form runs.  Same planes, both the oracle's, for the 5-frame I/P/B fixture and its 3-frame relatives."""
+    from cool_chic_amd._lib import Video, check, lib
+
+    for stream in ("vid5", "vid3_hop", "vid3_ldp"):
+        bs, _, _ = load_golden(stream)
+        want = oracle.decode_video(bs)
+        got = {}
+        for label, mb in (("in_kernel", None), ("ahead", "4096"), ("in_kernel_0", "0"), ("one_frame", "1")):
+            if mb is None:
+                monkeypatch.delenv("CCD_VIDEO_COEF_MB", raising=False)
+            else:
+                monkeypatch.setenv("CCD_VIDEO_COEF_MB", mb)
+            v = Video()
+            check(lib().ccd_decode_video(bs, len(bs), 0, C.byref(v)), "ccd_decode_video")
+            try:
+                planes = []
+                for i in range(v.n_frames):
+                    f = v.frames[i]
+                    shapes = [(f.h, f.w), (f.ch, f.cw), (f.ch, f.cw)]
+                    planes.append([np.ctypeslib.as_array(f.plane[p], shape=shapes[p]).copy() for p in range(3)])
+                got[label] = planes
+            finally:
+                lib().ccd_video_free(C.byref(v))
+        for label, planes in got.items():
+            assert len(planes) == len(want)
+            for i, fr in enumerate(planes):
+                for p in range(3):
+                    assert np.array_equal(fr[p], want[i]["planes"][p]), f"{stream} {label} frame {i} plane {p}"
+
+
 def test_video_1080p_gop(gpu, oracle):
     """SURVEY 8d config 3 at full picture size (reduced GOP): the I/P/B/B/B structure, networks and headers of
     the reference-encoded `vid5` stream with its latents tiled to 1920x1080 4:2:0, re-written frame by frame.
