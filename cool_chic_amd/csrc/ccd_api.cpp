@@ -961,7 +961,8 @@ int ccd_batch_add(ccd_batch* b, const uint8_t* cc_header, size_t n_hdr, const ui
 // (b) every workgroup still finds a CU at once.  A stream's workgroup owns a CU (139 KB of LDS) and the hardware deals the
 //     workgroups of ONE launch out to the 8 XCDs round-robin: two launches of 63 + 193 workgroups put 8 + 25 on one 32-CU XCD, the
 //     33rd waits for a whole chain - 68 ms instead of 36.6 (profiles/r06/streams_in_flight_overlap_before_xcd_rule.txt; a single
-//     launch of 256 deals 32 to each): sum over launches of ceil(n / 8) <= CUs / 8, else fewer groups.
+//     launch of 256 deals 32 to each): sum over launches of ceil(n / 8) <= CUs / 8 - else the group boundaries are moved to
+//     multiples of 8 streams (c, below), else fewer groups.
 static void plan_chain_groups(const double* est, const int* inst, int n, int n_conc, int n_cu, int* cg) {
     constexpr int kXcd = 8;  // gfx950
     double est_max = 0.0;
@@ -972,20 +973,39 @@ static void plan_chain_groups(const double* est, const int* inst, int n, int n_c
         n_inst = std::max(n_inst, inst[i] + 1);
     }
     int max_cg = std::max(1, std::min(3, n_conc / std::max(1, n_inst)));
+    const auto fits = [&](int groups) {
+        int per_xcd = (n_generic + kXcd - 1) / kXcd;
+        for (int k = 0; k < n_inst; ++k)
+            for (int g = 0; g < groups; ++g) {
+                int cnt = 0;
+                for (int i = 0; i < n; ++i) cnt += (inst[i] == k && cg[i] == g) ? 1 : 0;
+                per_xcd += (cnt + kXcd - 1) / kXcd;
+            }
+        return per_xcd <= n_cu / kXcd;
+    };
     for (; max_cg >= 1; --max_cg) {
         for (int i = 0; i < n; ++i) {
             const int c = est[i] >= 0.97 * est_max ? 0 : (est[i] >= 0.80 * est_max ? 1 : 2);
             cg[i] = inst[i] < 0 ? 0 : std::min(c, max_cg - 1);
         }
-        if (max_cg == 1) break;
-        int per_xcd = (n_generic + kXcd - 1) / kXcd;
-        for (int k = 0; k < n_inst; ++k)
-            for (int g = 0; g < max_cg; ++g) {
-                int cnt = 0;
-                for (int i = 0; i < n; ++i) cnt += (inst[i] == k && cg[i] == g) ? 1 : 0;
-                per_xcd += (cnt + kXcd - 1) / kXcd;
+        if (max_cg == 1 || fits(max_cg)) break;
+        // (c) a nearly full chip: the same split with every group boundary moved to a multiple of 8 streams - the slowest streams of
+        //     the next group join the slower one (their frames are synthesised a little later, nothing else changes) - deals whole
+        //     rounds to the XCDs: 63 + 193 becomes 64 + 192 = 8 + 24 per XCD
+        for (int k = 0; k < n_inst; ++k) {
+            std::vector<int> idx;
+            for (int i = 0; i < n; ++i) if (inst[i] == k) idx.push_back(i);
+            std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return cg[x] != cg[y] ? cg[x] < cg[y] : est[x] > est[y]; });
+            int bound = 0, prev = 0;
+            for (int g = 0; g + 1 < max_cg; ++g) {
+                for (int i : idx) bound += cg[i] == g ? 1 : 0;
+                const int rounded = std::min(static_cast<int>(idx.size()), std::max(prev, (bound + kXcd - 1) / kXcd * kXcd));
+                for (int r = prev; r < rounded; ++r) cg[idx[r]] = g;
+                prev = rounded;
             }
-        if (per_xcd <= n_cu / kXcd) break;
+            for (int r = prev; r < static_cast<int>(idx.size()); ++r) cg[idx[r]] = max_cg - 1;
+        }
+        if (fits(max_cg)) break;
     }
 }
 

@@ -309,9 +309,14 @@ def test_chain_groups_plan():
     assert plan(est, [0, 1, 0, 1, 0, 1])[0] == 2
     assert plan(est, [0, 1, 2, 3, 0, 1]) == (1, [0] * 6)
     assert plan(est, [-1] * 6) == (1, [0] * 6)
-    # the XCD rule at a full chip
-    g, cg = plan([1.09] * 63 + [1.0] * 193, [0] * 256)
+    # the XCD rule at a full chip: 63 + 193 would put 8 + 25 = 33 on one XCD - the boundary moves to a multiple of 8 (the slowest
+    # landscape stream joins the portrait group): 64 + 192 = 8 + 24; where no rounding helps, fewer groups
+    g, cg = plan([1.09] * 63 + [1.0 - 1e-6 * i for i in range(193)], [0] * 256)
+    assert g == 2 and cg.count(0) == 64 and cg[63] == 0 and cg[64] == 1
+    g, cg = plan([1.09] * 63 + [1.0] * 193 + [0.5] * 3, [0] * 259)    # 259 streams: more workgroups than CUs whatever the split
     assert g == 1 and set(cg) == {0}
+    g, cg = plan([1.09] * 60 + [1.0] * 100 + [0.5] * 96, [0] * 256)   # three groups 60 / 100 / 96 -> 64 / 96 / 96
+    assert g == 3 and [cg.count(k) for k in range(3)] == [64, 96, 96]
     g, cg = plan([1.09] * 64 + [1.0] * 192, [0] * 256)   # 8 + 24 = 32 per XCD: fits exactly
     assert g == 2
     g, cg = plan([1.09] * 56 + [1.0] * 168, [0] * 224)
