@@ -541,12 +541,15 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X: there is no CPU fallback"
     if args.backend == "gloo":
         local_rank %= torch.cuda.device_count()  # ranks may share a GPU: there is no device-to-device collective to collide
+    if args.backend == "nccl" and world > 1 and torch.cuda.device_count() < world:
+        # a launcher that narrows the visibility per rank (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES: every rank sees ONE GPU as
+        # device 0): take what is visible; that the ranks really sit on N different GPUs is checked by their UUIDs below
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)  # BEFORE the communicator exists: a rank on the wrong GPU hangs at the first collective
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL P2P buffers)
         if args.backend == "nccl":
-            assert torch.cuda.device_count() >= world, f"{world} ranks over RCCL need {world} GPUs, {torch.cuda.device_count()} visible (one GPU per rank; --backend gloo shares)"
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group("gloo")
@@ -559,7 +562,12 @@ def main():
         # (host, device) of every rank: N distinct GPUs - two ranks on one device would halve the numbers silently
         import socket
         who = [None] * world
-        dist.all_gather_object(who, (socket.gethostname(), torch.cuda.current_device() if args.backend == "nccl" else rank))
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        # the physical GPU, whatever its index here (uuid + PCI address; a torch without either falls back to the rank: no check)
+        gpu_id = f"{getattr(props, 'uuid', '')}/{getattr(props, 'pci_domain_id', '')}:{getattr(props, 'pci_bus_id', '')}:{getattr(props, 'pci_device_id', '')}"
+        if gpu_id == "/::":
+            gpu_id = f"rank{rank}"
+        dist.all_gather_object(who, (socket.gethostname(), gpu_id if args.backend == "nccl" else rank))
         gpus_active = len(set(who))
         assert gpus_active == world, f"{world} ranks on {gpus_active} distinct GPUs: {who}"
     all_legs = ["clic41", "gop1080p33", "uhd4k", "wide", "png", "e2e", "float", "envelope", "rate", "kodak24_hq", "clic41_alt", "cliffs"]
